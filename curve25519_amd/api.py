@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's operator interface for the scalar-multiplication path.
+
+Function names follow the reference's C API (include/curve25519_dh.h:34-48,
+include/ed25519_signature.h:40-93); each takes N-element contiguous arrays and calls the matching
+`*_batch` (host memory, numpy) or `*_dev` (device memory, torch CUDA tensors on the current stream)
+entry point of libcurve25519_amd.so.  Nothing here computes: no numpy/torch arithmetic, no CPU
+fallback -- without the HIP library and a gfx950 device every call raises EngineError.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import EngineError  # noqa: F401  (re-export)
+
+
+def _np(a, width, name):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim == 1 and a.size == width:
+        a = a.reshape(1, width)
+    if a.ndim != 2 or a.shape[1] != width:
+        raise ValueError(f"{name} must have shape (n, {width}), got {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _msgs(msg, n):
+    msg = np.ascontiguousarray(msg, dtype=np.uint8)
+    if n == 0:
+        return msg.reshape(0, 0), 0
+    msg = msg.reshape(n, -1)
+    return msg, msg.shape[1]
+
+
+# ---- host-memory (numpy) interface ---------------------------------------------------------------
+
+def curve25519_dh_CreateSharedKey(pk, sk):
+    """n x curve25519_dh_CreateSharedKey.  Returns (shared, clamped_sk); inputs are not modified
+    (the C function clamps in place -- the clamped copy is returned instead)."""
+    pk = _np(pk, 32, "pk")
+    sk = np.array(_np(sk, 32, "sk"), copy=True)
+    if pk.shape[0] != sk.shape[0]:
+        raise ValueError("pk and sk must have the same number of rows")
+    out = np.empty_like(pk)
+    L = _lib.load()
+    _lib.check(L.curve25519_dh_CreateSharedKey_batch(_ptr(out), _ptr(pk), _ptr(sk), pk.shape[0]),
+               "curve25519_dh_CreateSharedKey_batch")
+    return out, sk
+
+
+def curve25519_dh_CalculatePublicKey(sk, fast=False):
+    """n x curve25519_dh_CalculatePublicKey (or _fast).  Returns (pk, clamped_sk)."""
+    sk = np.array(_np(sk, 32, "sk"), copy=True)
+    out = np.empty_like(sk)
+    L = _lib.load()
+    fn = L.curve25519_dh_CalculatePublicKey_fast_batch if fast else L.curve25519_dh_CalculatePublicKey_batch
+    _lib.check(fn(_ptr(out), _ptr(sk), sk.shape[0]), "curve25519_dh_CalculatePublicKey_batch")
+    return out, sk
+
+
+def ed25519_CreateKeyPair(sk):
+    """n x ed25519_CreateKeyPair(blinding=NULL).  Returns (pub[n,32], priv[n,64])."""
+    sk = _np(sk, 32, "sk")
+    n = sk.shape[0]
+    pub = np.empty((n, 32), np.uint8)
+    priv = np.empty((n, 64), np.uint8)
+    _lib.check(_lib.load().ed25519_CreateKeyPair_batch(_ptr(pub), _ptr(priv), _ptr(sk), n), "ed25519_CreateKeyPair_batch")
+    return pub, priv
+
+
+def ed25519_SignMessage(priv, msg):
+    """n x ed25519_SignMessage(blinding=NULL) over fixed-length messages msg[n, msg_size]."""
+    priv = _np(priv, 64, "priv")
+    n = priv.shape[0]
+    msg, msg_size = _msgs(msg, n)
+    sig = np.empty((n, 64), np.uint8)
+    _lib.check(_lib.load().ed25519_SignMessage_batch(_ptr(sig), _ptr(priv), _ptr(msg), msg_size, n), "ed25519_SignMessage_batch")
+    return sig
+
+
+def ed25519_VerifySignature(sig, pk, msg):
+    """n x ed25519_VerifySignature.  Returns int32[n] of 1 (valid) / 0 (invalid)."""
+    sig = _np(sig, 64, "sig")
+    pk = _np(pk, 32, "pk")
+    n = sig.shape[0]
+    if pk.shape[0] != n:
+        raise ValueError("sig and pk must have the same number of rows")
+    msg, msg_size = _msgs(msg, n)
+    ok = np.empty(n, np.int32)
+    _lib.check(_lib.load().ed25519_VerifySignature_batch(_ptr(ok), _ptr(sig), _ptr(pk), _ptr(msg), msg_size, n),
+               "ed25519_VerifySignature_batch")
+    return ok
+
+
+def base_folding8_table():
+    """(256, 3, 32) uint8: the device-generated 8-fold base table in the reference's PA_POINT row order."""
+    out = np.empty((256, 3, 32), np.uint8)
+    _lib.check(_lib.load().c25519_amd_base_table(_ptr(out)), "c25519_amd_base_table")
+    return out
+
+
+def device_count() -> int:
+    return int(_lib.load().c25519_amd_device_count())
+
+
+# ---- device-memory (torch CUDA tensors) interface --------------------------------------------------
+# torch is only plumbing here: it owns the HBM buffers and the stream.
+
+def _dev(t, width, name):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous uint8 CUDA tensor")
+    if t.dim() != 2 or t.shape[1] != width:
+        raise ValueError(f"{name} must have shape (n, {width}), got {tuple(t.shape)}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def curve25519_dh_CreateSharedKey_dev(shared, pk, sk):
+    """In-place device form: writes `shared`, clamps `sk`; asynchronous on torch's current stream."""
+    n = pk.shape[0]
+    _lib.check(_lib.load().curve25519_dh_CreateSharedKey_dev(_dev(shared, 32, "shared"), _dev(pk, 32, "pk"),
+                                                           _dev(sk, 32, "sk"), n, _stream()),
+               "curve25519_dh_CreateSharedKey_dev")
+
+
+def curve25519_dh_CalculatePublicKey_dev(pk, sk, fast=False):
+    L = _lib.load()
+    fn = L.curve25519_dh_CalculatePublicKey_fast_dev if fast else L.curve25519_dh_CalculatePublicKey_dev
+    _lib.check(fn(_dev(pk, 32, "pk"), _dev(sk, 32, "sk"), sk.shape[0], _stream()), "curve25519_dh_CalculatePublicKey_dev")
+
+
+def ed25519_CreateKeyPair_dev(pub, priv, sk):
+    _lib.check(_lib.load().ed25519_CreateKeyPair_dev(_dev(pub, 32, "pub"), _dev(priv, 64, "priv"), _dev(sk, 32, "sk"),
+                                                   sk.shape[0], _stream()), "ed25519_CreateKeyPair_dev")
+
+
+def ed25519_SignMessage_dev(sig, priv, msg):
+    n = priv.shape[0]
+    _lib.check(_lib.load().ed25519_SignMessage_dev(_dev(sig, 64, "sig"), _dev(priv, 64, "priv"),
+                                                 C.c_void_p(msg.data_ptr()), msg.shape[1] if n else 0, n, _stream()),
+               "ed25519_SignMessage_dev")
+
+
+def ed25519_VerifySignature_dev(verdict, sig, pk, msg):
+    n = sig.shape[0]
+    _lib.check(_lib.load().ed25519_VerifySignature_dev(C.c_void_p(verdict.data_ptr()), _dev(sig, 64, "sig"),
+                                                     _dev(pk, 32, "pk"), C.c_void_p(msg.data_ptr()),
+                                                     msg.shape[1] if n else 0, n, _stream()),
+               "ed25519_VerifySignature_dev")

@@ -1,0 +1,50 @@
+"""Builds the gfx950 shared library (hipcc cross-compiles without a GPU).
+
+    python -m curve25519_amd.build          # -> curve25519_amd/libcurve25519_amd.so
+
+The .so is git-ignored but travels with gpurun snapshots; it is rebuilt when any source under
+csrc/ or include/ is newer.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libcurve25519_amd.so")
+ARCH = "gfx950"
+
+
+def _sources():
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    out += [os.path.join(ROOT, "include", f) for f in sorted(os.listdir(os.path.join(ROOT, "include")))]
+    return out
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(s) > t for s in _sources())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: the gfx950 library cannot be built on this machine")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+           os.path.join(CSRC, "engine.hip"), "-o", LIB + ".tmp"]
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

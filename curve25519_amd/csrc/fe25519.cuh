@@ -1,0 +1,341 @@
+// curve25519_amd/csrc/fe25519.cuh -- GF(2^255-19) for gfx950, one field element per lane.
+//
+// Device replacement for the reference's L0 layer (source/curve25519_mehdi.c: ecp_MulReduce :278,
+// ecp_SqrReduce :310, ecp_AddReduce :134, ecp_SubReduce :161, ecp_WordMulAddReduce :243, ecp_Mod :185,
+// ecp_Inverse :340; source/ed25519_verify.c: ecp_ModExp2523 :116).  Only the bytes that leave a kernel
+// have to match the reference (they are canonical there too), so the in-register form is free.
+//
+// Representation: 5 x 51-bit limbs, each held as a (26-bit, 25-bit) pair of 32-bit VGPRs, i.e. ten
+// unsaturated limbs of radix 2^25.5.  Why not saturated 4x64 / 8x32: measured on MI355X
+// (profiles/r01_valu_rates.txt) v_mad_u64_u32 issues at ~30 T lane-op/s, barely slower than
+// v_addc_co_u32 (~35 T/s), so a saturated schoolbook product pays one carry instruction per multiply
+// AND serialises every step on VCC.  With 2^25.5 limbs a product is a pure chain of v_mad_u64_u32 into
+// ten independent 64-bit accumulators (no carries, no VCC), the x19 fold of 2^255 = 19 is absorbed by
+// pre-scaling one operand, and add/sub are ten plain v_add_u32 / v_sub_u32.
+//
+// Bound contract (beta = limb / 2^w, w = 26 for even limbs, 25 for odd):
+//   reduced          : output of mul / sqr / mul121665_add / from_bytes, limb < 2^w + 2^17
+//   fe_add(a,b)      : beta_a + beta_b
+//   fe_sub(a,b)      : beta_a + 2   (adds 2p limb-wise; needs b reduced)
+//   fe_mul(a,b)      : needs beta_a <= 5, beta_b <= 3.3 (19*b_j and 2*a_i must fit 32 bits and every
+//                      column sum must stay below 2^64: 124.5 * beta_a * beta_b * 2^52 < 2^64)
+//   fe_sqr(a)        : needs beta_a <= 3.3
+// tools/fe_bounds.py replays every formula in the kernels against this contract.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace c25519 {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define C25519_DEV __device__ __forceinline__
+
+constexpr u32 M26 = 0x3ffffffu;
+constexpr u32 M25 = 0x1ffffffu;
+
+struct fe { u32 v[10]; };
+
+C25519_DEV constexpr int fe_w(int i) { return (i & 1) ? 25 : 26; }
+C25519_DEV constexpr u32 fe_mask(int i) { return (i & 1) ? M25 : M26; }
+// limbs of 2p: every limb stays >= 0 after subtracting a reduced element
+C25519_DEV constexpr u32 fe_2p(int i) { return i == 0 ? 0x7ffffdau : ((i & 1) ? 0x3fffffeu : 0x7fffffeu); }
+
+C25519_DEV void fe_set_u32(fe& r, u32 x)
+{
+#pragma unroll
+    for (int i = 1; i < 10; i++) r.v[i] = 0;
+    r.v[0] = x;
+}
+
+C25519_DEV void fe_add(fe& r, const fe& a, const fe& b)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + b.v[i];
+}
+
+// r = a - b + 2p  (b must be reduced so that no limb goes negative)
+C25519_DEV void fe_sub(fe& r, const fe& a, const fe& b)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + fe_2p(i) - b.v[i];
+}
+
+// r = 2p - a   (the reference negates with _w_maxP - A, ed25519_sign.c:130)
+C25519_DEV void fe_neg(fe& r, const fe& a)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = fe_2p(i) - a.v[i];
+}
+
+// branch-free select: r = mask ? a : b, mask is all-ones or zero (v_bfi_b32)
+C25519_DEV void fe_select(fe& r, u32 mask, const fe& a, const fe& b)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = (a.v[i] & mask) | (b.v[i] & ~mask);
+}
+
+// Sequential carry of ten 64-bit column sums into reduced limbs; the carry out of limb 9 re-enters
+// limb 0 times 19 (2^255 = 19 mod p).  Columns may be as large as 2^64-1.
+C25519_DEV void fe_carry64(fe& r, u64 (&h)[10])
+{
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        h[i + 1] += h[i] >> fe_w(i);
+        h[i] &= fe_mask(i);
+    }
+    u64 c = h[9] >> 25;
+    h[9] &= M25;
+    h[0] += c * 19;
+    h[1] += h[0] >> 26;
+    h[0] &= M26;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = (u32)h[i];
+}
+
+// r = a * b.   beta_a <= 5, beta_b <= 3.3; r may alias a or b.   (ecp_MulReduce)
+C25519_DEV void fe_mul(fe& r, const fe& a, const fe& b)
+{
+    u32 b19[10], a2[10];
+#pragma unroll
+    for (int j = 1; j < 10; j++) b19[j] = b.v[j] * 19u;
+#pragma unroll
+    for (int i = 1; i < 10; i += 2) a2[i] = a.v[i] * 2u;
+
+    u64 h[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        u64 acc = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            const bool wrap = i > k;                       // i + j = k + 10
+            const bool odd2 = (i & 1) && (j & 1);          // 2^25.5 radix: odd*odd picks up a factor 2
+            const u32 x = odd2 ? a2[i] : a.v[i];
+            const u32 y = wrap ? b19[j] : b.v[j];
+            acc += (u64)x * y;
+        }
+        h[k] = acc;
+    }
+    fe_carry64(r, h);
+}
+
+// column sums of a^2 (55 products instead of 100).   beta_a <= 3.3
+C25519_DEV void fe_sqr_columns(u64 (&h)[10], const fe& a)
+{
+    u32 f2[10], f19[10], f38[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) f2[i] = a.v[i] * 2u;
+#pragma unroll
+    for (int j = 5; j < 10; j++) f19[j] = a.v[j] * 19u;
+#pragma unroll
+    for (int j = 5; j < 10; j += 2) f38[j] = a.v[j] * 38u;
+
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        u64 acc = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            if (i > j) continue;                           // each unordered pair once
+            const bool wrap = (i + j) >= 10;
+            const bool odd2 = (i & 1) && (j & 1);
+            const u32 x = (i < j) ? f2[i] : a.v[i];        // cross terms doubled
+            const u32 y = odd2 ? (wrap ? f38[j] : f2[j]) : (wrap ? f19[j] : a.v[j]);
+            acc += (u64)x * y;
+        }
+        h[k] = acc;
+    }
+}
+
+// r = a^2.   beta_a <= 3.3; r may alias a.   (ecp_SqrReduce)
+C25519_DEV void fe_sqr(fe& r, const fe& a)
+{
+    u64 h[10];
+    fe_sqr_columns(h, a);
+    fe_carry64(r, h);
+}
+
+// r = a^2 - m with the subtraction folded into the carry chain (result reduced).
+// beta_a <= 3.3, beta_m <= 2 (bias 4p).
+C25519_DEV void fe_sqr_sub(fe& r, const fe& a, const fe& m)
+{
+    u64 h[10];
+    fe_sqr_columns(h, a);
+#pragma unroll
+    for (int i = 0; i < 10; i++) h[i] += (u64)(2u * fe_2p(i) - m.v[i]);
+    fe_carry64(r, h);
+}
+
+// r = 2*a^2 + p - m, folded into the carry chain (result reduced).
+// beta_a <= 2.3 (columns are doubled), p any beta < 8, m reduced (bias 2p).
+C25519_DEV void fe_sqr2_add_sub(fe& r, const fe& a, const fe& p, const fe& m)
+{
+    u64 h[10];
+    fe_sqr_columns(h, a);
+#pragma unroll
+    for (int i = 0; i < 10; i++) h[i] = 2 * h[i] + (u64)(p.v[i] + fe_2p(i) - m.v[i]);
+    fe_carry64(r, h);
+}
+
+C25519_DEV void fe_sqr_n(fe& r, const fe& a, int n)
+{
+    fe_sqr(r, a);
+    for (int i = 1; i < n; i++) fe_sqr(r, r);
+}
+
+// r = a + 121665 * b   (ecp_WordMulAddReduce with a24, curve25519_dh.c:53,:81); any beta, reduced out
+C25519_DEV void fe_mul121665_add(fe& r, const fe& a, const fe& b)
+{
+    u64 h[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) h[i] = (u64)b.v[i] * 121665u + a.v[i];
+    fe_carry64(r, h);
+}
+
+// one carry pass over 32-bit limbs: brings any beta < 2^6 back to reduced
+C25519_DEV void fe_carry32(fe& r, const fe& a)
+{
+    u32 h[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) h[i] = a.v[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        h[i + 1] += h[i] >> fe_w(i);
+        h[i] &= fe_mask(i);
+    }
+    u32 c = h[9] >> 25;
+    h[9] &= M25;
+    h[0] += c * 19u;
+    h[1] += h[0] >> 26;
+    h[0] &= M26;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = h[i];
+}
+
+// 256-bit little-endian words -> limbs.  All 256 bits are used: bit 255 counts as 2^255 = 19 mod p
+// (the reference does not mask it, curve25519_dh.c:104 / SURVEY.md 3.5).
+C25519_DEV void fe_from_words(fe& r, const u32 (&w)[8])
+{
+    r.v[0] = (w[0] & M26) + 19u * (w[7] >> 31);
+    r.v[1] = __builtin_amdgcn_alignbit(w[1], w[0], 26) & M25;
+    r.v[2] = __builtin_amdgcn_alignbit(w[2], w[1], 19) & M26;
+    r.v[3] = __builtin_amdgcn_alignbit(w[3], w[2], 13) & M25;
+    r.v[4] = w[3] >> 6;
+    r.v[5] = w[4] & M25;
+    r.v[6] = __builtin_amdgcn_alignbit(w[5], w[4], 25) & M26;
+    r.v[7] = __builtin_amdgcn_alignbit(w[6], w[5], 19) & M25;
+    r.v[8] = __builtin_amdgcn_alignbit(w[7], w[6], 12) & M26;
+    r.v[9] = (w[7] >> 6) & M25;
+}
+
+// same conversion with plain shifts, usable on compile-time constants (folds to immediates)
+C25519_DEV constexpr fe fe_const(const u32 (&w)[8])
+{
+    fe r{};
+    const u64 w01 = ((u64)w[1] << 32) | w[0], w12 = ((u64)w[2] << 32) | w[1], w23 = ((u64)w[3] << 32) | w[2];
+    const u64 w45 = ((u64)w[5] << 32) | w[4], w56 = ((u64)w[6] << 32) | w[5], w67 = ((u64)w[7] << 32) | w[6];
+    r.v[0] = (w[0] & M26) + 19u * (w[7] >> 31);
+    r.v[1] = (u32)(w01 >> 26) & M25;
+    r.v[2] = (u32)(w12 >> 19) & M26;
+    r.v[3] = (u32)(w23 >> 13) & M25;
+    r.v[4] = w[3] >> 6;
+    r.v[5] = w[4] & M25;
+    r.v[6] = (u32)(w45 >> 25) & M26;
+    r.v[7] = (u32)(w56 >> 19) & M25;
+    r.v[8] = (u32)(w67 >> 12) & M26;
+    r.v[9] = (w[7] >> 6) & M25;
+    return r;
+}
+
+// limbs -> canonical value in [0, p) as 256-bit little-endian words   (ecp_Mod + ecp_WordsToBytes)
+C25519_DEV void fe_to_words(u32 (&w)[8], const fe& a)
+{
+    u32 h[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) h[i] = a.v[i];
+    // two full carry passes: afterwards every limb is strictly below 2^w, value < 2^255
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            h[i + 1] += h[i] >> fe_w(i);
+            h[i] &= fe_mask(i);
+        }
+        u32 c = h[9] >> 25;
+        h[9] &= M25;
+        h[0] += c * 19u;
+    }
+    // h0 may now be up to 2^26 + 18: one more ripple of a single possible carry
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        h[i + 1] += h[i] >> fe_w(i);
+        h[i] &= fe_mask(i);
+    }
+    // (h9 cannot overflow here: it was < 2^25 and the ripple only happens when the lower limbs were
+    //  all-ones, in which case the earlier wrap left h0 small)  -- still fold defensively
+    {
+        u32 c = h[9] >> 25;
+        h[9] &= M25;
+        h[0] += c * 19u;
+    }
+    // q = 1 iff value >= p  <=>  value + 19 >= 2^255
+    u32 q = (h[0] + 19u) >> 26;
+#pragma unroll
+    for (int i = 1; i < 10; i++) q = (h[i] + q) >> fe_w(i);
+    h[0] += 19u * q;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        h[i + 1] += h[i] >> fe_w(i);
+        h[i] &= fe_mask(i);
+    }
+    h[9] &= M25;                                           // drops 2^255 * q
+
+    w[0] = h[0] | (h[1] << 26);
+    w[1] = (h[1] >> 6) | (h[2] << 19);
+    w[2] = (h[2] >> 13) | (h[3] << 13);
+    w[3] = (h[3] >> 19) | (h[4] << 6);
+    w[4] = h[5] | (h[6] << 25);
+    w[5] = (h[6] >> 7) | (h[7] << 19);
+    w[6] = (h[7] >> 13) | (h[8] << 12);
+    w[7] = (h[8] >> 20) | (h[9] << 6);
+}
+
+// x^(2^250 - 1) and x^11: shared front of the two fixed addition chains (254 S + 11 M in total,
+// the same operation count as ecp_Inverse :340-409 / ecp_ModExp2523 :116-135)
+C25519_DEV void fe_chain250(fe& x250, fe& x11, const fe& x)
+{
+    fe x2, x9, x5, x10, x20, x50, x100, t;
+    fe_sqr(x2, x);
+    fe_sqr_n(t, x2, 2);   fe_mul(x9, t, x);
+    fe_mul(x11, x9, x2);
+    fe_sqr(t, x11);       fe_mul(x5, t, x9);
+    fe_sqr_n(t, x5, 5);   fe_mul(x10, t, x5);
+    fe_sqr_n(t, x10, 10); fe_mul(x20, t, x10);
+    fe_sqr_n(t, x20, 20); fe_mul(t, t, x20);
+    fe_sqr_n(t, t, 10);   fe_mul(x50, t, x10);
+    fe_sqr_n(t, x50, 50); fe_mul(x100, t, x50);
+    fe_sqr_n(t, x100, 100); fe_mul(t, t, x100);
+    fe_sqr_n(t, t, 50);   fe_mul(x250, t, x50);
+}
+
+// r = z^(p-2); z = 0 gives 0 (what makes low-order X25519 inputs come out as all-zero bytes)
+C25519_DEV void fe_invert(fe& r, const fe& z)
+{
+    fe x250, x11;
+    fe_chain250(x250, x11, z);
+    fe_sqr_n(x250, x250, 5);
+    fe_mul(r, x250, x11);
+}
+
+// r = x^((p-5)/8) = x^(2^252 - 3)
+C25519_DEV void fe_pow2523(fe& r, const fe& x)
+{
+    fe x250, x11;
+    fe_chain250(x250, x11, x);
+    fe_sqr_n(x250, x250, 2);
+    fe_mul(r, x250, x);
+}
+
+}  // namespace c25519

@@ -1,0 +1,291 @@
+// curve25519_amd/csrc/ge25519.cuh -- twisted-Edwards (a = -1) point arithmetic in extended coordinates,
+// one point per lane, and the fixed-base walks built on it.
+//
+// Device replacement for the reference's L1/L2 Edwards layer:
+//   edp_DoublePoint (source/ed25519_sign.c:122), edp_AddAffinePoint (:97), edp_AddPoint
+//   (source/ed25519_verify.c:142), edp_ExtPoint2PE (ed25519_sign.c:270), edp_BasePointMult (:215),
+//   ed25519_CalculateX (ed25519_verify.c:66), the q_table build of ed25519_Verify_Init (:179-232) and
+//   edp_PolyPointMultiply (:243-280).
+// The formulas are the reference's (Hisil et al. 2008/522); where the unsigned-limb bound contract of
+// fe25519.cuh needs it, a sub-expression is negated consistently ((X:Y:Z:T) and (-X:-Y:-Z:-T) are the
+// same point) or folded into a squaring's carry chain.  Outputs leave through a field inversion and a
+// canonical encoding, so they are byte-identical to the reference.
+#pragma once
+#include "curve_constants.cuh"
+#include "fe25519.cuh"
+#include "sc25519.cuh"
+
+namespace c25519 {
+
+struct ge_ext { fe X, Y, Z, T; };                 // x = X/Z, y = Y/Z, T = XY/Z; all four reduced
+struct ge_pa  { fe ypx, ymx, t2d; };              // affine precomputed: y+x, y-x, 2d*x*y   (PA_POINT)
+struct ge_pe  { fe ypx, ymx, t2d, z2; };          // projective precomputed, + 2Z               (PE_POINT)
+
+constexpr int PA_WORDS = 30;                      // limbs per table row
+constexpr int PE_WORDS = 40;
+
+// p = 2p.  In: X, Y, Z reduced.  Out: all reduced.  4S + 4M.
+//   reference: A=X^2 B=Y^2 C=2Z^2 D=-A H=D-B G=D+B F=G-C E=(X+Y)^2+H ; X3=EF Y3=HG Z3=GF T3=EH
+//   here:      Hn=-H=A+B, Fn=-F=2Z^2+A-B  (both negated -> all four outputs negated: same point)
+C25519_DEV void ge_double(ge_ext& p)
+{
+    fe A, B, Hn, G, E, Fn, t;
+    fe_sqr(A, p.X);
+    fe_sqr(B, p.Y);
+    fe_add(Hn, A, B);                    // beta 2
+    fe_sub(G, B, A);                     // beta 3
+    fe_add(t, p.X, p.Y);                 // beta 2
+    fe_sqr_sub(E, t, Hn);                // (X+Y)^2 - A - B, reduced
+    fe_sqr2_add_sub(Fn, p.Z, A, B);      // 2Z^2 + A - B, reduced
+    fe_mul(p.X, E, Fn);
+    fe_mul(p.Y, G, Hn);
+    fe_mul(p.Z, G, Fn);
+    fe_mul(p.T, E, Hn);
+}
+
+// p = p + q, q affine precomputed with reduced limbs.  7M.   (edp_AddAffinePoint)
+C25519_DEV void ge_add_pa(ge_ext& p, const ge_pa& q)
+{
+    fe a, b, c, d, e, f, g, h;
+    fe_sub(a, p.Y, p.X);                 // beta 3
+    fe_mul(a, a, q.ymx);
+    fe_add(b, p.Y, p.X);                 // beta 2
+    fe_mul(b, b, q.ypx);
+    fe_mul(c, p.T, q.t2d);
+    fe_add(d, p.Z, p.Z);                 // beta 2
+    fe_sub(e, b, a);                     // E = B-A   beta 3
+    fe_add(h, b, a);                     // H = B+A   beta 2
+    fe_sub(f, d, c);                     // F = D-C   beta 4
+    fe_add(g, d, c);                     // G = D+C   beta 3
+    fe_mul(p.X, f, e);
+    fe_mul(p.Y, g, h);
+    fe_mul(p.T, e, h);
+    fe_mul(p.Z, f, g);
+}
+
+// r = p + q, q projective precomputed with reduced limbs.  8M.   (edp_AddPoint)
+C25519_DEV void ge_add_pe(ge_ext& r, const ge_ext& p, const ge_pe& q)
+{
+    fe a, b, c, d, e, f, g, h;
+    fe_sub(a, p.Y, p.X);
+    fe_mul(a, a, q.ymx);
+    fe_add(b, p.Y, p.X);
+    fe_mul(b, b, q.ypx);
+    fe_mul(c, p.T, q.t2d);
+    fe_mul(d, p.Z, q.z2);
+    fe_sub(e, b, a);                     // beta 3
+    fe_add(h, b, a);                     // beta 2
+    fe_sub(f, d, c);                     // beta 3
+    fe_add(g, d, c);                     // beta 2
+    fe_mul(r.X, e, f);
+    fe_mul(r.Y, g, h);
+    fe_mul(r.T, e, h);
+    fe_mul(r.Z, f, g);
+}
+
+// r = precomputed form of p, every limb reduced (so table entries can feed fe_sub / fe_mul freely)
+C25519_DEV void ge_to_pe(ge_pe& r, const ge_ext& p)
+{
+    fe t;
+    fe_add(t, p.Y, p.X);  fe_carry32(r.ypx, t);
+    fe_sub(t, p.Y, p.X);  fe_carry32(r.ymx, t);
+    fe_mul(r.t2d, p.T, fe_const(K_2D));
+    fe_add(t, p.Z, p.Z);  fe_carry32(r.z2, t);
+}
+
+// extended point from a precomputed row: (2x, 2y, 2z, 2xy) -- ed25519_sign.c:226-230 / ed25519_verify.c:258-262
+C25519_DEV void ge_from_pa(ge_ext& s, const ge_pa& q)
+{
+    fe t;
+    fe_sub(t, q.ypx, q.ymx);  fe_carry32(s.X, t);
+    fe_add(t, q.ypx, q.ymx);  fe_carry32(s.Y, t);
+    fe_mul(s.T, q.t2d, fe_const(K_DI));
+    fe_set_u32(s.Z, 2);                            // Z = 2R with R = 1 (the reference's random R is output-neutral)
+}
+
+C25519_DEV void ge_from_pe(ge_ext& s, const ge_pe& q)
+{
+    fe t;
+    fe_sub(t, q.ypx, q.ymx);  fe_carry32(s.X, t);
+    fe_add(t, q.ypx, q.ymx);  fe_carry32(s.Y, t);
+    fe_mul(s.T, q.t2d, fe_const(K_DI));
+    s.Z = q.z2;
+}
+
+// x from y with the requested parity: sqrt((y^2-1)/(d y^2+1)); like the reference there is NO
+// on-curve rejection -- a non-square input just yields whatever the formula yields.   (ed25519_CalculateX)
+C25519_DEV void ge_calc_x(fe& X, const fe& Y, u32 parity)
+{
+    fe u, v, a, b, t;
+    fe one;
+    fe_set_u32(one, 1);
+    fe_sqr(u, Y);
+    fe_mul(v, u, fe_const(K_D));
+    fe_sub(t, u, one);  fe_carry32(u, t);            // u = y^2 - 1, reduced
+    v.v[0] += 1;                                     // v = d y^2 + 1
+
+    fe_sqr(b, v);
+    fe_mul(a, u, b);
+    fe_mul(a, a, v);                                 // a = u v^3
+    fe_sqr(b, b);                                    // v^4
+    fe_mul(b, a, b);                                 // u v^7
+    fe_pow2523(b, b);
+    fe_mul(X, b, a);
+
+    fe_sqr(b, X);                                    // is v x^2 == u ?
+    fe_mul(b, b, v);
+    fe_sub(b, b, u);
+    u32 bw[8];
+    fe_to_words(bw, b);
+    u32 nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) nz |= bw[i];
+    fe_mul(t, X, fe_const(K_SQRTM1));
+    fe_select(X, nz ? 0xffffffffu : 0u, t, X);       // :92-93
+
+    u32 xw[8];
+    fe_to_words(xw, X);                              // canonical, to read the parity (:95-99)
+    fe_neg(t, X);
+    fe_select(t, ((xw[0] ^ parity) & 1u) ? 0xffffffffu : 0u, t, X);
+    fe_carry32(X, t);
+}
+
+// ---- 8-fold base table, staged in LDS ------------------------------------------------------------
+// LDS layout is limb-major: word w of row k sits at tbl[w * 256 + k], so the 64 secret row indices of
+// a wave spread over the banks instead of marching down one 96-byte row.
+C25519_DEV void lds_load_pa(ge_pa& q, const u32* tbl, u32 row)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        q.ypx.v[i] = tbl[(i) * 256 + row];
+        q.ymx.v[i] = tbl[(10 + i) * 256 + row];
+        q.t2d.v[i] = tbl[(20 + i) * 256 + row];
+    }
+}
+
+// cooperative copy of the device-resident limb table into this workgroup's LDS
+C25519_DEV void lds_stage_base_table(u32* lds_tbl, const u32* __restrict__ g_tbl)
+{
+    const uint4* src = reinterpret_cast<const uint4*>(g_tbl);
+    uint4* dst = reinterpret_cast<uint4*>(lds_tbl);
+    for (int i = threadIdx.x; i < PA_WORDS * 256 / 4; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// S = k * B by the 8-fold walk: S = T[c0]; S = 2S + T[cn], n = 1..31.   k (8 words) is consumed.
+C25519_DEV void ge_base_mult(ge_ext& S, u32 (&k)[8], const u32* lds_tbl)
+{
+    ge_pa q;
+    lds_load_pa(q, lds_tbl, fold8_next(k));
+    ge_from_pa(S, q);
+#pragma unroll 1
+    for (int n = 1; n < 32; n++) {
+        ge_double(S);
+        lds_load_pa(q, lds_tbl, fold8_next(k));
+        ge_add_pa(S, q);
+    }
+}
+
+// affine canonical words of S: x = X/Z, y = Y/Z   (tail of edp_BasePointMultiply, ed25519_sign.c:265-267)
+C25519_DEV void ge_to_affine_words(u32 (&xw)[8], u32 (&yw)[8], const ge_ext& S)
+{
+    fe zi, t;
+    fe_invert(zi, S.Z);
+    fe_mul(t, S.X, zi);  fe_to_words(xw, t);
+    fe_mul(t, S.Y, zi);  fe_to_words(yw, t);
+}
+
+// ed25519_PackPoint / ecp_EncodeInt (curve25519_utils.c:77-98): y with the parity of x in bit 255
+C25519_DEV void ge_pack(u32 (&out)[8], const u32 (&xw)[8], const u32 (&yw)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = yw[i];
+    out[7] = (yw[7] & 0x7fffffffu) | (xw[0] << 31);
+}
+
+// ---- per-lane 4-fold table in global scratch --------------------------------------------------------
+// One 16-row table of PE points per lane: 16 * 40 limbs.  A wave's tables are interleaved so that a
+// 16-byte access by 64 lanes is one contiguous KiB:  word (e, g, lane, c) at ((e*10 + g)*64 + lane)*4 + c,
+// g = limb group of four, c = limb in group.  160 KiB per wave.
+constexpr size_t QTABLE_WORDS_PER_WAVE = 16 * PE_WORDS * 64;
+
+C25519_DEV void qtable_store(u32* wave_tbl, u32 lane, int e, const ge_pe& q)
+{
+    uint4* base = reinterpret_cast<uint4*>(wave_tbl) + (size_t)e * 10 * 64 + lane;
+    const fe* f[4] = { &q.ypx, &q.ymx, &q.t2d, &q.z2 };
+    u32 w[PE_WORDS];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 10; i++) w[10 * j + i] = f[j]->v[i];
+#pragma unroll
+    for (int g = 0; g < 10; g++) base[g * 64] = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
+}
+
+C25519_DEV void qtable_load(ge_pe& q, const u32* wave_tbl, u32 lane, u32 e)
+{
+    const uint4* base = reinterpret_cast<const uint4*>(wave_tbl) + (size_t)e * 10 * 64 + lane;
+    u32 w[PE_WORDS];
+#pragma unroll
+    for (int g = 0; g < 10; g++) {
+        const uint4 v = base[g * 64];
+        w[4 * g] = v.x; w[4 * g + 1] = v.y; w[4 * g + 2] = v.z; w[4 * g + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        q.ypx.v[i] = w[i]; q.ymx.v[i] = w[10 + i]; q.t2d.v[i] = w[20 + i]; q.z2.v[i] = w[30 + i];
+    }
+}
+
+// q_table[k] = sum over set bits i of k of 2^(64 i) * Q, k = 0..15   (ed25519_Verify_Init :199-229)
+C25519_DEV void qtable_build(u32* wave_tbl, u32 lane, ge_ext& Q)
+{
+    ge_pe pe;
+    ge_ext T;
+    fe_set_u32(pe.ypx, 1); fe_set_u32(pe.ymx, 1); fe_set_u32(pe.t2d, 0); fe_set_u32(pe.z2, 2);
+    qtable_store(wave_tbl, lane, 0, pe);
+    ge_to_pe(pe, Q);
+    qtable_store(wave_tbl, lane, 1, pe);
+
+#pragma unroll 1
+    for (int blk = 1; blk < 4; blk++) {               // Q <- 2^64 Q, then fill rows [2^blk, 2^(blk+1))
+#pragma unroll 1
+        for (int i = 0; i < 64; i++) ge_double(Q);
+        const int top = 1 << blk;
+        ge_to_pe(pe, Q);
+        qtable_store(wave_tbl, lane, top, pe);
+#pragma unroll 1
+        for (int s = 1; s < top; s++) {               // row top+s = Q + row s   (QTABLE_SET, :175-177)
+            qtable_load(pe, wave_tbl, lane, (u32)s);
+            ge_add_pe(T, Q, pe);
+            ge_to_pe(pe, T);
+            qtable_store(wave_tbl, lane, top + s, pe);
+        }
+    }
+}
+
+// S = s*B + h*Q by the interleaved 4-fold / 8-fold walk   (edp_PolyPointMultiply :243-280).
+// s and h (8 words each) are consumed.
+C25519_DEV void ge_poly_mult(ge_ext& S, u32 (&s)[8], u32 (&h)[8], const u32* wave_tbl, u32 lane, const u32* lds_tbl)
+{
+    ge_pe pe;
+    ge_pa pa;
+    qtable_load(pe, wave_tbl, lane, fold4_next(h, false));
+    ge_from_pe(S, pe);
+#pragma unroll 1
+    for (int i = 1; i < 32; i++) {
+        ge_double(S);
+        qtable_load(pe, wave_tbl, lane, fold4_next(h, false));
+        ge_add_pe(S, S, pe);
+    }
+#pragma unroll 1
+    for (int i = 32; i < 64; i++) {
+        ge_double(S);
+        lds_load_pa(pa, lds_tbl, fold8_next(s));
+        ge_add_pa(S, pa);
+        qtable_load(pe, wave_tbl, lane, fold4_next(h, true));
+        ge_add_pe(S, S, pe);
+    }
+}
+
+}  // namespace c25519

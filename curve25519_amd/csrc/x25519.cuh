@@ -1,0 +1,98 @@
+// curve25519_amd/csrc/x25519.cuh -- variable-base Montgomery ladder, one keypair per lane.
+//
+// Device replacement for ecp_PointMultiply (source/curve25519_dh.c:94-157) as reached through
+// curve25519_dh_CreateSharedKey (:201-208) and curve25519_dh_CalculatePublicKey (:191-198):
+//   * the secret key is clamped (ecp_TrimSecretKey, curve25519_utils.c:28) and the clamped bytes are
+//     written back, because the reference clamps in the caller's buffer;
+//   * all 256 bits of the peer public key are used, reduced mod p (no masking of bit 255, no
+//     low-order rejection: those inputs produce 32 zero bytes exactly like the reference);
+//   * after clamping the top set bit is always bit 254, so the ladder is 254 fixed steps;
+//   * the reference's random projective Z (:123) is output-neutral; Z = 1 here.
+//
+// The reference selects (P,Q) by pointer swap (ECP_MONT, :89).  Here the differential addition is
+// symmetric in its two inputs, so the state is kept as (S = sum, D = double) and only the INPUT OF
+// THE DOUBLING is selected per bit with v_bfi_b32 -- 20 selects per step instead of a 40-limb swap,
+// no secret-dependent branch or address.
+#pragma once
+#include "fe25519.cuh"
+
+namespace c25519 {
+
+// one ladder step.  prev_eq = all-ones when this bit equals the previous one.
+//   S' = S + D (difference = base),  D' = 2 * (prev_eq ? D : S)
+C25519_DEV void ladder_step(fe& SX, fe& SZ, fe& DX, fe& DZ, const fe& base, u32 prev_eq)
+{
+    fe A, B, C, Dp, P, M;
+    fe_sub(A, SX, SZ);                 // beta 3
+    fe_add(B, SX, SZ);                 // beta 2
+    fe_sub(C, DX, DZ);                 // beta 3
+    fe_add(Dp, DX, DZ);                // beta 2
+    fe_select(P, prev_eq, Dp, B);      // doubling input, x+z
+    fe_select(M, prev_eq, C, A);       // doubling input, x-z
+
+    fe_mul(A, A, Dp);                  // (x1-z1)(x2+z2)
+    fe_mul(B, C, B);                   // (x2-z2)(x1+z1)
+    fe_add(C, A, B);                   // beta 2
+    fe_sub(B, A, B);                   // beta 3
+    fe_sqr(SX, C);                     // x3
+    fe_sqr(A, B);
+    fe_mul(SZ, A, base);               // z3 = (..)^2 * xb
+
+    fe_sqr(A, P);                      // (x+z)^2
+    fe_sqr(B, M);                      // (x-z)^2
+    fe_mul(DX, A, B);                  // x4
+    fe_sub(B, A, B);                   // beta 3
+    fe_mul121665_add(A, A, B);         // (x+z)^2 + 121665*B
+    fe_mul(DZ, B, A);                  // z4
+}
+
+// out = clamp(k) * (u : 1), x-only.  k_words are the CLAMPED scalar words.
+C25519_DEV void x25519_ladder(u32 (&out)[8], const u32 (&u)[8], const u32 (&k)[8])
+{
+    fe X1, SX, SZ, DX, DZ;
+    fe_from_words(X1, u);
+
+    // P = (X1 : 1), Q = 2P  (curve25519_dh.c:123-125 with zr = 1); bit 254 is the leading one
+    SX = X1;
+    fe_set_u32(SZ, 1);
+    {
+        fe A, B;
+        fe_add(A, SX, SZ);
+        fe_sub(B, SX, SZ);
+        fe_sqr(A, A);
+        fe_sqr(B, B);
+        fe_mul(DX, A, B);
+        fe_sub(B, A, B);
+        fe_mul121665_add(A, A, B);
+        fe_mul(DZ, B, A);
+    }
+
+    // state invariant: previous bit b_prev = 1  <=>  (P,Q) = (S,D); else (P,Q) = (D,S)
+    u32 prev = 1;
+#pragma unroll 1
+    for (int w = 7; w >= 0; w--) {
+        u32 kw = k[0];
+#pragma unroll
+        for (int t = 1; t < 8; t++) kw = (w == t) ? k[t] : kw;
+        const int top = (w == 7) ? 29 : 31;              // bit 254 consumed above, bit 255 is zero
+        kw <<= (31 - top);
+#pragma unroll 1
+        for (int b = top; b >= 0; b--) {
+            const u32 bit = kw >> 31;
+            kw <<= 1;
+            const u32 eq = (u32)0 - (u32)(bit == prev);
+            ladder_step(SX, SZ, DX, DZ, X1, eq);
+            prev = bit;
+        }
+    }
+    // P = PP[1] is what the reference converts (:148-150): P = S if the last bit was 1, else D
+    const u32 m = (u32)0 - prev;
+    fe PX, PZ;
+    fe_select(PX, m, SX, DX);
+    fe_select(PZ, m, SZ, DZ);
+    fe_invert(PZ, PZ);
+    fe_mul(PX, PX, PZ);
+    fe_to_words(out, PX);
+}
+
+}  // namespace c25519

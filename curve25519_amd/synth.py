@@ -1,0 +1,65 @@
+"""Deterministic synthetic inputs for the BASELINE.json configs.
+
+One splitmix64 stream per array, little-endian bytes; the same stream is implemented in C by
+oracle/orc_sc.c:orc_fill_random so fixtures, the CPU baseline and the GPU path all see identical
+bytes.  Pure numpy -- no dependency on the oracle or on the HIP library.
+"""
+import numpy as np
+
+GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+
+# fixed seeds of the benchmark configurations
+SEED_X25519_SK = 0x5eed0001
+SEED_X25519_PK = 0x5eed0002
+SEED_ED_SK = 0x5eed0003
+SEED_ED_MSG = 0x5eed0004
+SEED_ED_CORRUPT = 0x5eed0005
+
+
+def random_bytes(shape, seed: int) -> np.ndarray:
+    """uint8 array of `shape` filled from splitmix64(seed)."""
+    n = int(np.prod(shape))
+    words = (n + 7) // 8
+    with np.errstate(over="ignore"):
+        s = np.uint64(seed) + GOLDEN * np.arange(1, words + 1, dtype=np.uint64)
+        z = s
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z.astype("<u8").view(np.uint8)[:n].reshape(shape).copy()
+
+
+def x25519_inputs(n: int):
+    """(sk, pk): n x 32 uniform bytes each.  pk bit 255 is deliberately NOT masked."""
+    return random_bytes((n, 32), SEED_X25519_SK), random_bytes((n, 32), SEED_X25519_PK)
+
+
+def ed25519_inputs(n: int, msg_size: int = 32):
+    """(sk32, msg): secret seeds and fixed-length messages."""
+    return random_bytes((n, 32), SEED_ED_SK), random_bytes((n, msg_size), SEED_ED_MSG)
+
+
+def corrupt_for_verify(sig: np.ndarray, msg: np.ndarray):
+    """Config 4's 1/64 sprinkle of bad entries: returns (sig', msg', expected_bad_mask).
+
+    Entry i is corrupted when the low 6 bits of its control byte are zero; bits 6..7 choose what
+    gets one bit flipped: 0/3 -> message, 1 -> R half of the signature, 2 -> S half.
+    """
+    n = sig.shape[0]
+    ctl = random_bytes((n, 4), SEED_ED_CORRUPT)
+    bad = (ctl[:, 0] & 63) == 0
+    which = ctl[:, 0] >> 6
+    pos = ctl[:, 1].astype(np.int64)
+    bit = (np.uint8(1) << (ctl[:, 2] & 7)).astype(np.uint8)
+    sig = sig.copy()
+    msg = msg.copy()
+    idx = np.nonzero(bad)[0]
+    for i in idx:
+        if which[i] == 1:
+            sig[i, pos[i] % 32] ^= bit[i]
+        elif which[i] == 2:
+            # keep S's top 3 bits alone so the flipped S stays a different residue mod L
+            sig[i, 32 + pos[i] % 31] ^= bit[i]
+        else:
+            msg[i, pos[i] % msg.shape[1]] ^= bit[i]
+    return sig, msg, bad

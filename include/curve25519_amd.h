@@ -1,0 +1,81 @@
+/*
+ * include/curve25519_amd.h -- batched entry points of the MI355X engine (C ABI).
+ *
+ * The reference has no batch API: its callers loop over the single-call functions of
+ * include/curve25519_dh.h and include/ed25519_signature.h (e.g. test/curve25519_test.c:144-318).
+ * Each function below is the N-element form of exactly one reference call and produces, element by
+ * element, the bytes that call would produce.  Layouts are contiguous fixed-stride arrays:
+ *
+ *     sk, pk, shared : n x 32 bytes          priv, sig : n x 64 bytes
+ *     msg            : n x msg_size bytes    verdict   : n x int (1 valid / 0 invalid)
+ *
+ * Two flavours:
+ *   *_batch : host pointers.  Synchronous: uploads, runs the kernels, downloads.  Callable from
+ *             several host threads at once (each thread owns its stream and staging buffers).
+ *   *_dev   : device pointers (hipMalloc'ed memory of the current device, 16-byte aligned) and a
+ *             hipStream_t passed as void* (NULL = default stream).  Asynchronous: returns after
+ *             enqueueing.  This is what bench.py times with inputs resident in HBM.
+ *
+ * Return value: 0 on success, otherwise a HIP error code (c25519_amd_last_error() gives the text).
+ * There is no CPU fallback: without a usable gfx950 device every entry point fails.
+ */
+#ifndef CURVE25519_AMD_H
+#define CURVE25519_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* library / device status ------------------------------------------------------------------- */
+const char *c25519_amd_version(void);
+const char *c25519_amd_last_error(void);               /* per-thread, "" when none */
+int  c25519_amd_device_count(void);                    /* usable HIP devices (0 when none) */
+int  c25519_amd_set_device(int device);                /* device used by this host thread */
+
+/* X25519 ------------------------------------------------------------------------------------ */
+/* n x curve25519_dh_CreateSharedKey (reference include/curve25519_dh.h:45); sk is clamped in place */
+int curve25519_dh_CreateSharedKey_batch(unsigned char *shared, const unsigned char *pk,
+                                        unsigned char *sk, size_t n);
+int curve25519_dh_CreateSharedKey_dev(void *shared, const void *pk, void *sk, size_t n, void *stream);
+
+/* n x curve25519_dh_CalculatePublicKey (reference :34): ladder on the base point u = 9 */
+int curve25519_dh_CalculatePublicKey_batch(unsigned char *pk, unsigned char *sk, size_t n);
+int curve25519_dh_CalculatePublicKey_dev(void *pk, void *sk, size_t n, void *stream);
+
+/* n x curve25519_dh_CalculatePublicKey_fast (reference :40): Edwards 8-fold walk + birational map */
+int curve25519_dh_CalculatePublicKey_fast_batch(unsigned char *pk, unsigned char *sk, size_t n);
+int curve25519_dh_CalculatePublicKey_fast_dev(void *pk, void *sk, size_t n, void *stream);
+
+/* Ed25519 ----------------------------------------------------------------------------------- */
+/* n x ed25519_CreateKeyPair (reference include/ed25519_signature.h:40), blinding = NULL */
+int ed25519_CreateKeyPair_batch(unsigned char *pub, unsigned char *priv, const unsigned char *sk, size_t n);
+int ed25519_CreateKeyPair_dev(void *pub, void *priv, const void *sk, size_t n, void *stream);
+
+/* n x ed25519_SignMessage (reference :47), blinding = NULL, all messages msg_size bytes long */
+int ed25519_SignMessage_batch(unsigned char *sig, const unsigned char *priv, const unsigned char *msg,
+                              size_t msg_size, size_t n);
+int ed25519_SignMessage_dev(void *sig, const void *priv, const void *msg, size_t msg_size, size_t n,
+                            void *stream);
+
+/* n x ed25519_VerifySignature (reference :67): full Init + Check per element, distinct keys */
+int ed25519_VerifySignature_batch(int *verdict, const unsigned char *sig, const unsigned char *pk,
+                                  const unsigned char *msg, size_t msg_size, size_t n);
+int ed25519_VerifySignature_dev(void *verdict, const void *sig, const void *pk, const void *msg,
+                                size_t msg_size, size_t n, void *stream);
+
+/* bytes of device scratch ed25519_VerifySignature_dev needs for n elements (per-lane 4-fold tables);
+ * the library allocates and caches it per host thread. */
+size_t ed25519_VerifySignature_scratch_bytes(size_t n);
+
+/* introspection used by tests and bench ------------------------------------------------------ */
+/* copies the device-generated 256 x 96-byte 8-fold base table (canonical Y+X, Y-X, 2dT rows --
+ * the content of reference source/base_folding8.h) to `out` */
+int c25519_amd_base_table(unsigned char *out /* 24576 bytes */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,43 @@
+/*
+ * include/curve25519_dh.h -- X25519 key agreement, drop-in for msotoodeh/curve25519's
+ * include/curve25519_dh.h (the three prototypes at reference include/curve25519_dh.h:34-48).
+ *
+ * Same names, same argument order, same byte-level behaviour as the reference's portable-C build:
+ *   - every buffer is 32 bytes, little-endian;
+ *   - `sk` is IN/OUT: it is clamped in the caller's buffer (reference source/curve25519_dh.c:186,196,206);
+ *   - all 256 bits of a peer public key are used (bit 255 is not masked), nothing is validated,
+ *     low-order inputs yield 32 zero bytes;
+ *   - the functions return void: there is no error channel.  This library computes on an AMD
+ *     MI355X (gfx950) through HIP and ABORTS the process with a message on stderr if no usable
+ *     device is present -- it never falls back to a CPU implementation.
+ *
+ * A single call is executed as a device batch of one.  Throughput comes from the batch entry points
+ * in curve25519_amd.h.
+ */
+#ifndef CURVE25519_AMD_DH_H
+#define CURVE25519_AMD_DH_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* pk = clamp(sk) * 9 by the Montgomery ladder.   replaces reference include/curve25519_dh.h:34 */
+void curve25519_dh_CalculatePublicKey(
+    unsigned char *pk,          /* [32 bytes] OUT: public key */
+    unsigned char *sk);         /* [32 bytes] IN/OUT: secret key, clamped on return */
+
+/* Same result through the Edwards 8-fold fixed-base walk.   replaces reference :40 */
+void curve25519_dh_CalculatePublicKey_fast(
+    unsigned char *pk,          /* [32 bytes] OUT: public key */
+    unsigned char *sk);         /* [32 bytes] IN/OUT: secret key, clamped on return */
+
+/* shared = clamp(sk) * pk.   replaces reference :45.  `shared` may alias `pk`. */
+void curve25519_dh_CreateSharedKey(
+    unsigned char *shared,      /* [32 bytes] OUT: shared secret */
+    const unsigned char *pk,    /* [32 bytes] IN: peer public key */
+    unsigned char *sk);         /* [32 bytes] IN/OUT: secret key, clamped on return */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,197 @@
+// tools/ubench/valu_rates.hip -- measures the sustained issue rate of the VALU instructions the
+// field arithmetic is built from, on the device it runs on (gfx950).  The v_mad_u64_u32 figure is the
+// denominator of the integer-MAC roofline reported by bench.py ("measured device
+// integer-multiply peak").  Build: hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+constexpr int ITERS = 4096;
+constexpr int UNROLL = 16;      // instructions of the tested kind per loop iteration
+
+// Each body issues UNROLL instructions on 8 independent dependency chains (2 per chain).
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_rate(unsigned* out, unsigned seed)
+{
+    unsigned a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u;
+    unsigned r0 = a, r1 = b, r2 = a + 1, r3 = b + 1, r4 = a + 2, r5 = b + 2, r6 = a + 3, r7 = b + 3;
+    unsigned t0 = b, t1 = a, t2 = b + 5, t3 = a + 5, t4 = b + 6, t5 = a + 6, t6 = b + 7, t7 = a + 7;
+    unsigned long long q0 = a, q1 = b, q2 = r2, q3 = r3, q4 = r4, q5 = r5, q6 = r6, q7 = r7;
+    double d0 = a, d1 = b, d2 = 1.0, d3 = 2.0, d4 = 3.0, d5 = 4.0, d6 = 5.0, d7 = 6.0;
+    double dm = 1.0000001, da = 1e-9;
+    float f0 = a, f1 = b, f2 = 1, f3 = 2, f4 = 3, f5 = 4, f6 = 5, f7 = 6, fm = 1.0001f, fa = 1e-5f;
+    for (int it = 0; it < ITERS; ++it) {
+        if constexpr (KIND == 0) {          // v_mad_u64_u32, accumulate chain
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q##i) : "v"(a), "v"(b) : "vcc");
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 1) {   // v_mul_lo_u32
+#define X(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 2) {   // v_mul_hi_u32
+#define X(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 3) {   // v_add_u32
+#define X(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 4) {   // v_add_co_u32 / v_addc_co_u32 pair (counts as 2)
+#define X(i) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc" : "+v"(r##i), "+v"(t##i) : "v"(a), "v"(b) : "vcc");
+            REP8(X)
+#undef X
+        } else if constexpr (KIND == 5) {   // v_add3_u32
+#define X(i) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r##i) : "v"(a), "v"(b));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 6) {   // v_fma_f64
+#define X(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d##i) : "v"(dm), "v"(da));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 7) {   // v_mad_u32_u24
+#define X(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(r##i) : "v"(a), "v"(b));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 8) {   // v_lshl_add_u64 (64-bit add)
+#define X(i) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q##i) : "v"(q7));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 9) {   // v_alignbit_b32
+#define X(i) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 10) {  // v_lshrrev_b64
+#define X(i) asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(q##i));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 11) {  // v_mul_hi_u32_u24
+#define X(i) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 12) {  // v_fma_f32
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f##i) : "v"(fm), "v"(fa));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 13) {  // v_cndmask_b32 (vcc)
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r##i) : "v"(a) : );
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 14) {  // v_xor_b32
+#define X(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 15) {  // mixed: 1 mad_u64_u32 + 1 addc per pair (counts 16 = 8 mad + 8 addc)
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(q##i), "+v"(r##i) : "v"(a), "v"(b) : "vcc");
+            REP8(X)
+#undef X
+        } else if constexpr (KIND == 16) {  // mixed: 1 mad_u64_u32 + 3 v_add_u32 (counts 16 = 4 mad + 12 add)
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_add_u32 %1, %1, %2\n\tv_add_u32 %1, %1, %3\n\tv_add_u32 %1, %1, %2" : "+v"(q##i), "+v"(r##i) : "v"(a), "v"(b) : "vcc");
+            X(0) X(1) X(2) X(3)
+#undef X
+        } else if constexpr (KIND == 17) {  // v_pk_fma_f32
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(d##i) : "v"(dm), "v"(da));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 18) {  // v_mul_u32_u24
+#define X(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 19) {  // v_mul_f64
+#define X(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d##i) : "v"(dm));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 20) {  // v_add_f64
+#define X(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d##i) : "v"(da));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 21) {  // v_cvt_f64_u32 + v_cvt_u32_f64 pair (counts 2 each -> 16)
+#define X(i) asm volatile("v_cvt_f64_u32 %0, %1\n\tv_cvt_u32_f64 %1, %0" : "+v"(d##i), "+v"(r##i));
+            REP8(X)
+#undef X
+        } else if constexpr (KIND == 22) {  // mad_u64_u32 with SGPR-free null carry: v_mad_u64_u32 dst, s[..]
+#define X(i) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(q##i) : "v"(a), "v"(b) : "s20", "s21");
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 23) {  // v_mad_i32_i24 ... placeholder for v_perm/v_bfe: v_bfe_u32
+#define X(i) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(r##i));
+            REP8(X) REP8(X)
+#undef X
+        }
+    }
+    unsigned acc = t0 ^ t1 ^ t2 ^ t3 ^ t4 ^ t5 ^ t6 ^ t7 ^ r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+    unsigned long long qa = q0 ^ q1 ^ q2 ^ q3 ^ q4 ^ q5 ^ q6 ^ q7;
+    double ds = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7;
+    float fs = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7;
+    acc ^= (unsigned)qa ^ (unsigned)(qa >> 32) ^ (unsigned)__double2loint(ds) ^ __float_as_uint(fs);
+    if (acc == 0x12345678u) out[0] = acc;      // keep everything live, (almost) never store
+}
+
+struct Kind { int id; const char* name; };
+static const Kind kinds[] = {
+    {0, "v_mad_u64_u32"}, {22, "v_mad_u64_u32(sgpr carry)"}, {1, "v_mul_lo_u32"}, {2, "v_mul_hi_u32"},
+    {3, "v_add_u32"}, {4, "v_add_co+v_addc_co"}, {5, "v_add3_u32"}, {6, "v_fma_f64"}, {19, "v_mul_f64"},
+    {20, "v_add_f64"}, {21, "v_cvt_f64_u32+v_cvt_u32_f64"}, {7, "v_mad_u32_u24"}, {18, "v_mul_u32_u24"},
+    {11, "v_mul_hi_u32_u24"}, {8, "v_lshl_add_u64"}, {9, "v_alignbit_b32"}, {10, "v_lshrrev_b64"},
+    {23, "v_bfe_u32"}, {12, "v_fma_f32"}, {17, "v_pk_fma_f32"}, {13, "v_cndmask_b32"}, {14, "v_xor_b32"},
+    {15, "mix 1 mad64 : 1 addc"}, {16, "mix 1 mad64 : 3 add"},
+};
+
+template <int KIND> static void launch(int blocks, unsigned* d, hipStream_t s) { k_rate<KIND><<<blocks, 256, 0, s>>>(d, 1); }
+
+static void dispatch(int kind, int blocks, unsigned* d, hipStream_t s)
+{
+    switch (kind) {
+#define C(k) case k: launch<k>(blocks, d, s); break;
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(18)
+        C(19) C(20) C(21) C(22) C(23)
+#undef C
+    }
+}
+
+int main(int argc, char** argv)
+{
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    int cus = prop.multiProcessorCount;
+    double ghz = prop.clockRate / 1e6;
+    printf("device %s  CUs %d  clock %.3f GHz\n", prop.name, cus, ghz);
+    unsigned* d; CHECK(hipMalloc(&d, 64));
+    hipStream_t s; CHECK(hipStreamCreate(&s));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const char* json = argc > 1 ? argv[1] : nullptr;
+    FILE* jf = json ? fopen(json, "w") : nullptr;
+    if (jf) fprintf(jf, "{\"device\": \"%s\", \"cus\": %d, \"clock_ghz\": %.3f, \"rates\": {\n", prop.name, cus, ghz);
+    bool first = true;
+    for (int wps : {1, 2, 4, 8}) {               // waves per SIMD: 256-thread block = 1 wave per SIMD
+        int blocks = cus * wps;
+        for (const Kind& k : kinds) {
+            dispatch(k.id, blocks, d, s);
+            CHECK(hipStreamSynchronize(s));
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CHECK(hipEventRecord(e0, s));
+                dispatch(k.id, blocks, d, s);
+                CHECK(hipEventRecord(e1, s));
+                CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            double insts = (double)blocks * 4 /*waves*/ * ITERS * UNROLL;     // wave-instructions
+            double lane_ops_per_s = insts * 64 / (best * 1e-3);
+            double per_clk_per_simd = lane_ops_per_s / (cus * 4.0 * ghz * 1e9);
+            printf("wps=%d %-30s %8.3f ms  %8.2f Tlane-op/s  %6.2f lanes/clk/SIMD\n", wps, k.name, best,
+                   lane_ops_per_s / 1e12, per_clk_per_simd);
+            if (jf) { fprintf(jf, "%s  \"%s@wps%d\": %.4e", first ? "" : ",\n", k.name, wps, lane_ops_per_s); first = false; }
+        }
+    }
+    if (jf) { fprintf(jf, "\n}}\n"); fclose(jf); }
+    return 0;
+}
