@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: 2^20 curve25519_dh_CreateSharedKey operations per
+GPU (BASELINE.json configs[1]), inputs already resident in HBM, followed for N > 1 by the single RCCL
+gather of the 32-byte results to rank 0 that north_star names.  Weak scaling: every rank owns its own
+2^20 keypairs.  Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      -- the X25519 kernel against the HBM roof the contract asks for (frac << 1 by
+                   construction: the path is VALU-integer bound) ...
+  roofline_valu -- ... and against the measured v_mad_u64_u32 issue peak (profiles/r01_valu_rates.json),
+                   which is the roof that actually binds;
+  cpu_baseline  -- the reference's portable-C path (oracle/_ref) or the oracle port timed on this host;
+  extra         -- Ed25519 sign / verify throughput at the same batch size (configs[2], configs[3]).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 1 << 20
+BYTES_PER_OP = {"x25519": 96, "sign": 160, "verify": 132}          # SURVEY.md 8(d), compulsory HBM bytes
+MACS_PER_OP = {"x25519": 184104, "sign": 52992, "verify": 245664}  # SURVEY.md 8(a), 32x32 MACs at 72/mul
+HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md
+
+
+def measured_mad_peak():
+    """lane-MAC/s of v_mad_u64_u32 measured by tools/ubench/valu_rates on MI355X (committed summary)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_valu_rates.json")) as f:
+            rates = json.load(f)["rates"]
+        return max(v for k, v in rates.items() if k.startswith("v_mad_u64_u32"))
+    except Exception:
+        return None
+
+
+def cpu_baseline(n_per_thread=2048):
+    """Time curve25519_dh_CreateSharedKey on the host cores: the real reference (portable C) when its
+    prebuilt library travelled with the repo, else the oracle port.  Bounded sample, same input
+    distribution as the GPU workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from oracle_lib import Oracle, Reference
+    from curve25519_amd import synth
+    cores = os.cpu_count() or 1
+    n = n_per_thread * cores
+    sk, pk = synth.x25519_inputs(n)
+    if Reference.available():
+        ref = Reference()
+        kind = "reference"
+
+        def work(lo, hi):
+            ref.x25519_shared(pk[lo:hi], sk[lo:hi])       # ctypes releases the GIL inside each call
+    else:
+        orc = Oracle()
+        kind = "port"
+
+        def work(lo, hi):
+            orc.x25519_shared(pk[lo:hi], sk[lo:hi], threads=1)
+
+    t0 = time.perf_counter()
+    work(0, n_per_thread)
+    single = n_per_thread / (time.perf_counter() - t0)
+    threads = [threading.Thread(target=work, args=(i * n_per_thread, (i + 1) * n_per_thread)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    multi = n / (time.perf_counter() - t0)
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    return {"value": round(multi, 1), "unit": "X25519 shared-key ops/s", "cores": cores, "kind": kind,
+            "sample": f"{n} curve25519_dh_CreateSharedKey calls ({n_per_thread} per thread, {cores} threads), "
+                      f"seeded uniform sk/pk", "single_core_ops_per_s": round(single, 1), "cpu_model": model}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH, help="operations per GPU per step (default 2^20)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the Ed25519 sign/verify side measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from curve25519_amd import synth
+    from curve25519_amd.sharded import HipEngine, gather_rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = args.batch
+    eng = HipEngine(dev)
+    # this rank's shard of the global seeded stream: rows [rank*n, (rank+1)*n)
+    sk_all, pk_all = synth.x25519_inputs(n) if world == 1 else (None, None)
+    if world > 1:
+        import numpy as np
+        sk_all = synth.random_bytes((n, 32), synth.SEED_X25519_SK + 0x100 * rank)
+        pk_all = synth.random_bytes((n, 32), synth.SEED_X25519_PK + 0x100 * rank)
+    sk = torch.from_numpy(sk_all).to(dev)
+    pk = torch.from_numpy(pk_all).to(dev)
+    out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        eng.api.curve25519_dh_CreateSharedKey_dev(out, pk, sk)
+        if ev:
+            ev[1].record()
+        if world > 1:
+            gather_rows(out, root=0)
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+
+    result = None
+    if rank == 0:
+        value = world * n * args.steps / elapsed
+        kernel_s = kernel_ms * 1e-3
+        achieved_gbs = BYTES_PER_OP["x25519"] * n / kernel_s / 1e9
+        peak_mac = measured_mad_peak()
+        achieved_mac = MACS_PER_OP["x25519"] * n / kernel_s
+        result = {
+            "metric": "X25519 shared-key ops/sec (batch=2^20 per GPU, variable-base Montgomery ladder)",
+            "value": round(value, 1), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 limbs, u64 accumulators (v_mad_u64_u32)", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: batch 2^20 X25519 curve25519_dh_CreateSharedKey per GPU, "
+                                   "one keypair per lane, inputs resident in HBM",
+                       "batch_per_gpu": n, "global_batch": n * world,
+                       "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel": "k_x25519", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": BYTES_PER_OP["x25519"] * n,
+                         "note": "VALU-integer bound path: HBM fraction is tiny by construction, see roofline_valu"},
+            "roofline_valu": {"bound": "valu v_mad_u64_u32", "achieved": round(achieved_mac / 1e12, 4),
+                              "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s",
+                              "frac": round(achieved_mac / peak_mac, 4) if peak_mac else None,
+                              "algorithmic_macs_per_op": MACS_PER_OP["x25519"]},
+        }
+
+    # ---- side measurements, outside the timed region (rank 0, single GPU only) ----
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = {}
+        esk_np, msg_np = synth.ed25519_inputs(n)
+        esk = torch.from_numpy(esk_np).to(dev)
+        msg = torch.from_numpy(msg_np).to(dev)
+        pub, priv = eng.ed25519_keypair(esk)
+        sig = eng.ed25519_sign(priv, msg)
+        torch.cuda.synchronize()
+
+        def timeit(fn, reps=3):
+            fn(); torch.cuda.synchronize()
+            best = 1e30
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); fn(); b.record(); torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b))
+            return best
+
+        ok = torch.empty((n, 1), dtype=torch.int32, device=dev)
+        for name, fn in (("sign", lambda: eng.api.ed25519_SignMessage_dev(sig, priv, msg)),
+                         ("verify", lambda: eng.api.ed25519_VerifySignature_dev(ok, sig, pub, msg)),
+                         ("keypair", lambda: eng.api.ed25519_CreateKeyPair_dev(pub, priv, esk))):
+            ms = timeit(fn)
+            extra[f"ed25519_{name}_per_s"] = round(n / (ms * 1e-3), 1)
+            extra[f"ed25519_{name}_kernel_ms"] = round(ms, 4)
+        extra["ed25519_verify_all_valid"] = bool(int(ok.sum().item()) == n)
+        result["extra"] = extra
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline()
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

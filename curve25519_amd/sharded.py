@@ -1,0 +1,90 @@
+"""Multi-GPU layer: one process per GPU, contiguous shards, one gather of the result slab to the root.
+
+The path is embarrassingly parallel: element i of a batch never looks at element j,
+the only shared data is the read-only 24 KiB base table, which every GPU regenerates for itself.  So
+there is no data-path collective at all; the single exchange step is the `gather` of each rank's
+output rows to the root that BASELINE.json's north_star names (RCCL over xGMI when the backend is
+"nccl"; the same code runs over gloo on CPU tensors in the tests).
+
+`engine` is any object with the batch methods used below.  The product engine is `HipEngine`
+(device tensors, libcurve25519_amd.so); tests/ substitute an oracle-backed engine to exercise the
+sharding and gather logic without a GPU.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous index ranges [lo, hi) of a batch of n over `world` ranks (sizes differ by <= 1)."""
+    return [(n * r // world, n * (r + 1) // world) for r in range(world)]
+
+
+def gather_rows(local: torch.Tensor, root: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Gather each rank's [m_r, w] rows to `root` in rank order (one collective; rows padded to the
+    largest shard so that every peer sends the same count).  Returns the concatenation on root, None
+    elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return local
+    m = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(m) for _ in range(world)]
+    dist.all_gather(counts, m, group=group)           # tiny control message, not the data path
+    counts = [int(c.item()) for c in counts]
+    mmax = max(counts)
+    send = local
+    if local.shape[0] != mmax:
+        send = torch.zeros((mmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == root else None
+    dist.gather(send, recv, dst=root, group=group)
+    if rank != root:
+        return None
+    return torch.cat([r[:c] for r, c in zip(recv, counts)], dim=0)
+
+
+class HipEngine:
+    """Device-resident batches on the current CUDA device, asynchronous on torch's current stream."""
+
+    def __init__(self, device=None):
+        from . import api
+        self.api = api
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+    def _empty(self, n, w, dtype=torch.uint8):
+        return torch.empty((n, w), dtype=dtype, device=self.device)
+
+    def x25519_shared(self, pk, sk):
+        out = self._empty(pk.shape[0], 32)
+        self.api.curve25519_dh_CreateSharedKey_dev(out, pk, sk)
+        return out
+
+    def ed25519_keypair(self, sk):
+        pub, priv = self._empty(sk.shape[0], 32), self._empty(sk.shape[0], 64)
+        self.api.ed25519_CreateKeyPair_dev(pub, priv, sk)
+        return pub, priv
+
+    def ed25519_sign(self, priv, msg):
+        sig = self._empty(priv.shape[0], 64)
+        self.api.ed25519_SignMessage_dev(sig, priv, msg)
+        return sig
+
+    def ed25519_verify(self, sig, pk, msg):
+        ok = torch.empty((sig.shape[0], 1), dtype=torch.int32, device=self.device)
+        self.api.ed25519_VerifySignature_dev(ok, sig, pk, msg)
+        return ok
+
+
+def x25519_shared_sharded(engine, pk_local, sk_local, root: int = 0, group=None):
+    """Each rank computes its shard; the shared secrets are gathered to `root`."""
+    return gather_rows(engine.x25519_shared(pk_local, sk_local), root, group)
+
+
+def ed25519_sign_sharded(engine, priv_local, msg_local, root: int = 0, group=None):
+    return gather_rows(engine.ed25519_sign(priv_local, msg_local), root, group)
+
+
+def ed25519_verify_sharded(engine, sig_local, pk_local, msg_local, root: int = 0, group=None):
+    return gather_rows(engine.ed25519_verify(sig_local, pk_local, msg_local), root, group)

@@ -23,6 +23,13 @@ def _p(a):
     return a.ctypes.data_as(u8p)
 
 
+def _rows(a, n):
+    """reshape to (n, row_len); an empty batch keeps whatever row length it has (or 0)."""
+    if n == 0:
+        return a.reshape(0, a.shape[1] if a.ndim == 2 else 0)
+    return a.reshape(n, -1)
+
+
 def build_oracle(force=False):
     srcs = [os.path.join(ORC_DIR, f) for f in os.listdir(ORC_DIR) if f.endswith((".c", ".h"))]
     stale = (not os.path.exists(ORC_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORC_SO) for s in srcs)
@@ -83,7 +90,7 @@ class Oracle:
         priv = np.ascontiguousarray(priv, dtype=np.uint8)
         msg = np.ascontiguousarray(msg, dtype=np.uint8)
         n = priv.shape[0]
-        msg = msg.reshape(n, -1)
+        msg = _rows(msg, n)
         sig = np.empty((n, 64), np.uint8)
         self.lib.orc_ed25519_sign_batch(_p(sig), _p(priv), _p(msg), msg.shape[1], n, threads)
         return sig
@@ -92,7 +99,7 @@ class Oracle:
         sig = np.ascontiguousarray(sig, dtype=np.uint8)
         pk = np.ascontiguousarray(pk, dtype=np.uint8)
         n = sig.shape[0]
-        msg = np.ascontiguousarray(msg, dtype=np.uint8).reshape(n, -1)
+        msg = _rows(np.ascontiguousarray(msg, dtype=np.uint8), n)
         ok = np.empty(n, np.int32)
         self.lib.orc_ed25519_verify_batch(ok.ctypes.data_as(C.POINTER(C.c_int32)), _p(sig), _p(pk), _p(msg),
                                           msg.shape[1], n, threads)
@@ -172,7 +179,7 @@ class Reference:
     def ed25519_sign(self, priv, msg):
         priv = np.ascontiguousarray(priv, dtype=np.uint8)
         n = priv.shape[0]
-        msg = np.ascontiguousarray(msg, dtype=np.uint8).reshape(n, -1)
+        msg = _rows(np.ascontiguousarray(msg, dtype=np.uint8), n)
         sig = np.empty((n, 64), np.uint8)
         for i in range(n):
             self.lib.ed25519_SignMessage(_p(sig[i]), _p(priv[i]), None, _p(msg[i]), msg.shape[1])
@@ -182,7 +189,7 @@ class Reference:
         sig = np.ascontiguousarray(sig, dtype=np.uint8)
         pk = np.ascontiguousarray(pk, dtype=np.uint8)
         n = sig.shape[0]
-        msg = np.ascontiguousarray(msg, dtype=np.uint8).reshape(n, -1)
+        msg = _rows(np.ascontiguousarray(msg, dtype=np.uint8), n)
         ok = np.empty(n, np.int32)
         for i in range(n):
             ok[i] = self.lib.ed25519_VerifySignature(_p(sig[i]), _p(pk[i]), _p(msg[i]), msg.shape[1])

@@ -1,0 +1,89 @@
+"""CPU suite, part 2: the drop-in boundary.  The C-ABI library must load without a GPU, export every
+symbol the headers in include/ declare, fail loudly (error code + message, never a CPU result) when
+asked to compute without a device, and the product package must not touch the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = set()
+    for h in ("curve25519_dh.h", "ed25519_signature.h", "curve25519_amd.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text):
+            name = m.group(1)
+            if name.startswith(("curve25519_", "ed25519_", "c25519_")):
+                names.add(name)
+    return sorted(names)
+
+
+def test_headers_declare_the_reference_api():
+    names = declared_functions()
+    for must in ("curve25519_dh_CalculatePublicKey", "curve25519_dh_CalculatePublicKey_fast",
+                 "curve25519_dh_CreateSharedKey", "ed25519_CreateKeyPair", "ed25519_SignMessage",
+                 "ed25519_Blinding_Init", "ed25519_Blinding_Finish", "ed25519_VerifySignature",
+                 "ed25519_Verify_Init", "ed25519_Verify_Check", "ed25519_Verify_Finish"):
+        assert must in names
+    text = open(os.path.join(ROOT, "include", "ed25519_signature.h")).read()
+    for macro, val in (("ed25519_public_key_size", 32), ("ed25519_secret_key_size", 32),
+                       ("ed25519_private_key_size", 64), ("ed25519_signature_size", 64)):
+        assert re.search(rf"#define\s+{macro}\s+{val}\b", text)
+
+
+def test_library_exports_every_declared_symbol():
+    from curve25519_amd import _lib
+    lib = _lib.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in curve25519_amd/_lib.py"
+    assert b"gfx950" in lib.c25519_amd_version()
+    assert lib.ed25519_VerifySignature_scratch_bytes(64) == 16 * 40 * 64 * 4
+    assert lib.ed25519_VerifySignature_scratch_bytes(65) == 2 * 16 * 40 * 64 * 4
+
+
+def test_headers_compile_as_c_and_cxx(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "curve25519_dh.h"\n#include "ed25519_signature.h"\n#include "curve25519_amd.h"\n'
+                   "int main(void){unsigned char b[ed25519_signature_size]; return sizeof b == 64 ? 0 : 1;}\n")
+    for cc, flags in (("gcc", ["-std=c99", "-pedantic", "-Werror"]), ("g++", ["-x", "c++", "-Werror"])):
+        subprocess.check_call([cc, *flags, "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o",
+                               str(tmp_path / "t.o")])
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from curve25519_amd import _lib, api
+    lib = _lib.load()
+    assert lib.c25519_amd_device_count() == 0
+    sk = np.zeros((2, 32), np.uint8)
+    with pytest.raises(_lib.EngineError):
+        api.curve25519_dh_CreateSharedKey(sk, sk)
+    with pytest.raises(_lib.EngineError):
+        api.ed25519_CreateKeyPair(sk)
+    assert lib.c25519_amd_last_error() != b""
+    # n == 0 is a no-op everywhere, even without a device
+    assert lib.curve25519_dh_CreateSharedKey_batch(sk.ctypes.data, sk.ctypes.data, sk.ctypes.data, 0) == 0
+
+
+def test_product_does_not_use_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "curve25519_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".h", ".c", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                code = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith(("#", "//", "*", '"""')))
+                assert "oracle_lib" not in code and "liborc25519" not in code and "orc25519.h" not in code, f
+    for h in os.listdir(os.path.join(ROOT, "include")):
+        assert "orc_" not in open(os.path.join(ROOT, "include", h)).read()
+    out = subprocess.check_output(["ldd", os.path.join(pkg, "libcurve25519_amd.so")], text=True)
+    assert "liborc" not in out and "curve25519_ref" not in out

@@ -1,0 +1,260 @@
+"""GPU suite (pytest -m gpu, MI355X): the HIP path, called through the C-ABI of libcurve25519_amd.so, against
+the committed golden fixtures (which hold the REAL reference's outputs) and against the oracle on seeded
+inputs -- bit-exact everywhere, since every value on this path is an integer.
+
+Sizes: known-answer vectors, the 1024-record fixture, config 1's N = 4096 and the full N = 2^20 batches of
+configs 2-4 (digest of the reference's outputs + size-independent properties), ragged batch sizes
+around the wave / workgroup widths, empty batches, message lengths around the SHA-512 block edges."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from curve25519_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+KAT = json.load(open(os.path.join(GOLD, "kat.json")))
+DIG = json.load(open(os.path.join(GOLD, "digests.json")))
+R1024 = np.load(os.path.join(GOLD, "random_1024.npz"))
+THREADS = os.cpu_count() or 1
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+
+
+def h2a(s):
+    return np.frombuffer(bytes.fromhex(s), np.uint8).reshape(1, -1)
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "the gpu suite needs an MI355X"
+    from curve25519_amd import api as a
+    assert a.device_count() >= 1
+    return a
+
+
+def test_native_library_is_what_runs(api):
+    """The extension must be the in-tree .so and must really be mapped into this process."""
+    from curve25519_amd import _lib
+    path = _lib.library_path()
+    assert os.path.dirname(path) == os.path.join(ROOT, "curve25519_amd")
+    api.curve25519_dh_CreateSharedKey(np.zeros((1, 32), np.uint8), np.ones((1, 32), np.uint8))
+    assert "libcurve25519_amd.so" in open("/proc/self/maps").read()
+
+
+def test_base_table_equals_reference_table(api, oracle):
+    tbl = api.base_folding8_table()
+    assert sha(tbl) == KAT["base_folding8_sha256"]
+    assert np.array_equal(tbl, oracle.base_table())
+
+
+# ---- known-answer vectors -------------------------------------------------------------------------------
+
+def test_x25519_kats(api):
+    recs = KAT["x25519"]
+    pk = np.concatenate([h2a(r["pk"]) for r in recs])
+    sk = np.concatenate([h2a(r["sk"]) for r in recs])
+    shared, clamped = api.curve25519_dh_CreateSharedKey(pk, sk)
+    for i, r in enumerate(recs):
+        assert shared[i].tobytes().hex() == r["shared"], r["name"]
+        assert clamped[i].tobytes().hex() == r["sk_clamped"], r["name"]
+
+
+def test_x25519_public_kats(api):
+    recs = KAT["x25519_public"]
+    sk = np.concatenate([h2a(r["sk"]) for r in recs])
+    for fast in (False, True):
+        pk, clamped = api.curve25519_dh_CalculatePublicKey(sk, fast=fast)
+        for i, r in enumerate(recs):
+            assert pk[i].tobytes().hex() == r["pk"], (r["name"], fast)
+            assert clamped[i].tobytes().hex() == r["sk_clamped"]
+
+
+def test_ed25519_kats_all_message_lengths(api):
+    for r in KAT["ed25519"]:                        # message lengths 0..257 -> one batch of one per length
+        msg = np.frombuffer(bytes.fromhex(r["msg"]), np.uint8).reshape(1, -1)
+        pub, priv = api.ed25519_CreateKeyPair(h2a(r["sk"]))
+        assert pub.tobytes().hex() == r["pk"] and priv.tobytes().hex() == r["priv"], r["name"]
+        sig = api.ed25519_SignMessage(priv, msg)
+        assert sig.tobytes().hex() == r["sig"], r["name"]
+        assert int(api.ed25519_VerifySignature(sig, pub, msg)[0]) == 1, r["name"]
+
+
+def test_ed25519_verify_quirks(api):
+    """Negative vectors and the reference's non-RFC behaviour: S+L accepted, no key validation."""
+    for r in KAT["ed25519_verify"]:
+        msg = np.frombuffer(bytes.fromhex(r["msg"]), np.uint8).reshape(1, -1)
+        got = int(api.ed25519_VerifySignature(h2a(r["sig"]), h2a(r["pk"]), msg)[0])
+        assert got == r["verify"], r["name"]
+
+
+# ---- fixtures with the reference's outputs --------------------------------------------------------------
+
+def test_random_1024_fixture(api):
+    g = R1024
+    shared, clamped = api.curve25519_dh_CreateSharedKey(g["x_pk"], g["x_sk"])
+    assert np.array_equal(shared, g["x_shared"]) and np.array_equal(clamped, g["x_sk_clamped"])
+    pub, priv = api.ed25519_CreateKeyPair(g["ed_sk"])
+    assert np.array_equal(pub, g["ed_pub"]) and np.array_equal(priv, g["ed_priv"])
+    assert np.array_equal(api.ed25519_SignMessage(priv, g["ed_msg"]), g["ed_sig"])
+    assert np.array_equal(api.ed25519_VerifySignature(g["v_sig"], pub, g["v_msg"]), g["v_ok"])
+
+
+def gpu_digests(api, n):
+    sk, pk = synth.x25519_inputs(n)
+    shared, clamped = api.curve25519_dh_CreateSharedKey(pk, sk)
+    esk, msg = synth.ed25519_inputs(n)
+    pub, priv = api.ed25519_CreateKeyPair(esk)
+    sig = api.ed25519_SignMessage(priv, msg)
+    bsig, bmsg, bad = synth.corrupt_for_verify(sig, msg)
+    ok = api.ed25519_VerifySignature(bsig, pub, bmsg)
+    assert np.array_equal(ok == 0, bad), "exactly the corrupted entries are rejected"
+    return {"n": n, "x25519_shared": sha(shared), "x25519_sk_clamped": sha(clamped), "ed25519_pub": sha(pub),
+            "ed25519_priv": sha(priv), "ed25519_sig": sha(sig), "ed25519_verdicts": sha(ok.astype("<i4")),
+            "verify_rejected": int(bad.sum())}
+
+
+@pytest.mark.parametrize("n", [k for k in ("1024", "4096", str(1 << 20)) if k in DIG])
+def test_seeded_batches_hash_to_the_reference_digests(api, n):
+    """BASELINE.json configs 1-4 at their real sizes: outputs of the HIP path hash to the digests of the
+    reference's outputs on the same seeded inputs."""
+    assert gpu_digests(api, int(n)) == DIG[n]
+
+
+# ---- against the oracle: ragged sizes, edge inputs -------------------------------------------------------
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 255, 256, 257, 1000, 4097])
+def test_ragged_batch_sizes(api, oracle, n):
+    sk = synth.random_bytes((n, 32), 0xA000 + n)
+    pk = synth.random_bytes((n, 32), 0xB000 + n)
+    msg = synth.random_bytes((n, 24), 0xC000 + n)
+    shared, clamped = api.curve25519_dh_CreateSharedKey(pk, sk)
+    e_shared, e_clamped = oracle.x25519_shared(pk, sk, threads=THREADS)
+    assert np.array_equal(shared, e_shared) and np.array_equal(clamped, e_clamped)
+    pub, priv = api.ed25519_CreateKeyPair(sk)
+    e_pub, e_priv = oracle.ed25519_keypair(sk, threads=THREADS)
+    assert np.array_equal(pub, e_pub) and np.array_equal(priv, e_priv)
+    sig = api.ed25519_SignMessage(priv, msg)
+    assert np.array_equal(sig, oracle.ed25519_sign(priv, msg, threads=THREADS))
+    if n:
+        sig[::2, 40] ^= 1
+    ok = api.ed25519_VerifySignature(sig, pub, msg)
+    assert np.array_equal(ok, oracle.ed25519_verify(sig, pub, msg, threads=THREADS))
+    assert ok.shape == (n,)
+
+
+def test_edge_public_keys_and_garbage(api, oracle):
+    P = 2**255 - 19
+    vals = [0, 1, 2, 9, P - 1, P, P + 1, P + 9, 2**255 - 1, 2**255, 2**255 + 9, 2**256 - 1, 2**256 - 20]
+    pk = np.stack([np.frombuffer(int(v).to_bytes(32, "little"), np.uint8) for v in vals] * 5)
+    sk = synth.random_bytes((pk.shape[0], 32), 0xED6E)
+    shared, _ = api.curve25519_dh_CreateSharedKey(pk, sk)
+    assert np.array_equal(shared, oracle.x25519_shared(pk, sk)[0])
+    assert not shared[0].any() and not shared[1].any()            # low-order inputs -> zero bytes
+    # Ed25519 verify on unvalidated garbage keys / signatures must give the reference's verdicts
+    n = 2048
+    gs, gp, gm = synth.random_bytes((n, 64), 31), synth.random_bytes((n, 32), 32), synth.random_bytes((n, 32), 33)
+    gp[: len(vals)] = pk[: len(vals)]
+    assert np.array_equal(api.ed25519_VerifySignature(gs, gp, gm), oracle.ed25519_verify(gs, gp, gm, threads=THREADS))
+
+
+@pytest.mark.parametrize("mlen", [0, 1, 3, 8, 47, 48, 49, 63, 64, 65, 111, 112, 113, 128, 300])
+def test_message_lengths(api, oracle, mlen):
+    n = 130
+    sk = synth.random_bytes((n, 32), 0x5000 + mlen)
+    msg = synth.random_bytes((n, mlen), 0x6000 + mlen)
+    pub, priv = oracle.ed25519_keypair(sk, threads=THREADS)
+    sig = api.ed25519_SignMessage(priv, msg)
+    assert np.array_equal(sig, oracle.ed25519_sign(priv, msg, threads=THREADS))
+    assert api.ed25519_VerifySignature(sig, pub, msg).all()
+    if mlen:
+        msg[:, mlen - 1] ^= 0x80
+        assert not api.ed25519_VerifySignature(sig, pub, msg).any()
+
+
+# ---- size-independent properties at the full batch size --------------------------------------------------
+
+def test_full_size_properties(api):
+    n = 1 << 20
+    a = synth.random_bytes((n, 32), 0x1111)
+    b = synth.random_bytes((n, 32), 0x2222)
+    pa, _ = api.curve25519_dh_CalculatePublicKey(a, fast=True)
+    pb, _ = api.curve25519_dh_CalculatePublicKey(b)
+    s1, _ = api.curve25519_dh_CreateSharedKey(pb, a)
+    s2, _ = api.curve25519_dh_CreateSharedKey(pa, b)
+    assert np.array_equal(s1, s2), "a*(b*G) == b*(a*G) for every lane (8-fold walk vs ladder on one side)"
+    assert s1.any(axis=1).all()
+    msg = synth.random_bytes((n, 32), 0x3333)
+    pub, priv = api.ed25519_CreateKeyPair(a)
+    sig = api.ed25519_SignMessage(priv, msg)
+    assert api.ed25519_VerifySignature(sig, pub, msg).all(), "sign -> verify round trip"
+    assert not api.ed25519_VerifySignature(sig, np.roll(pub, 1, axis=0), msg).any(), "wrong key rejects"
+
+
+# ---- the other faces of the boundary --------------------------------------------------------------------
+
+def test_device_pointer_entry_points(api, oracle):
+    import torch
+    n = 3000
+    dev = torch.device("cuda", 0)
+    sk_np, pk_np = synth.x25519_inputs(n)
+    sk, pk = torch.from_numpy(sk_np).to(dev), torch.from_numpy(pk_np).to(dev)
+    out = torch.empty_like(pk)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        api.curve25519_dh_CreateSharedKey_dev(out, pk, sk)
+    s.synchronize()
+    e_out, e_sk = oracle.x25519_shared(pk_np, sk_np, threads=THREADS)
+    assert np.array_equal(out.cpu().numpy(), e_out) and np.array_equal(sk.cpu().numpy(), e_sk)
+    api.curve25519_dh_CreateSharedKey_dev(pk, pk, sk)              # shared may alias pk
+    torch.cuda.synchronize()
+    assert np.array_equal(pk.cpu().numpy(), e_out)
+    from curve25519_amd import _lib
+    with pytest.raises(_lib.EngineError):                           # misaligned device pointer is refused
+        api.curve25519_dh_CreateSharedKey_dev(out, out.view(-1)[1:32 * (n - 1) + 1].view(n - 1, 32), sk[: n - 1])
+
+
+def test_single_call_reference_api(api):
+    """The eleven reference entry points, one element at a time (a device batch of one each)."""
+    from curve25519_amd import _lib
+    L = _lib.load()
+    buf = lambda b: (C.c_ubyte * len(b)).from_buffer_copy(b)  # noqa: E731
+    r = next(x for x in KAT["x25519"] if x["name"] == "rfc7748-1")
+    sk, pk, out = buf(bytes.fromhex(r["sk"])), buf(bytes.fromhex(r["pk"])), (C.c_ubyte * 32)()
+    L.curve25519_dh_CreateSharedKey(out, pk, sk)
+    assert bytes(out).hex() == r["shared"] and bytes(sk).hex() == r["sk_clamped"]
+    r = KAT["x25519_public"][0]
+    for fn in (L.curve25519_dh_CalculatePublicKey, L.curve25519_dh_CalculatePublicKey_fast):
+        sk = buf(bytes.fromhex(r["sk"]))
+        fn(out, sk)
+        assert bytes(out).hex() == r["pk"]
+    r = next(x for x in KAT["ed25519"] if x["name"] == "rfc8032-test3")
+    pub, priv, sig = (C.c_ubyte * 32)(), (C.c_ubyte * 64)(), (C.c_ubyte * 64)()
+    msg = bytes.fromhex(r["msg"])
+    L.ed25519_CreateKeyPair(pub, priv, None, buf(bytes.fromhex(r["sk"])))
+    L.ed25519_SignMessage(sig, priv, None, buf(msg), len(msg))
+    assert bytes(pub).hex() == r["pk"] and bytes(sig).hex() == r["sig"]
+    assert L.ed25519_VerifySignature(sig, pub, buf(msg), len(msg)) == 1
+    ctx = L.ed25519_Verify_Init(None, pub)
+    assert L.ed25519_Verify_Check(ctx, sig, buf(msg), len(msg)) == 1
+    assert L.ed25519_Verify_Check(ctx, sig, buf(b"xx"), 2) == 0
+    L.ed25519_Verify_Finish(ctx)
+
+
+def test_c_caller_links_and_passes(tmp_path):
+    """A plain C program written against the reference's two public headers, linked to this library."""
+    exe = str(tmp_path / "dropin_test")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "dropin_test.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "curve25519_amd"), "-lcurve25519_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "curve25519_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "0 failure(s)" in p.stdout

@@ -1,0 +1,133 @@
+"""CPU suite, part 1: pins the oracle (oracle/liborc25519.so) to the committed golden vectors -- RFC 7748 /
+RFC 8032 known answers, the reference's own test inputs, edge-case public keys, 1024 seeded random
+records with the reference's outputs, and SHA-256 digests of the reference's outputs on the seeded
+N = 1024 / 4096 / 2^20 batches -- and, where oracle/_ref is present, to the real reference directly."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from curve25519_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KAT = json.load(open(os.path.join(GOLD, "kat.json")))
+DIG = json.load(open(os.path.join(GOLD, "digests.json")))
+R1024 = np.load(os.path.join(GOLD, "random_1024.npz"))
+h2a = lambda s, w=None: np.frombuffer(bytes.fromhex(s), np.uint8).reshape(1, -1 if w is None else w)  # noqa: E731
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+THREADS = os.cpu_count() or 1
+
+
+def test_sha512_kats(oracle):
+    for rec in KAT["sha512"]:
+        msg = bytes.fromhex(rec["msg"]) if "msg" in rec else bytes.fromhex(rec["msg_repeat"][0]) * rec["msg_repeat"][1]
+        assert oracle.sha512(msg).hex() == rec["digest"]
+    for n in (0, 1, 111, 112, 113, 127, 128, 129, 239, 240, 241, 255, 256, 1000):
+        d = bytes((7 * i + 1) & 0xff for i in range(n))
+        assert oracle.sha512(d) == hashlib.sha512(d).digest(), n
+
+
+def test_fold_recoding(oracle):
+    for rec in KAT["folds"]:
+        k = bytes.fromhex(rec["k"])
+        assert oracle.fold8(k).tobytes().hex() == rec["fold8"]
+        assert oracle.fold4(k).tobytes().hex() == rec["fold4"]
+
+
+def test_base_table_digest(oracle):
+    tbl = oracle.base_table()
+    assert sha(tbl) == KAT["base_folding8_sha256"]
+    one = (1).to_bytes(32, "little")
+    assert tbl[0, 0].tobytes() == one and tbl[0, 1].tobytes() == one and not tbl[0, 2].any()   # neutral row
+
+
+@pytest.mark.parametrize("rec", KAT["x25519"], ids=lambda r: r["name"])
+def test_x25519_kat(oracle, rec):
+    shared, clamped = oracle.x25519_shared(h2a(rec["pk"]), h2a(rec["sk"]))
+    assert shared.tobytes().hex() == rec["shared"]
+    assert clamped.tobytes().hex() == rec["sk_clamped"]
+
+
+@pytest.mark.parametrize("rec", KAT["x25519_public"], ids=lambda r: r["name"])
+def test_x25519_public_kat(oracle, rec):
+    for fast in (False, True):
+        pk, clamped = oracle.x25519_public(h2a(rec["sk"]), fast=fast)
+        assert pk.tobytes().hex() == rec["pk"] and clamped.tobytes().hex() == rec["sk_clamped"]
+
+
+@pytest.mark.parametrize("rec", KAT["ed25519"], ids=lambda r: r["name"])
+def test_ed25519_kat(oracle, rec):
+    msg = np.frombuffer(bytes.fromhex(rec["msg"]), np.uint8).reshape(1, -1)
+    pub, priv = oracle.ed25519_keypair(h2a(rec["sk"]))
+    assert pub.tobytes().hex() == rec["pk"] and priv.tobytes().hex() == rec["priv"]
+    sig = oracle.ed25519_sign(priv, msg)
+    assert sig.tobytes().hex() == rec["sig"]
+    assert int(oracle.ed25519_verify(sig, pub, msg)[0]) == rec["verify"]
+
+
+@pytest.mark.parametrize("rec", KAT["ed25519_verify"], ids=lambda r: r["name"])
+def test_ed25519_verify_kat(oracle, rec):
+    msg = np.frombuffer(bytes.fromhex(rec["msg"]), np.uint8).reshape(1, -1)
+    assert int(oracle.ed25519_verify(h2a(rec["sig"]), h2a(rec["pk"]), msg)[0]) == rec["verify"]
+
+
+def test_random_1024(oracle):
+    g = R1024
+    shared, clamped = oracle.x25519_shared(g["x_pk"], g["x_sk"], threads=THREADS)
+    assert np.array_equal(shared, g["x_shared"]) and np.array_equal(clamped, g["x_sk_clamped"])
+    pub, priv = oracle.ed25519_keypair(g["ed_sk"], threads=THREADS)
+    assert np.array_equal(pub, g["ed_pub"]) and np.array_equal(priv, g["ed_priv"])
+    assert np.array_equal(oracle.ed25519_sign(priv, g["ed_msg"], threads=THREADS), g["ed_sig"])
+    ok = oracle.ed25519_verify(g["v_sig"], pub, g["v_msg"], threads=THREADS)
+    assert np.array_equal(ok, g["v_ok"]) and 0 < int((ok == 0).sum()) < 64
+    # the fixture itself follows the seeded generator
+    sk, pk = synth.x25519_inputs(1024)
+    assert np.array_equal(sk, g["x_sk"]) and np.array_equal(pk, g["x_pk"])
+
+
+def seeded_digests(engine, n, threads):
+    sk, pk = synth.x25519_inputs(n)
+    shared, clamped = engine.x25519_shared(pk, sk, threads=threads)
+    esk, msg = synth.ed25519_inputs(n)
+    pub, priv = engine.ed25519_keypair(esk, threads=threads)
+    sig = engine.ed25519_sign(priv, msg, threads=threads)
+    bsig, bmsg, bad = synth.corrupt_for_verify(sig, msg)
+    ok = engine.ed25519_verify(bsig, pub, bmsg, threads=threads)
+    return {"n": n, "x25519_shared": sha(shared), "x25519_sk_clamped": sha(clamped), "ed25519_pub": sha(pub),
+            "ed25519_priv": sha(priv), "ed25519_sig": sha(sig), "ed25519_verdicts": sha(ok.astype("<i4")),
+            "verify_rejected": int(bad.sum())}
+
+
+@pytest.mark.parametrize("n", [k for k in ("1024", "4096", str(1 << 20)) if k in DIG])
+def test_seeded_batch_digests(oracle, n):
+    """Config 1 (N=4096) and the full-size N=2^20 batches: oracle outputs hash to the reference's digests."""
+    assert seeded_digests(oracle, int(n), THREADS) == DIG[n]
+
+
+def test_against_reference_build(oracle, reference):
+    """Direct differential test against the real reference library (only where oracle/_ref exists)."""
+    n = 384
+    sk = synth.random_bytes((n, 32), 0xD1FF01)
+    pk = synth.random_bytes((n, 32), 0xD1FF02)
+    pk[:8] = 0xff                                   # 2^256-1 rows
+    a, b = oracle.x25519_shared(pk, sk), reference.x25519_shared(pk, sk)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for fast in (False, True):
+        assert np.array_equal(oracle.x25519_public(sk, fast=fast)[0], reference.x25519_public(sk, fast=fast)[0])
+    pub, priv = oracle.ed25519_keypair(sk)
+    rpub, rpriv = reference.ed25519_keypair(sk)
+    assert np.array_equal(pub, rpub) and np.array_equal(priv, rpriv)
+    for mlen in (0, 1, 32, 100, 200):
+        msg = synth.random_bytes((n, mlen), 0xD1FF03 + mlen)
+        sig = oracle.ed25519_sign(priv, msg)
+        assert np.array_equal(sig, reference.ed25519_sign(priv, msg)), mlen
+        bad = sig.copy()
+        bad[::3, 7] ^= 4
+        assert np.array_equal(oracle.ed25519_verify(bad, pub, msg), reference.ed25519_verify(bad, pub, msg))
+    # garbage keys and signatures: no validation anywhere, verdicts must still agree
+    gs, gp = synth.random_bytes((n, 64), 11), synth.random_bytes((n, 32), 12)
+    msg = synth.random_bytes((n, 32), 13)
+    assert np.array_equal(oracle.ed25519_verify(gs, gp, msg), reference.ed25519_verify(gs, gp, msg))
+    assert np.array_equal(oracle.base_table(), reference.base_table())
