@@ -19,7 +19,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,40 +40,45 @@ def measured_mad_peak():
         return None
 
 
-def cpu_baseline(n_per_thread=2048):
-    """Time curve25519_dh_CreateSharedKey on the host cores: the real reference (portable C) when its
-    prebuilt library travelled with the repo, else the oracle port.  Bounded sample, same input
-    distribution as the GPU workload."""
+def cpu_baseline(n_per_thread=8192):
+    """Time curve25519_dh_CreateSharedKey (plus Ed25519 sign / verify) on the host cores: the real reference
+    (portable-C build, oracle/_ref) when its prebuilt library travelled with the repo, else the oracle port.
+    A C thread pool fans one contiguous slice per core; bounded sample, same input distribution as the GPU
+    workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     from oracle_lib import Oracle, Reference
     from curve25519_amd import synth
     cores = os.cpu_count() or 1
     n = n_per_thread * cores
     sk, pk = synth.x25519_inputs(n)
+    esk, msg = synth.ed25519_inputs(cores * 256)
+    orc = Oracle()
+    pub, priv = orc.ed25519_keypair(esk, threads=cores)
     if Reference.available():
-        ref = Reference()
-        kind = "reference"
-
-        def work(lo, hi):
-            ref.x25519_shared(pk[lo:hi], sk[lo:hi])       # ctypes releases the GIL inside each call
+        ref, kind = Reference(), "reference"
+        shared = lambda p, s, t: ref.x25519_shared_threaded(p, s, t)          # noqa: E731
+        sign = lambda t: ref.ed25519_sign_threaded(priv, msg, t)              # noqa: E731
+        verify = lambda sg, t: ref.ed25519_verify_threaded(sg, pub, msg, t)   # noqa: E731
     else:
-        orc = Oracle()
         kind = "port"
+        shared = lambda p, s, t: orc.x25519_shared(p, s, threads=t)           # noqa: E731
+        sign = lambda t: orc.ed25519_sign(priv, msg, threads=t)               # noqa: E731
+        verify = lambda sg, t: orc.ed25519_verify(sg, pub, msg, threads=t)    # noqa: E731
 
-        def work(lo, hi):
-            orc.x25519_shared(pk[lo:hi], sk[lo:hi], threads=1)
+    def rate(fn, count):
+        t0 = time.perf_counter()
+        out = fn()
+        return count / (time.perf_counter() - t0), out
 
-    t0 = time.perf_counter()
-    work(0, n_per_thread)
-    single = n_per_thread / (time.perf_counter() - t0)
-    threads = [threading.Thread(target=work, args=(i * n_per_thread, (i + 1) * n_per_thread)) for i in range(cores)]
-    t0 = time.perf_counter()
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    multi = n / (time.perf_counter() - t0)
+    single, _ = rate(lambda: shared(pk[:4096], sk[:4096], 1), 4096)         # config 1: 4096 sequential calls
+    # all cores, in rounds of 1024 per thread, until the sample is used up or ~10 s have gone by
+    done, t0, chunk = 0, time.perf_counter(), 1024 * cores
+    while done < n and time.perf_counter() - t0 < 10.0:
+        shared(pk[done:done + chunk], sk[done:done + chunk], cores)
+        done += chunk
+    multi, n = done / (time.perf_counter() - t0), done
+    sign_rate, sig = rate(lambda: sign(cores), cores * 256)
+    verify_rate, ok = rate(lambda: verify(sig, cores), cores * 256)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -82,8 +86,11 @@ def cpu_baseline(n_per_thread=2048):
     except Exception:
         pass
     return {"value": round(multi, 1), "unit": "X25519 shared-key ops/s", "cores": cores, "kind": kind,
-            "sample": f"{n} curve25519_dh_CreateSharedKey calls ({n_per_thread} per thread, {cores} threads), "
-                      f"seeded uniform sk/pk", "single_core_ops_per_s": round(single, 1), "cpu_model": model}
+            "sample": f"{n} curve25519_dh_CreateSharedKey calls over {cores} threads "
+                      f"(C thread pool, one contiguous slice each); seeded uniform sk/pk",
+            "single_core_ops_per_s": round(single, 1), "ed25519_sign_per_s": round(sign_rate, 1),
+            "ed25519_verify_per_s": round(verify_rate, 1), "ed25519_verify_all_valid": bool(ok.all()),
+            "cpu_model": model}
 
 
 def main():

@@ -88,6 +88,13 @@ void orc_ed25519_sign_batch(uint8_t *sig, const uint8_t *priv, const uint8_t *ms
 void orc_ed25519_verify_batch(int32_t *ok, const uint8_t *sig, const uint8_t *pk, const uint8_t *msg,
                               size_t msg_size, size_t n, int nthreads);
 
+/* the REAL reference library (oracle/_ref) driven over a thread pool: the timed CPU baseline of bench.py */
+int orc_ref_x25519_shared_batch(const char *so_path, uint8_t *shared, const uint8_t *pk, uint8_t *sk, size_t n, int nthreads);
+int orc_ref_ed25519_sign_batch(const char *so_path, uint8_t *sig, const uint8_t *priv, const uint8_t *msg, size_t msg_size,
+                               size_t n, int nthreads);
+int orc_ref_ed25519_verify_batch(const char *so_path, int32_t *ok, const uint8_t *sig, const uint8_t *pk, const uint8_t *msg,
+                                 size_t msg_size, size_t n, int nthreads);
+
 /* deterministic input generator shared by oracle, tests and bench (splitmix64 stream) */
 void orc_fill_random(uint8_t *dst, size_t nbytes, uint64_t seed);
 

@@ -195,6 +195,42 @@ class Reference:
             ok[i] = self.lib.ed25519_VerifySignature(_p(sig[i]), _p(pk[i]), _p(msg[i]), msg.shape[1])
         return ok
 
+    # threaded drivers (C thread pool in liborc25519.so calling into the dlopen'ed reference)
+    def _drv(self):
+        build_oracle()
+        d = C.CDLL(ORC_SO)
+        d.orc_ref_x25519_shared_batch.argtypes = [C.c_char_p, u8p, u8p, u8p, C.c_size_t, C.c_int]
+        d.orc_ref_ed25519_sign_batch.argtypes = [C.c_char_p, u8p, u8p, u8p, C.c_size_t, C.c_size_t, C.c_int]
+        d.orc_ref_ed25519_verify_batch.argtypes = [C.c_char_p, C.POINTER(C.c_int32), u8p, u8p, u8p, C.c_size_t,
+                                                   C.c_size_t, C.c_int]
+        return d
+
+    def x25519_shared_threaded(self, pk, sk, threads):
+        pk = np.ascontiguousarray(pk, dtype=np.uint8)
+        sk = np.array(sk, dtype=np.uint8, copy=True, order="C")
+        out = np.empty_like(pk)
+        rc = self._drv().orc_ref_x25519_shared_batch(REF_SO.encode(), _p(out), _p(pk), _p(sk), pk.shape[0], threads)
+        assert rc == 0
+        return out, sk
+
+    def ed25519_sign_threaded(self, priv, msg, threads):
+        priv = np.ascontiguousarray(priv, dtype=np.uint8)
+        n = priv.shape[0]
+        msg = _rows(np.ascontiguousarray(msg, dtype=np.uint8), n)
+        sig = np.empty((n, 64), np.uint8)
+        assert self._drv().orc_ref_ed25519_sign_batch(REF_SO.encode(), _p(sig), _p(priv), _p(msg), msg.shape[1], n, threads) == 0
+        return sig
+
+    def ed25519_verify_threaded(self, sig, pk, msg, threads):
+        sig = np.ascontiguousarray(sig, dtype=np.uint8)
+        pk = np.ascontiguousarray(pk, dtype=np.uint8)
+        n = sig.shape[0]
+        msg = _rows(np.ascontiguousarray(msg, dtype=np.uint8), n)
+        ok = np.empty(n, np.int32)
+        assert self._drv().orc_ref_ed25519_verify_batch(REF_SO.encode(), ok.ctypes.data_as(C.POINTER(C.c_int32)), _p(sig),
+                                                        _p(pk), _p(msg), msg.shape[1], n, threads) == 0
+        return ok
+
     def base_table(self):
         t = (C.c_uint8 * (256 * 96)).in_dll(self.lib, "_w_base_folding8")
         return np.frombuffer(bytes(t), np.uint8).reshape(256, 3, 32).copy()

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 rocpd (.db) outputs into the small text files kept under profiles/.
+
+    python tools/rocpd_summary.py stats gpurun_out/prof_stats/stats_results.db
+    python tools/rocpd_summary.py pmc   gpurun_out/prof_fetch/fetch_results.db [more.db ...]
+"""
+import sqlite3
+import sys
+
+
+def short(name):
+    return name.split("(")[0][:60]
+
+
+def stats(path):
+    db = sqlite3.connect(path)
+    print(f"# rocprofv3 --kernel-trace --stats   ({path})")
+    print(f"{'kernel':<28}{'calls':>6}{'total_ms':>12}{'avg_ms':>12}{'min_ms':>12}{'max_ms':>12}{'pct':>8}  grid x wg  vgpr agpr sgpr lds")
+    rows = db.execute(
+        "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(grid_x), max(workgroup_x),"
+        " max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size) from kernels group by name order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows)
+    for r in rows:
+        print(f"{short(r[0]):<28}{r[1]:>6}{r[2]/1e6:>12.3f}{r[3]/1e6:>12.4f}{r[4]/1e6:>12.4f}{r[5]/1e6:>12.4f}{100*r[2]/total:>8.2f}"
+              f"  {r[6]} x {r[7]}  {r[8]} {r[9]} {r[10]} {r[11]}")
+
+
+def pmc(paths):
+    for path in paths:
+        db = sqlite3.connect(path)
+        print(f"# rocprofv3 --pmc   ({path})   per-dispatch averages")
+        rows = db.execute(
+            "select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+            "group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
+        print(f"{'kernel':<28}{'counter':<26}{'dispatches':>10}{'avg_value':>20}{'avg_dispatch_ms':>18}")
+        for k, c, n, v, d in rows:
+            if k.startswith(("void at::", "__amd")):
+                continue
+            print(f"{short(k):<28}{c:<26}{n:>10}{v:>20.2f}{d/1e6:>18.4f}")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2:])
