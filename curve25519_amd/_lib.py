@@ -23,6 +23,10 @@ SIGNATURES = {
     "ed25519_VerifySignature_batch": [_vp, _vp, _vp, _vp, _sz, _sz],
     "ed25519_VerifySignature_dev": [_vp, _vp, _vp, _vp, _sz, _sz, _vp],
     "ed25519_VerifySignature_scratch_bytes": [_sz],
+    "ed25519_Verify_Init_batch": [_vp, _vp, _sz],
+    "ed25519_Verify_Init_dev": [_vp, _vp, _sz, _vp],
+    "ed25519_Verify_Check_batch": [_vp, _vp, _vp, _vp, _sz, _sz],
+    "ed25519_Verify_Check_dev": [_vp, _vp, _vp, _vp, _sz, _sz, _vp],
     "c25519_amd_base_table": [_vp],
     "c25519_amd_device_count": [],
     "c25519_amd_set_device": [C.c_int],

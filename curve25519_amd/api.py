@@ -95,6 +95,28 @@ def ed25519_VerifySignature(sig, pk, msg):
     return ok
 
 
+def ed25519_Verify_Init(pk):
+    """n x ed25519_Verify_Init: per-key contexts, uint8[n, 2080] (pk || 16 rows x 4 canonical elements)."""
+    pk = _np(pk, 32, "pk")
+    ctx = np.empty((pk.shape[0], 2080), np.uint8)
+    _lib.check(_lib.load().ed25519_Verify_Init_batch(_ptr(ctx), _ptr(pk), pk.shape[0]), "ed25519_Verify_Init_batch")
+    return ctx
+
+
+def ed25519_Verify_Check(ctx, sig, msg):
+    """One key (a 2080-byte context), n (signature, message) pairs -> int32[n] verdicts."""
+    ctx = np.ascontiguousarray(ctx, dtype=np.uint8).reshape(-1)
+    if ctx.size != 2080:
+        raise ValueError("ctx must be one 2080-byte context")
+    sig = _np(sig, 64, "sig")
+    n = sig.shape[0]
+    msg, msg_size = _msgs(msg, n)
+    ok = np.empty(n, np.int32)
+    _lib.check(_lib.load().ed25519_Verify_Check_batch(_ptr(ok), _ptr(ctx), _ptr(sig), _ptr(msg), msg_size, n),
+               "ed25519_Verify_Check_batch")
+    return ok
+
+
 def base_folding8_table():
     """(256, 3, 32) uint8: the device-generated 8-fold base table in the reference's PA_POINT row order."""
     out = np.empty((256, 3, 32), np.uint8)

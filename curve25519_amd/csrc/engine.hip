@@ -219,50 +219,60 @@ __global__ void __launch_bounds__(ED_BLOCK) k_ed25519_sign(void* sig, const void
     store32(sig, 2 * i + 1, s);
 }
 
-// ed25519_VerifySignature (ed25519_verify.c:163-173) = Verify_Init (:179-232) + Verify_Check (:287-313)
-__global__ void __launch_bounds__(ED_BLOCK) k_ed25519_verify(int* verdict, const void* sig, const void* pk,
-                                                              const uint8_t* msg, size_t msg_size, size_t n,
-                                                              const u32* __restrict__ g_tbl, u32* scratch)
+// ed25519_Verify_Init (ed25519_verify.c:179-232): decompress -A (inverted parity :192-195, no validation) and
+// fill the key's 16-row 4-fold table.  `tables` holds n tables of Tbl's format, `stride_words` apart.
+template <typename Tbl>
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_init(const void* pk, size_t n, u32* tables,
+                                                                      size_t stride_words)
+{
+    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u32 yw[8];
+    load32(yw, pk, i);
+    const u32 parity = yw[7] >> 31;
+    yw[7] &= 0x7fffffffu;
+    ge_ext Q;
+    fe_from_words(Q.Y, yw);
+    ge_calc_x(Q.X, Q.Y, ~parity);
+    fe_mul(Q.T, Q.X, Q.Y);
+    fe_set_u32(Q.Z, 1);
+    const Tbl tbl{ tables + i * stride_words };
+    qtable_build(tbl, Q);
+}
+
+// ed25519_Verify_Check (ed25519_verify.c:287-313): h = H(enc(R) || pk || m) mod L canonical; s = raw 256
+// bits (no s < L check, :308); T = s*B + h*(-A); verdict = (enc(T) == enc(R)).
+// pk_stride / table stride 0 = one key for the whole batch (two-phase API), otherwise one key per element.
+template <typename Tbl>
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check(int* verdict, const void* sig, const void* pk,
+                                                                       size_t pk_stride, const uint8_t* msg,
+                                                                       size_t msg_size, size_t n,
+                                                                       const u32* __restrict__ g_tbl, u32* tables,
+                                                                       size_t stride_words)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
     lds_stage_base_table(lds_tbl, g_tbl);
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const u32 lane = threadIdx.x & 63u;
-    u32* wave_tbl = scratch + (i >> 6) * QTABLE_WORDS_PER_WAVE;
 
-    u32 Rw[8], Sw[8], pkw[8];
+    u32 Rw[8], Sw[8], h[8];
     load32(Rw, sig, 2 * i);
     load32(Sw, sig, 2 * i + 1);
-    load32(pkw, pk, i);
-
-    // --- Verify_Init: decompress -A (inverted parity, :192-195), no validation, build the 4-fold table
     {
-        u32 yw[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) yw[j] = pkw[j];
-        const u32 parity = yw[7] >> 31;
-        yw[7] &= 0x7fffffffu;
-        ge_ext Q;
-        fe_from_words(Q.Y, yw);
-        ge_calc_x(Q.X, Q.Y, ~parity);
-        fe_mul(Q.T, Q.X, Q.Y);
-        fe_set_u32(Q.Z, 1);
-        qtable_build(wave_tbl, lane, Q);
+        u32 pkw[8], le[16];
+        u64 pre[8], dg[8];
+        load32(pkw, pk, i * pk_stride);
+        sha512_words_from_le32(pre, Rw);
+        sha512_words_from_le32(pre + 4, pkw);
+        sha512_prefixed<8>(dg, pre, msg + i * msg_size, msg_size);
+        sha512_digest_le_words(le, dg);
+        sc_reduce512(h, le);
+        sc_mod(h);
     }
 
-    // --- Verify_Check: h = H(enc(R) || pk || m) mod L canonical; s = raw 256 bits, no s < L check (:308)
-    u64 pre[8], dg[8];
-    sha512_words_from_le32(pre, Rw);
-    sha512_words_from_le32(pre + 4, pkw);
-    sha512_prefixed<8>(dg, pre, msg + i * msg_size, msg_size);
-    u32 le[16], h[8];
-    sha512_digest_le_words(le, dg);
-    sc_reduce512(h, le);
-    sc_mod(h);
-
+    const Tbl tbl{ tables + i * stride_words };
     ge_ext T;
-    ge_poly_mult(T, Sw, h, wave_tbl, lane, lds_tbl);
+    ge_poly_mult(T, Sw, h, tbl, lds_tbl);
     u32 xw[8], yw[8], enc[8];
     ge_to_affine_words(xw, yw, T);
     ge_pack(enc, xw, yw);
@@ -270,6 +280,72 @@ __global__ void __launch_bounds__(ED_BLOCK) k_ed25519_verify(int* verdict, const
 #pragma unroll
     for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
     verdict[i] = diff == 0 ? 1 : 0;           // memcmp(md, signature, 32) == 0   (:312)
+}
+
+// Same check with ONE key for the whole batch (the reference's two-phase use: Verify_Init once, many
+// Verify_Check calls, ed25519_verify.c:282-286).  ctx is the 2080-byte context (pk || 16 canonical rows); the
+// workgroup converts it once into limb form in LDS (limb-major, 16 rows wide: the 16 possible row indices
+// of a lookup fall into 16 different banks).
+struct QTableLds {
+    const u32* base;                                       // [40][16]
+    C25519_DEV void load(ge_pe& q, u32 e) const
+    {
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            q.ypx.v[i] = base[(i) * 16 + e];
+            q.ymx.v[i] = base[(10 + i) * 16 + e];
+            q.t2d.v[i] = base[(20 + i) * 16 + e];
+            q.z2.v[i] = base[(30 + i) * 16 + e];
+        }
+    }
+};
+
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(int* verdict, const void* sig,
+                                                                              const u32* __restrict__ ctx,
+                                                                              const uint8_t* msg, size_t msg_size,
+                                                                              size_t n, const u32* __restrict__ g_tbl)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
+    __shared__ u32 lds_q[PE_WORDS * 16];
+    if (threadIdx.x < 64) {                                // 16 rows x 4 field elements
+        const u32 row = threadIdx.x >> 2, f = threadIdx.x & 3;
+        u32 w[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j] = ctx[8 + row * 32 + f * 8 + j];
+        fe v;
+        fe_from_words(v, w);
+#pragma unroll
+        for (int l = 0; l < 10; l++) lds_q[(10 * f + l) * 16 + row] = v.v[l];
+    }
+    lds_stage_base_table(lds_tbl, g_tbl);                  // ends with __syncthreads()
+    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    if (i >= n) return;
+
+    u32 Rw[8], Sw[8], h[8];
+    load32(Rw, sig, 2 * i);
+    load32(Sw, sig, 2 * i + 1);
+    {
+        u32 pkw[8], le[16];
+        u64 pre[8], dg[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) pkw[j] = ctx[j];
+        sha512_words_from_le32(pre, Rw);
+        sha512_words_from_le32(pre + 4, pkw);
+        sha512_prefixed<8>(dg, pre, msg + i * msg_size, msg_size);
+        sha512_digest_le_words(le, dg);
+        sc_reduce512(h, le);
+        sc_mod(h);
+    }
+    const QTableLds tbl{ lds_q };
+    ge_ext T;
+    ge_poly_mult(T, Sw, h, tbl, lds_tbl);
+    u32 xw[8], yw[8], enc[8];
+    ge_to_affine_words(xw, yw, T);
+    ge_pack(enc, xw, yw);
+    u32 diff = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
+    verdict[i] = diff == 0 ? 1 : 0;
 }
 
 // ================================================================================================
@@ -426,7 +502,7 @@ int ed25519_SignMessage_dev(void* sig, const void* priv, const void* msg, size_t
 
 size_t ed25519_VerifySignature_scratch_bytes(size_t n)
 {
-    return ((n + 63) / 64) * QTABLE_WORDS_PER_WAVE * sizeof(u32);
+    return n * QTABLE_LIMB_WORDS * sizeof(u32);
 }
 
 int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, const void* msg, size_t msg_size,
@@ -439,8 +515,39 @@ int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, 
     if (int rc = base_tables(&tbl, nullptr)) return rc;
     void* scratch = nullptr;
     if (int rc = verify_scratch(&scratch, n)) return rc;
-    k_ed25519_verify<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
-        (int*)verdict, sig, pk, (const uint8_t*)msg, msg_size, n, tbl, (u32*)scratch);
+    k_ed25519_verify_init<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
+        pk, n, (u32*)scratch, QTABLE_LIMB_WORDS);
+    C25519_TRY(hipGetLastError());
+    k_ed25519_verify_check<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
+        (int*)verdict, sig, pk, 1, (const uint8_t*)msg, msg_size, n, tbl, (u32*)scratch, QTABLE_LIMB_WORDS);
+    C25519_TRY(hipGetLastError());
+    return 0;
+}
+
+// two-phase verification on the device: contexts are 2080-byte records (pk || 16 x 128-byte canonical rows),
+// the reference's EDP_SIGV_CTX size and row order.
+int ed25519_Verify_Init_dev(void* ctx, const void* pk, size_t n, void* stream)
+{
+    if (!ctx || !pk) return bad_arg("null pointer");
+    if (int rc = check_dev_args(n, { ctx, pk })) return rc;
+    if (n == 0) return 0;
+    C25519_TRY(hipMemcpy2DAsync(ctx, 2080, pk, 32, 32, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    k_ed25519_verify_init<QTableCanon><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
+        pk, n, (u32*)ctx + 8, 2080 / 4);
+    C25519_TRY(hipGetLastError());
+    return 0;
+}
+
+int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, const void* msg, size_t msg_size,
+                             size_t n, void* stream)
+{
+    if (!verdict || !ctx || !sig || (!msg && msg_size)) return bad_arg("null pointer");
+    if (int rc = check_dev_args(n, { ctx, sig })) return rc;
+    if (n == 0) return 0;
+    const u32* tbl = nullptr;
+    if (int rc = base_tables(&tbl, nullptr)) return rc;
+    k_ed25519_verify_check_shared<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
+        (int*)verdict, sig, (const u32*)ctx, (const uint8_t*)msg, msg_size, n, tbl);
     C25519_TRY(hipGetLastError());
     return 0;
 }
@@ -617,22 +724,54 @@ void ed25519_Blinding_Finish(void* context)
     }
 }
 
-// Two-phase verification keeps the key in the context and defers all arithmetic to Verify_Check,
-// which runs the same fused device kernel as ed25519_VerifySignature.  The context is the caller's
-// 2080-byte storage (reference EDP_SIGV_CTX) or malloc'ed here.
-struct sigv_ctx { unsigned char pk[32]; unsigned char reserved[2048]; };
+// Two-phase verification.  The context is the reference's EDP_SIGV_CTX shape (2080 bytes: pk, then 16
+// rows of four canonical field elements), filled by the device; it lives in the caller's storage or is
+// malloc'ed here, exactly as in the reference (ed25519_verify.c:179-237).
+int ed25519_Verify_Init_batch(void* ctx, const unsigned char* pk, size_t n)
+{
+    if (!ctx || !pk) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    Staging& s = staging();
+    C25519_RC(s.ensure_stream());
+    C25519_RC(up(s, 0, pk, 32 * n));
+    C25519_RC(s.reserve(1, 2080 * n));
+    C25519_RC(ed25519_Verify_Init_dev(s.ptr[1], s.ptr[0], n, s.stream));
+    C25519_RC(down(s, ctx, 1, 2080 * n));
+    C25519_TRY(hipStreamSynchronize(s.stream));
+    return 0;
+}
+
+int ed25519_Verify_Check_batch(int* verdict, const void* ctx, const unsigned char* sig, const unsigned char* msg,
+                               size_t msg_size, size_t n)
+{
+    if (!verdict || !ctx || !sig || (!msg && msg_size)) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    Staging& s = staging();
+    C25519_RC(s.ensure_stream());
+    C25519_RC(up(s, 0, sig, 64 * n));
+    C25519_RC(up(s, 1, ctx, 2080));
+    C25519_RC(up(s, 2, msg, msg_size * n));
+    C25519_RC(s.reserve(3, sizeof(int) * n));
+    C25519_RC(ed25519_Verify_Check_dev(s.ptr[3], s.ptr[1], s.ptr[0], s.ptr[2], msg_size, n, s.stream));
+    C25519_RC(down(s, verdict, 3, sizeof(int) * n));
+    C25519_TRY(hipStreamSynchronize(s.stream));
+    return 0;
+}
 
 void* ed25519_Verify_Init(void* context, const unsigned char* publicKey)
 {
-    sigv_ctx* ctx = (sigv_ctx*)context;
-    if (!ctx) ctx = (sigv_ctx*)malloc(sizeof(sigv_ctx));
-    if (ctx) memcpy(ctx->pk, publicKey, 32);
+    void* ctx = context ? context : malloc(2080);
+    if (!ctx) return nullptr;                  // allocation failure is the only error the reference reports
+    if (int rc = ed25519_Verify_Init_batch(ctx, publicKey, 1)) c25519_host::die(__func__, rc);
     return ctx;
 }
 
 int ed25519_Verify_Check(const void* context, const unsigned char* signature, const unsigned char* msg, size_t msg_size)
 {
-    return ed25519_VerifySignature(signature, ((const sigv_ctx*)context)->pk, msg, msg_size);
+    int verdict = 0;
+    if (int rc = ed25519_Verify_Check_batch(&verdict, context, signature, msg, msg_size, 1))
+        c25519_host::die(__func__, rc);
+    return verdict;
 }
 
 void ed25519_Verify_Finish(void* ctx) { free(ctx); }

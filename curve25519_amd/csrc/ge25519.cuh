@@ -203,49 +203,85 @@ C25519_DEV void ge_pack(u32 (&out)[8], const u32 (&xw)[8], const u32 (&yw)[8])
     out[7] = (yw[7] & 0x7fffffffu) | (xw[0] << 31);
 }
 
-// ---- per-lane 4-fold table in global scratch --------------------------------------------------------
-// One 16-row table of PE points per lane: 16 * 40 limbs.  A wave's tables are interleaved so that a
-// 16-byte access by 64 lanes is one contiguous KiB:  word (e, g, lane, c) at ((e*10 + g)*64 + lane)*4 + c,
-// g = limb group of four, c = limb in group.  160 KiB per wave.
-constexpr size_t QTABLE_WORDS_PER_WAVE = 16 * PE_WORDS * 64;
+// ---- 4-fold tables (verify) ------------------------------------------------------------------------------
+// 16 rows of PE points, q_table[k] = sum over set bits i of k of 2^(64 i) * Q   (ed25519_Verify_Init :199-229).
+// Two storage formats behind the same load/store interface:
+//   QTableLimbs -- lane-private rows of 40 limbs (160 B) in a global scratch slab, rows of one lane contiguous
+//                  (2560 B per lane).  A row lookup by a secret index touches 3 cache lines of that lane's
+//                  own memory; no conversion work.  Used by the one-shot ed25519_VerifySignature path.
+//   QTableCanon -- the reference's EDP_SIGV_CTX row layout: 4 field elements of 8 canonical words (128 B per
+//                  row, 2048 B per table).  This is what ed25519_Verify_Init hands back to the caller
+//                  (fits the reference's 2080-byte context) and what Verify_Check consumes.
+constexpr size_t QTABLE_LIMB_WORDS = 16 * PE_WORDS;       // per lane
+constexpr size_t QTABLE_CANON_WORDS = 16 * 32;            // per table
 
-C25519_DEV void qtable_store(u32* wave_tbl, u32 lane, int e, const ge_pe& q)
-{
-    uint4* base = reinterpret_cast<uint4*>(wave_tbl) + (size_t)e * 10 * 64 + lane;
-    const fe* f[4] = { &q.ypx, &q.ymx, &q.t2d, &q.z2 };
-    u32 w[PE_WORDS];
+struct QTableLimbs {
+    u32* base;                                             // this lane's 16 rows
+    C25519_DEV void store(int e, const ge_pe& q) const
+    {
+        uint4* row = reinterpret_cast<uint4*>(base + (size_t)e * PE_WORDS);
+        const fe* f[4] = { &q.ypx, &q.ymx, &q.t2d, &q.z2 };
+        u32 w[PE_WORDS];
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int i = 0; i < 10; i++) w[10 * j + i] = f[j]->v[i];
+            for (int i = 0; i < 10; i++) w[10 * j + i] = f[j]->v[i];
 #pragma unroll
-    for (int g = 0; g < 10; g++) base[g * 64] = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
-}
-
-C25519_DEV void qtable_load(ge_pe& q, const u32* wave_tbl, u32 lane, u32 e)
-{
-    const uint4* base = reinterpret_cast<const uint4*>(wave_tbl) + (size_t)e * 10 * 64 + lane;
-    u32 w[PE_WORDS];
-#pragma unroll
-    for (int g = 0; g < 10; g++) {
-        const uint4 v = base[g * 64];
-        w[4 * g] = v.x; w[4 * g + 1] = v.y; w[4 * g + 2] = v.z; w[4 * g + 3] = v.w;
+        for (int g = 0; g < 10; g++) row[g] = make_uint4(w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]);
     }
+    C25519_DEV void load(ge_pe& q, u32 e) const
+    {
+        const uint4* row = reinterpret_cast<const uint4*>(base + (size_t)e * PE_WORDS);
+        u32 w[PE_WORDS];
 #pragma unroll
-    for (int i = 0; i < 10; i++) {
-        q.ypx.v[i] = w[i]; q.ymx.v[i] = w[10 + i]; q.t2d.v[i] = w[20 + i]; q.z2.v[i] = w[30 + i];
+        for (int g = 0; g < 10; g++) {
+            const uint4 v = row[g];
+            w[4 * g] = v.x; w[4 * g + 1] = v.y; w[4 * g + 2] = v.z; w[4 * g + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            q.ypx.v[i] = w[i]; q.ymx.v[i] = w[10 + i]; q.t2d.v[i] = w[20 + i]; q.z2.v[i] = w[30 + i];
+        }
     }
-}
+};
 
-// q_table[k] = sum over set bits i of k of 2^(64 i) * Q, k = 0..15   (ed25519_Verify_Init :199-229)
-C25519_DEV void qtable_build(u32* wave_tbl, u32 lane, ge_ext& Q)
+struct QTableCanon {
+    u32* base;                                             // 16 rows x (YpX, YmX, T2d, Z2) x 8 words
+    C25519_DEV void store(int e, const ge_pe& q) const
+    {
+        uint4* row = reinterpret_cast<uint4*>(base + (size_t)e * 32);
+        const fe* f[4] = { &q.ypx, &q.ymx, &q.t2d, &q.z2 };
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u32 w[8];
+            fe_to_words(w, *f[j]);
+            row[2 * j] = make_uint4(w[0], w[1], w[2], w[3]);
+            row[2 * j + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+    }
+    C25519_DEV void load(ge_pe& q, u32 e) const
+    {
+        const uint4* row = reinterpret_cast<const uint4*>(base + (size_t)e * 32);
+        fe* f[4] = { &q.ypx, &q.ymx, &q.t2d, &q.z2 };
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint4 a = row[2 * j], b = row[2 * j + 1];
+            const u32 w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+            fe_from_words(*f[j], w);
+        }
+    }
+};
+
+// fill all 16 rows from Q (= -A).  Q is consumed.
+template <typename Tbl>
+C25519_DEV void qtable_build(const Tbl& tbl, ge_ext& Q)
 {
     ge_pe pe;
     ge_ext T;
     fe_set_u32(pe.ypx, 1); fe_set_u32(pe.ymx, 1); fe_set_u32(pe.t2d, 0); fe_set_u32(pe.z2, 2);
-    qtable_store(wave_tbl, lane, 0, pe);
+    tbl.store(0, pe);
     ge_to_pe(pe, Q);
-    qtable_store(wave_tbl, lane, 1, pe);
+    tbl.store(1, pe);
 
 #pragma unroll 1
     for (int blk = 1; blk < 4; blk++) {               // Q <- 2^64 Q, then fill rows [2^blk, 2^(blk+1))
@@ -253,29 +289,30 @@ C25519_DEV void qtable_build(u32* wave_tbl, u32 lane, ge_ext& Q)
         for (int i = 0; i < 64; i++) ge_double(Q);
         const int top = 1 << blk;
         ge_to_pe(pe, Q);
-        qtable_store(wave_tbl, lane, top, pe);
+        tbl.store(top, pe);
 #pragma unroll 1
         for (int s = 1; s < top; s++) {               // row top+s = Q + row s   (QTABLE_SET, :175-177)
-            qtable_load(pe, wave_tbl, lane, (u32)s);
+            tbl.load(pe, (u32)s);
             ge_add_pe(T, Q, pe);
             ge_to_pe(pe, T);
-            qtable_store(wave_tbl, lane, top + s, pe);
+            tbl.store(top + s, pe);
         }
     }
 }
 
 // S = s*B + h*Q by the interleaved 4-fold / 8-fold walk   (edp_PolyPointMultiply :243-280).
 // s and h (8 words each) are consumed.
-C25519_DEV void ge_poly_mult(ge_ext& S, u32 (&s)[8], u32 (&h)[8], const u32* wave_tbl, u32 lane, const u32* lds_tbl)
+template <typename Tbl>
+C25519_DEV void ge_poly_mult(ge_ext& S, u32 (&s)[8], u32 (&h)[8], const Tbl& tbl, const u32* lds_tbl)
 {
     ge_pe pe;
     ge_pa pa;
-    qtable_load(pe, wave_tbl, lane, fold4_next(h, false));
+    tbl.load(pe, fold4_next(h, false));
     ge_from_pe(S, pe);
 #pragma unroll 1
     for (int i = 1; i < 32; i++) {
         ge_double(S);
-        qtable_load(pe, wave_tbl, lane, fold4_next(h, false));
+        tbl.load(pe, fold4_next(h, false));
         ge_add_pe(S, S, pe);
     }
 #pragma unroll 1
@@ -283,7 +320,7 @@ C25519_DEV void ge_poly_mult(ge_ext& S, u32 (&s)[8], u32 (&h)[8], const u32* wav
         ge_double(S);
         lds_load_pa(pa, lds_tbl, fold8_next(s));
         ge_add_pa(S, pa);
-        qtable_load(pe, wave_tbl, lane, fold4_next(h, true));
+        tbl.load(pe, fold4_next(h, true));
         ge_add_pe(S, S, pe);
     }
 }

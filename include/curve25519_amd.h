@@ -67,8 +67,21 @@ int ed25519_VerifySignature_dev(void *verdict, const void *sig, const void *pk, 
                                 size_t msg_size, size_t n, void *stream);
 
 /* bytes of device scratch ed25519_VerifySignature_dev needs for n elements (per-lane 4-fold tables);
- * the library allocates and caches it per host thread. */
+ * the library allocates and caches it per host thread (2560 bytes per element). */
 size_t ed25519_VerifySignature_scratch_bytes(size_t n);
+
+/* Two-phase verification (reference include/ed25519_signature.h:77-93): one key, many signatures.
+ * A context is 2080 bytes -- the reference's EDP_SIGV_CTX size: the 32-byte key followed by the 16-row
+ * 4-fold table of 2^(64i)*(-A) subset sums, four canonical 32-byte field elements per row.
+ *   Verify_Init_batch / _dev : n keys -> n contexts (n x 2080 bytes)
+ *   Verify_Check_batch / _dev: ONE context, n (signature, message) pairs -> n verdicts; this is the
+ *                              amortised path, the per-key table is staged in LDS. */
+int ed25519_Verify_Init_batch(void *ctx, const unsigned char *pk, size_t n);
+int ed25519_Verify_Init_dev(void *ctx, const void *pk, size_t n, void *stream);
+int ed25519_Verify_Check_batch(int *verdict, const void *ctx, const unsigned char *sig,
+                               const unsigned char *msg, size_t msg_size, size_t n);
+int ed25519_Verify_Check_dev(void *verdict, const void *ctx, const void *sig, const void *msg,
+                             size_t msg_size, size_t n, void *stream);
 
 /* introspection used by tests and bench ------------------------------------------------------ */
 /* copies the device-generated 256 x 96-byte 8-fold base table (canonical Y+X, Y-X, 2dT rows --

@@ -221,6 +221,38 @@ def test_device_pointer_entry_points(api, oracle):
         api.curve25519_dh_CreateSharedKey_dev(out, out.view(-1)[1:32 * (n - 1) + 1].view(n - 1, 32), sk[: n - 1])
 
 
+def test_two_phase_verification(api, oracle):
+    """ed25519_Verify_Init once per key, many ed25519_Verify_Check (reference ed25519_verify.c:282-286):
+    same verdicts as the one-shot path and as the oracle; the context has the reference's 2080-byte shape."""
+    nk, n = 5, 3000
+    sk = synth.random_bytes((nk, 32), 0x7001)
+    pub, priv = oracle.ed25519_keypair(sk)
+    ctx = api.ed25519_Verify_Init(pub)
+    assert ctx.shape == (nk, 2080) and np.array_equal(ctx[:, :32], pub)
+    one = (1).to_bytes(32, "little")
+    for k in range(nk):                                   # row 0 is the neutral element (1, 1, 0, 2)
+        assert ctx[k, 32:64].tobytes() == one and ctx[k, 64:96].tobytes() == one
+        assert not ctx[k, 96:128].any() and ctx[k, 128:160].tobytes() == (2).to_bytes(32, "little")
+    for k in range(nk):
+        msg = synth.random_bytes((n, 40), 0x7100 + k)
+        sig = oracle.ed25519_sign(np.repeat(priv[k:k + 1], n, axis=0), msg, threads=THREADS)
+        sig[::7, 3] ^= 0x20
+        msg[1::7, 39] ^= 1
+        sig[2::7, 33] ^= 2
+        got = api.ed25519_Verify_Check(ctx[k], sig, msg)
+        exp = oracle.ed25519_verify(sig, np.repeat(pub[k:k + 1], n, axis=0), msg, threads=THREADS)
+        assert np.array_equal(got, exp)
+        assert np.array_equal(got, api.ed25519_VerifySignature(sig, np.repeat(pub[k:k + 1], n, axis=0), msg))
+        assert 0 < got.sum() < n
+    # garbage keys: Verify_Init never rejects, verdicts still match the oracle
+    gp = synth.random_bytes((4, 32), 0x7200)
+    gctx = api.ed25519_Verify_Init(gp)
+    gs, gm = synth.random_bytes((256, 64), 0x7201), synth.random_bytes((256, 16), 0x7202)
+    for k in range(4):
+        assert np.array_equal(api.ed25519_Verify_Check(gctx[k], gs, gm),
+                              oracle.ed25519_verify(gs, np.repeat(gp[k:k + 1], 256, axis=0), gm))
+
+
 def test_single_call_reference_api(api):
     """The eleven reference entry points, one element at a time (a device batch of one each)."""
     from curve25519_amd import _lib
