@@ -40,6 +40,20 @@ def measured_mad_peak():
         return None
 
 
+def measured_traffic(kernel="k_x25519"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc runs of
+    this same bench, summarised by tools/rocpd_summary.py): WRITE_SIZE + 2 x FETCH_SIZE, both in KiB --
+    the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section) for wide coalesced reads."""
+    try:
+        import glob
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+        with open(path) as f:
+            k = json.load(f)[kernel]
+        return int((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024), os.path.basename(path)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(n_per_thread=8192):
     """Time curve25519_dh_CreateSharedKey (plus Ed25519 sign / verify) on the host cores: the real reference
     (portable-C build, oracle/_ref) when its prebuilt library travelled with the repo, else the oracle port.
@@ -101,6 +115,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="operations per GPU per step (default 2^20)")
     ap.add_argument("--no-extra", action="store_true", help="skip the Ed25519 sign/verify side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="run the N>1 code path (process group + RCCL gather) with a world of one rank")
     args = ap.parse_args()
 
     import torch
@@ -117,8 +133,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.dist_selftest
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.batch
@@ -135,7 +153,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,8 +163,8 @@ def main():
         eng.api.curve25519_dh_CreateSharedKey_dev(out, pk, sk)
         if ev:
             ev[1].record()
-        if world > 1:
-            gather_rows(out, root=0)
+        if use_dist:
+            gather_rows(out, root=0, always=True)
 
     for _ in range(args.warmup):
         step()
@@ -157,7 +175,7 @@ def main():
         step(events[k])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -169,6 +187,7 @@ def main():
         kernel_s = kernel_ms * 1e-3
         achieved_gbs = BYTES_PER_OP["x25519"] * n / kernel_s / 1e9
         peak_mac = measured_mad_peak()
+        traffic, traffic_src = measured_traffic()
         achieved_mac = MACS_PER_OP["x25519"] * n / kernel_s
         result = {
             "metric": "X25519 shared-key ops/sec (batch=2^20 per GPU, variable-base Montgomery ladder)",
@@ -180,7 +199,9 @@ def main():
                        "batch_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "traffic_source": f"profiles/{traffic_src}: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch; includes "
+                                           "the 32 B/op clamped-key write-back the reference API requires" if traffic_src else None,
                          "kernel": "k_x25519", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": BYTES_PER_OP["x25519"] * n,
                          "note": "VALU-integer bound path: HBM fraction is tiny by construction, see roofline_valu"},
@@ -226,7 +247,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -69,9 +69,26 @@ C25519_DEV void fe_neg(fe& r, const fe& a)
     for (int i = 0; i < 10; i++) r.v[i] = fe_2p(i) - a.v[i];
 }
 
-// branch-free select: r = mask ? a : b, mask is all-ones or zero (v_bfi_b32)
+// x + x without letting the compiler turn it back into a shift: on gfx950 v_add_u32 issues at the fast
+// VOP2 rate (~24 lanes/clk/SIMD) while v_lshlrev_b32 runs at the slower VOP3-class rate (~15.8), see
+// profiles/r01_valu_rates_select_shift.txt.
+C25519_DEV u32 dbl32(u32 x)
+{
+#ifdef C25519_DBL_BY_SHIFT
+    return x * 2u;
+#else
+    u32 t = x;
+    asm("" : "+v"(t));
+    return x + t;
+#endif
+}
+
+// branch-free select: r = mask ? a : b, mask is all-ones or zero
 C25519_DEV void fe_select(fe& r, u32 mask, const fe& a, const fe& b)
 {
+#ifdef C25519_SELECT_BFI
+    asm("" : "+v"(mask));                 // keep it a bitwise select (v_bfi_b32) instead of v_cndmask on vcc
+#endif
 #pragma unroll
     for (int i = 0; i < 10; i++) r.v[i] = (a.v[i] & mask) | (b.v[i] & ~mask);
 }
@@ -101,7 +118,7 @@ C25519_DEV void fe_mul(fe& r, const fe& a, const fe& b)
 #pragma unroll
     for (int j = 1; j < 10; j++) b19[j] = b.v[j] * 19u;
 #pragma unroll
-    for (int i = 1; i < 10; i += 2) a2[i] = a.v[i] * 2u;
+    for (int i = 1; i < 10; i += 2) a2[i] = dbl32(a.v[i]);
 
     u64 h[10];
 #pragma unroll
@@ -126,7 +143,7 @@ C25519_DEV void fe_sqr_columns(u64 (&h)[10], const fe& a)
 {
     u32 f2[10], f19[10], f38[10];
 #pragma unroll
-    for (int i = 0; i < 10; i++) f2[i] = a.v[i] * 2u;
+    for (int i = 0; i < 10; i++) f2[i] = dbl32(a.v[i]);
 #pragma unroll
     for (int j = 5; j < 10; j++) f19[j] = a.v[j] * 19u;
 #pragma unroll

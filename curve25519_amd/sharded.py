@@ -21,13 +21,13 @@ def shard_bounds(n: int, world: int) -> List[Tuple[int, int]]:
     return [(n * r // world, n * (r + 1) // world) for r in range(world)]
 
 
-def gather_rows(local: torch.Tensor, root: int = 0, group=None) -> Optional[torch.Tensor]:
+def gather_rows(local: torch.Tensor, root: int = 0, group=None, always: bool = False) -> Optional[torch.Tensor]:
     """Gather each rank's [m_r, w] rows to `root` in rank order (one collective; rows padded to the
     largest shard so that every peer sends the same count).  Returns the concatenation on root, None
     elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
+    if world == 1 and not always:
         return local
     m = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = [torch.zeros_like(m) for _ in range(world)]

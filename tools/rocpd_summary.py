@@ -39,8 +39,25 @@ def pmc(paths):
             print(f"{short(k):<28}{c:<26}{n:>10}{v:>20.2f}{d/1e6:>18.4f}")
 
 
+def pmc_json(paths):
+    """{kernel: {counter: per-dispatch average}} as JSON (read by bench.py for roofline.traffic)."""
+    import json
+    out = {}
+    for path in paths:
+        db = sqlite3.connect(path)
+        for k, c, v, d in db.execute("select kernel_name, counter_name, avg(value), avg(duration) from counters_collection "
+                                     "group by kernel_name, counter_name"):
+            if k.startswith(("void at::", "__amd")):
+                continue
+            out.setdefault(short(k), {})[c] = v
+            out[short(k)].setdefault("dispatch_ms", {})[c] = d / 1e6
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "pmc-json":
+        pmc_json(sys.argv[2:])
     else:
         pmc(sys.argv[2:])

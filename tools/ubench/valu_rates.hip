@@ -120,6 +120,38 @@ __global__ void __launch_bounds__(256) k_rate(unsigned* out, unsigned seed)
 #define X(i) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(q##i) : "v"(a), "v"(b) : "s20", "s21");
             REP8(X) REP8(X)
 #undef X
+        } else if constexpr (KIND == 24) {  // v_cndmask_b32 VOP3 form, mask in an SGPR pair
+#define X(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[22:23]" : "+v"(r##i) : "v"(a) : );
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 25) {  // v_bfi_b32 (bitwise select)
+#define X(i) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(r##i) : "v"(a), "v"(b));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 26) {  // v_and_or_b32
+#define X(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r##i) : "v"(a), "v"(b));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 27) {  // v_cndmask_b32 with vcc freshly written by a v_cmp each time
+#define X(i) asm volatile("v_cmp_lt_u32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(r##i) : "v"(a) : "vcc");
+            REP8(X)
+#undef X
+        } else if constexpr (KIND == 28) {  // v_lshlrev_b32 (VOP2 shift)
+#define X(i) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(r##i));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 29) {  // v_sub_u32
+#define X(i) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 30) {  // v_and_b32
+#define X(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 31) {  // v_mov_b32
+#define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
         } else if constexpr (KIND == 23) {  // v_mad_i32_i24 ... placeholder for v_perm/v_bfe: v_bfe_u32
 #define X(i) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(r##i));
             REP8(X) REP8(X)
@@ -142,6 +174,8 @@ static const Kind kinds[] = {
     {11, "v_mul_hi_u32_u24"}, {8, "v_lshl_add_u64"}, {9, "v_alignbit_b32"}, {10, "v_lshrrev_b64"},
     {23, "v_bfe_u32"}, {12, "v_fma_f32"}, {17, "v_pk_fma_f32"}, {13, "v_cndmask_b32"}, {14, "v_xor_b32"},
     {15, "mix 1 mad64 : 1 addc"}, {16, "mix 1 mad64 : 3 add"},
+    {24, "v_cndmask_b32_e64(sgpr mask)"}, {25, "v_bfi_b32"}, {26, "v_and_or_b32"}, {27, "v_cmp+v_cndmask(vcc)"},
+    {28, "v_lshlrev_b32"}, {29, "v_sub_u32"}, {30, "v_and_b32"}, {31, "v_mov_b32"},
 };
 
 template <int KIND> static void launch(int blocks, unsigned* d, hipStream_t s) { k_rate<KIND><<<blocks, 256, 0, s>>>(d, 1); }
@@ -151,7 +185,7 @@ static void dispatch(int kind, int blocks, unsigned* d, hipStream_t s)
     switch (kind) {
 #define C(k) case k: launch<k>(blocks, d, s); break;
         C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(18)
-        C(19) C(20) C(21) C(22) C(23)
+        C(19) C(20) C(21) C(22) C(23) C(24) C(25) C(26) C(27) C(28) C(29) C(30) C(31)
 #undef C
     }
 }
@@ -170,7 +204,7 @@ int main(int argc, char** argv)
     FILE* jf = json ? fopen(json, "w") : nullptr;
     if (jf) fprintf(jf, "{\"device\": \"%s\", \"cus\": %d, \"clock_ghz\": %.3f, \"rates\": {\n", prop.name, cus, ghz);
     bool first = true;
-    for (int wps : {1, 2, 4, 8}) {               // waves per SIMD: 256-thread block = 1 wave per SIMD
+    for (int wps : {2, 8}) {               // waves per SIMD: 256-thread block = 1 wave per SIMD
         int blocks = cus * wps;
         for (const Kind& k : kinds) {
             dispatch(k.id, blocks, d, s);
