@@ -3,6 +3,13 @@
 // device.  Entry points are declared in include/curve25519_amd.h, include/curve25519_dh.h and
 // include/ed25519_signature.h (each cites the reference prototype it replaces).
 //
+// Every operation is two or three launches on the caller's stream:
+//   1. a "mult" kernel does the scalar multiplication and leaves the PROJECTIVE result in scratch,
+//   2. k_batch_invert turns projective into the canonical output bytes, sharing one field inversion
+//      (the reference's ecp_Inverse, 254 S + 11 M) between K elements per lane with Montgomery's trick --
+//      the reference pays one inversion per call (curve25519_dh.c:148, ed25519_sign.c:265),
+//   3. (sign only) a finish kernel hashes enc(R) || pk || m and computes S.
+//
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared engine.hip -o libcurve25519_amd.so
 #include "capi_common.hpp"
 #include "fe25519.cuh"
@@ -20,8 +27,9 @@
 using namespace c25519;
 
 // ------------------------------------------------------------------------------------------------
-// lane I/O: 32-byte records as two 16-byte accesses (a wave covers 2 KiB of contiguous memory)
+// lane I/O
 // ------------------------------------------------------------------------------------------------
+// 32-byte API records as two 16-byte accesses (a wave covers 2 KiB of contiguous memory)
 C25519_DEV void load32(u32 (&w)[8], const void* base, size_t i)
 {
     const uint4* p = reinterpret_cast<const uint4*>(base) + 2 * i;
@@ -34,6 +42,34 @@ C25519_DEV void store32(void* base, size_t i, const u32 (&w)[8])
     p[0] = make_uint4(w[0], w[1], w[2], w[3]);
     p[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
+// scratch arrays are struct-of-arrays: word w of element i at base[w*n + i], so every access by a wave
+// is one contiguous 256-byte segment whichever element -> lane mapping a kernel uses
+C25519_DEV void soa_store_fe(u32* base, size_t n, size_t i, const fe& f)
+{
+#pragma unroll
+    for (int w = 0; w < 10; w++) base[(size_t)w * n + i] = f.v[w];
+}
+C25519_DEV void soa_load_fe(fe& f, const u32* base, size_t n, size_t i)
+{
+#pragma unroll
+    for (int w = 0; w < 10; w++) f.v[w] = base[(size_t)w * n + i];
+}
+C25519_DEV void soa_store8(u32* base, size_t n, size_t i, const u32 (&v)[8])
+{
+#pragma unroll
+    for (int w = 0; w < 8; w++) base[(size_t)w * n + i] = v[w];
+}
+C25519_DEV void soa_load8(u32 (&v)[8], const u32* base, size_t n, size_t i)
+{
+#pragma unroll
+    for (int w = 0; w < 8; w++) v[w] = base[(size_t)w * n + i];
+}
+
+// per-call scratch, carved out of one slab (all sizes in u32 words per element)
+constexpr size_t SCR_FE = 10;
+struct ProjScratch {            // projective result + prefix products of the batched inversion
+    u32 *a, *b, *z, *prefix;    // X25519: a = PX, z = PZ.  Edwards: a = X, b = Y, z = Z.
+};
 
 // ------------------------------------------------------------------------------------------------
 // X25519   (curve25519_dh_CreateSharedKey / curve25519_dh_CalculatePublicKey)
@@ -41,17 +77,19 @@ C25519_DEV void store32(void* base, size_t i, const u32 (&w)[8])
 constexpr int X_BLOCK = 64;
 
 // pk == nullptr: base point u = 9
-__global__ void __launch_bounds__(X_BLOCK) k_x25519(void* out, const void* pk, void* sk, size_t n)
+__global__ void __launch_bounds__(X_BLOCK) k_x25519_ladder(ProjScratch scr, const void* pk, void* sk, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * X_BLOCK + threadIdx.x;
     if (i >= n) return;
-    u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8], o[8];
+    u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8];
     if (pk) load32(u, pk, i);
     load32(k, sk, i);
     clamp_words(k);
     store32(sk, i, k);                       // the reference clamps in the caller's buffer
-    x25519_ladder(o, u, k);
-    store32(out, i, o);                      // written last: `out` may alias `pk`
+    fe PX, PZ;
+    x25519_ladder_xz(PX, PZ, u, k);
+    soa_store_fe(scr.a, n, i, PX);
+    soa_store_fe(scr.z, n, i, PZ);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -125,97 +163,104 @@ C25519_DEV void ed_expand_seed(u32 (&a)[8], u64 (&b_words)[4], const u32 (&seed)
     for (int i = 0; i < 4; i++) b_words[i] = dg[4 + i];
 }
 
-// packed canonical encoding of k*B
-C25519_DEV void ed_base_mult_packed(u32 (&enc)[8], u32 (&k)[8], const u32* lds_tbl)
+C25519_DEV void store_proj(const ProjScratch& scr, size_t n, size_t i, const ge_ext& S)
 {
-    ge_ext S;
-    u32 xw[8], yw[8];
-    ge_base_mult(S, k, lds_tbl);
-    ge_to_affine_words(xw, yw, S);
-    ge_pack(enc, xw, yw);
+    soa_store_fe(scr.a, n, i, S.X);
+    soa_store_fe(scr.b, n, i, S.Y);
+    soa_store_fe(scr.z, n, i, S.Z);
 }
 
-// ed25519_CreateKeyPair (ed25519_sign.c:344-367): pub = enc(a*B), priv = sk || pub
-__global__ void __launch_bounds__(ED_BLOCK) k_ed25519_keypair(void* pub, void* priv, const void* sk, size_t n,
-                                                               const u32* __restrict__ g_tbl)
+// ed25519_CreateKeyPair (ed25519_sign.c:344-367), first part: a = clamp(H(sk)), S = a*B projective;
+// privKey[0..31] = sk.  The public key bytes are written by k_batch_invert<FinishKeypair>.
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_keypair_mult(ProjScratch scr, void* priv, const void* sk,
+                                                                       size_t n, const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
     lds_stage_base_table(lds_tbl, g_tbl);
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
-    u32 seed[8], a[8], enc[8];
+    u32 seed[8], a[8];
     u64 b_words[4];
     load32(seed, sk, i);
-    ed_expand_seed(a, b_words, seed);
-    ed_base_mult_packed(enc, a, lds_tbl);
-    store32(pub, i, enc);
     store32(priv, 2 * i, seed);
-    store32(priv, 2 * i + 1, enc);
+    ed_expand_seed(a, b_words, seed);
+    ge_ext S;
+    ge_base_mult(S, a, lds_tbl);
+    store_proj(scr, n, i, S);
 }
 
-// curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189): u = (Z+Y)/(Z-Y) of clamp(sk)*B
-__global__ void __launch_bounds__(ED_BLOCK) k_x25519_public_fast(void* pk, void* sk, size_t n,
-                                                                  const u32* __restrict__ g_tbl)
+// curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189): S = clamp(sk)*B, u = (Z+Y)/(Z-Y);
+// numerator and denominator go to scratch in the X25519 slots.
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_x25519_public_fast_mult(ProjScratch scr, void* sk, size_t n,
+                                                                          const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
     lds_stage_base_table(lds_tbl, g_tbl);
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
-    u32 k[8], o[8];
+    u32 k[8];
     load32(k, sk, i);
     clamp_words(k);
     store32(sk, i, k);
     ge_ext S;
     ge_base_mult(S, k, lds_tbl);
     fe num, den, t;
-    fe_add(num, S.Z, S.Y);                    // beta 2
-    fe_sub(t, S.Z, S.Y);                      // beta 3
-    fe_carry32(den, t);
-    fe_invert(den, den);
-    fe_mul(t, num, den);
-    fe_to_words(o, t);
-    store32(pk, i, o);
+    fe_add(t, S.Z, S.Y);  fe_carry32(num, t);
+    fe_sub(t, S.Z, S.Y);  fe_carry32(den, t);
+    soa_store_fe(scr.a, n, i, num);
+    soa_store_fe(scr.z, n, i, den);
 }
 
-// ed25519_SignMessage (ed25519_sign.c:372-419), blinding == NULL
-__global__ void __launch_bounds__(ED_BLOCK) k_ed25519_sign(void* sig, const void* priv, const uint8_t* msg,
-                                                            size_t msg_size, size_t n, const u32* __restrict__ g_tbl)
+// ed25519_SignMessage (ed25519_sign.c:372-419), blinding == NULL, first part (:385-400):
+// a = clamp(H(sk)[0..31]), r = H(H(sk)[32..63] || m) mod L (canonical), R = r*B projective.
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_mult(ProjScratch scr, u32* a_out, u32* r_out,
+                                                                    const void* priv, const uint8_t* msg,
+                                                                    size_t msg_size, size_t n,
+                                                                    const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
     lds_stage_base_table(lds_tbl, g_tbl);
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const uint8_t* m = msg + i * msg_size;
+    u32 seed[8], a[8], r[8];
+    {
+        u64 b_words[4], dg[8];
+        u32 le[16];
+        load32(seed, priv, 2 * i);
+        ed_expand_seed(a, b_words, seed);
+        sha512_prefixed<4>(dg, b_words, msg + i * msg_size, msg_size);
+        sha512_digest_le_words(le, dg);
+        sc_reduce512(r, le);
+        sc_mod(r);
+    }
+    soa_store8(a_out, n, i, a);
+    soa_store8(r_out, n, i, r);
+    ge_ext S;
+    ge_base_mult(S, r, lds_tbl);              // consumes r
+    store_proj(scr, n, i, S);
+}
 
-    u32 seed[8], pkw[8], a[8];
-    u64 b_words[4], dg[8];
-    load32(seed, priv, 2 * i);
+// ... last part (:404-414): h = H(enc(R) || pk || m), S = h*a + r mod L.  enc(R) is already in sig[0..31].
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_finish(void* sig, const void* priv, const uint8_t* msg,
+                                                                      size_t msg_size, size_t n, const u32* a_in,
+                                                                      const u32* r_in)
+{
+    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u32 encR[8], pkw[8], a[8], r[8], h[8], s[8], le[16];
+    u64 pre[8], dg[8];
+    load32(encR, sig, 2 * i);
     load32(pkw, priv, 2 * i + 1);
-    ed_expand_seed(a, b_words, seed);         // a = clamp(H(sk)[0..31]), b = H(sk)[32..63]   (:385-389)
-
-    u32 r[8], le[16];                         // r = H(b || m) mod L, canonical            (:392-397)
-    sha512_prefixed<4>(dg, b_words, m, msg_size);
-    sha512_digest_le_words(le, dg);
-    sc_reduce512(r, le);
-    sc_mod(r);
-
-    u32 rk[8], encR[8];                       // R = r*B                                    (:400-401)
-#pragma unroll
-    for (int j = 0; j < 8; j++) rk[j] = r[j];
-    ed_base_mult_packed(encR, rk, lds_tbl);
-
-    u64 pre[8];                               // h = H(enc(R) || pk || m)                    (:404-409)
     sha512_words_from_le32(pre, encR);
     sha512_words_from_le32(pre + 4, pkw);
-    sha512_prefixed<8>(dg, pre, m, msg_size);
+    sha512_prefixed<8>(dg, pre, msg + i * msg_size, msg_size);
     sha512_digest_le_words(le, dg);
-    u32 h[8], s[8];
     sc_reduce512(h, le);
-    sc_mul(s, h, a);                          // S = h*a + r mod L                            (:411-413)
+    soa_load8(a, a_in, n, i);
+    soa_load8(r, r_in, n, i);
+    sc_mul(s, h, a);
     sc_add(s, s, r);
     sc_mod(s);
-
-    store32(sig, 2 * i, encR);
     store32(sig, 2 * i + 1, s);
 }
 
@@ -240,28 +285,18 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_init(const void*
     qtable_build(tbl, Q);
 }
 
-// ed25519_Verify_Check (ed25519_verify.c:287-313): h = H(enc(R) || pk || m) mod L canonical; s = raw 256
-// bits (no s < L check, :308); T = s*B + h*(-A); verdict = (enc(T) == enc(R)).
-// pk_stride / table stride 0 = one key for the whole batch (two-phase API), otherwise one key per element.
+// ed25519_Verify_Check (ed25519_verify.c:287-313), first part: h = H(enc(R) || pk || m) mod L canonical;
+// s = raw 256 bits (no s < L check, :308); T = s*B + h*(-A) projective.  The comparison with enc(R) happens in
+// k_batch_invert<FinishVerify>.   pk_stride 1 = one key per element.
 template <typename Tbl>
-__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check(int* verdict, const void* sig, const void* pk,
-                                                                       size_t pk_stride, const uint8_t* msg,
-                                                                       size_t msg_size, size_t n,
-                                                                       const u32* __restrict__ g_tbl, u32* tables,
-                                                                       size_t stride_words)
+C25519_DEV void verify_check_lane(const ProjScratch& scr, size_t n, size_t i, const void* sig, const u32 (&pkw)[8],
+                                  const uint8_t* msg, size_t msg_size, const Tbl& tbl, const u32* lds_tbl)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
-    lds_stage_base_table(lds_tbl, g_tbl);
-    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
-    if (i >= n) return;
-
-    u32 Rw[8], Sw[8], h[8];
-    load32(Rw, sig, 2 * i);
-    load32(Sw, sig, 2 * i + 1);
+    u32 Sw[8], h[8];
     {
-        u32 pkw[8], le[16];
+        u32 Rw[8], le[16];
         u64 pre[8], dg[8];
-        load32(pkw, pk, i * pk_stride);
+        load32(Rw, sig, 2 * i);
         sha512_words_from_le32(pre, Rw);
         sha512_words_from_le32(pre + 4, pkw);
         sha512_prefixed<8>(dg, pre, msg + i * msg_size, msg_size);
@@ -269,17 +304,26 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check(int* verdi
         sc_reduce512(h, le);
         sc_mod(h);
     }
-
-    const Tbl tbl{ tables + i * stride_words };
+    load32(Sw, sig, 2 * i + 1);
     ge_ext T;
     ge_poly_mult(T, Sw, h, tbl, lds_tbl);
-    u32 xw[8], yw[8], enc[8];
-    ge_to_affine_words(xw, yw, T);
-    ge_pack(enc, xw, yw);
-    u32 diff = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
-    verdict[i] = diff == 0 ? 1 : 0;           // memcmp(md, signature, 32) == 0   (:312)
+    store_proj(scr, n, i, T);
+}
+
+template <typename Tbl>
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check(ProjScratch scr, const void* sig, const void* pk,
+                                                                       const uint8_t* msg, size_t msg_size, size_t n,
+                                                                       const u32* __restrict__ g_tbl, u32* tables,
+                                                                       size_t stride_words)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
+    lds_stage_base_table(lds_tbl, g_tbl);
+    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u32 pkw[8];
+    load32(pkw, pk, i);
+    const Tbl tbl{ tables + i * stride_words };
+    verify_check_lane(scr, n, i, sig, pkw, msg, msg_size, tbl, lds_tbl);
 }
 
 // Same check with ONE key for the whole batch (the reference's two-phase use: Verify_Init once, many
@@ -300,7 +344,7 @@ struct QTableLds {
     }
 };
 
-__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(int* verdict, const void* sig,
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(ProjScratch scr, const void* sig,
                                                                               const u32* __restrict__ ctx,
                                                                               const uint8_t* msg, size_t msg_size,
                                                                               size_t n, const u32* __restrict__ g_tbl)
@@ -320,32 +364,123 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(int
     lds_stage_base_table(lds_tbl, g_tbl);                  // ends with __syncthreads()
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
-
-    u32 Rw[8], Sw[8], h[8];
-    load32(Rw, sig, 2 * i);
-    load32(Sw, sig, 2 * i + 1);
-    {
-        u32 pkw[8], le[16];
-        u64 pre[8], dg[8];
+    u32 pkw[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) pkw[j] = ctx[j];
-        sha512_words_from_le32(pre, Rw);
-        sha512_words_from_le32(pre + 4, pkw);
-        sha512_prefixed<8>(dg, pre, msg + i * msg_size, msg_size);
-        sha512_digest_le_words(le, dg);
-        sc_reduce512(h, le);
-        sc_mod(h);
-    }
+    for (int j = 0; j < 8; j++) pkw[j] = ctx[j];
     const QTableLds tbl{ lds_q };
-    ge_ext T;
-    ge_poly_mult(T, Sw, h, tbl, lds_tbl);
-    u32 xw[8], yw[8], enc[8];
-    ge_to_affine_words(xw, yw, T);
+    verify_check_lane(scr, n, i, sig, pkw, msg, msg_size, tbl, lds_tbl);
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched inversion + output encoding
+// ------------------------------------------------------------------------------------------------
+// Lane j owns elements j, j+m, j+2m, ... (m = number of lanes, so every access stays coalesced) and inverts
+// their Z's with ONE exponentiation: prefix products forward, z^(p-2) once, then unwinding backwards
+// (Montgomery's trick).  A zero Z (low-order X25519 input, garbage Ed25519 key) must come out as 0 exactly like
+// the reference's z^(p-2) does, so zeros are replaced by 1 in the product and their inverse is forced to 0.
+// Fin::emit(e, zinv) turns element e's projective value and 1/Z into the operation's output bytes.
+struct FinishX25519 {                       // out = canonical(PX / PZ)           (curve25519_dh.c:148-150)
+    const u32* px; void* out; size_t n;
+    C25519_DEV void emit(size_t e, const fe& zinv) const
+    {
+        fe x;
+        u32 w[8];
+        soa_load_fe(x, px, n, e);
+        fe_mul(x, x, zinv);
+        fe_to_words(w, x);
+        store32(out, e, w);
+    }
+};
+
+C25519_DEV void affine_pack(u32 (&enc)[8], const u32* X, const u32* Y, size_t n, size_t e, const fe& zinv)
+{
+    fe t;
+    u32 xw[8], yw[8];
+    soa_load_fe(t, X, n, e);  fe_mul(t, t, zinv);  fe_to_words(xw, t);     // ed25519_sign.c:265-267
+    soa_load_fe(t, Y, n, e);  fe_mul(t, t, zinv);  fe_to_words(yw, t);
     ge_pack(enc, xw, yw);
-    u32 diff = 0;
+}
+
+struct FinishPack {                          // 32-byte record `slot` of `stride`-record rows <- enc(x, y)
+    const u32 *X, *Y; void* out; size_t n, stride, slot; void* out2; size_t stride2, slot2;
+    C25519_DEV void emit(size_t e, const fe& zinv) const
+    {
+        u32 enc[8];
+        affine_pack(enc, X, Y, n, e, zinv);
+        store32(out, e * stride + slot, enc);
+        if (out2) store32(out2, e * stride2 + slot2, enc);
+    }
+};
+
+struct FinishVerify {                        // verdict = (enc(T) == enc(R) bytes)   (ed25519_verify.c:310-312)
+    const u32 *X, *Y; const void* sig; int* verdict; size_t n;
+    C25519_DEV void emit(size_t e, const fe& zinv) const
+    {
+        u32 enc[8], Rw[8];
+        affine_pack(enc, X, Y, n, e, zinv);
+        load32(Rw, sig, 2 * e);
+        u32 diff = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
-    verdict[i] = diff == 0 ? 1 : 0;
+        for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
+        verdict[e] = diff == 0 ? 1 : 0;
+    }
+};
+
+constexpr int INV_BLOCK = 64;
+constexpr int INV_MAX_K = 16;
+
+template <typename Fin>
+__global__ void __launch_bounds__(INV_BLOCK) k_batch_invert(const u32* Z, u32* prefix, size_t n, size_t m, int K, Fin fin)
+{
+    const size_t j = (size_t)blockIdx.x * INV_BLOCK + threadIdx.x;
+    if (j >= m) return;
+    fe acc, z;
+    u32 zero_mask = 0;
+    fe_set_u32(acc, 1);
+#pragma unroll 1
+    for (int t = 0; t < K; t++) {
+        const size_t e = j + (size_t)t * m;
+        if (e >= n) break;
+        soa_load_fe(z, Z, n, e);
+        u32 w[8], nz = 0;
+        fe_to_words(w, z);
+#pragma unroll
+        for (int q = 0; q < 8; q++) nz |= w[q];
+        const u32 is_zero = nz ? 0u : 0xffffffffu;
+        zero_mask |= (is_zero & 1u) << t;
+        fe one;
+        fe_set_u32(one, 1);
+        fe_select(z, is_zero, one, z);                     // z == 0 (mod p) takes no part in the product
+        fe_mul(acc, acc, z);
+        soa_store_fe(prefix, n, e, acc);
+    }
+    fe inv;
+    fe_invert(inv, acc);
+#pragma unroll 1
+    for (int t = K - 1; t >= 0; t--) {
+        const size_t e = j + (size_t)t * m;
+        if (e >= n) continue;
+        fe zi;
+        if (t > 0) {
+            fe p;
+            soa_load_fe(p, prefix, n, e - m);
+            fe_mul(zi, inv, p);
+        } else {
+            zi = inv;
+        }
+        const u32 was_zero = ((zero_mask >> t) & 1u) ? 0xffffffffu : 0u;
+        if (t > 0) {
+            soa_load_fe(z, Z, n, e);
+            fe one;
+            fe_set_u32(one, 1);
+            fe_select(z, was_zero, one, z);
+            fe_mul(inv, inv, z);
+        }
+        fe zero;
+        fe_set_u32(zero, 0);
+        fe_select(zi, was_zero, zero, zi);
+        fin.emit(e, zi);
+    }
 }
 
 // ================================================================================================
@@ -366,9 +501,6 @@ struct DeviceTables {
     u32* bytes = nullptr;     // [256][24]
 };
 DeviceTables g_tables[MAX_DEVICES];
-thread_local size_t tl_qscratch_cap = 0;
-thread_local void* tl_qscratch = nullptr;
-thread_local int tl_qscratch_dev = -1;
 
 int init_tables(DeviceTables& t)
 {
@@ -404,20 +536,71 @@ int check_dev_args(size_t n, std::initializer_list<const void*> ptrs)
     return 0;
 }
 
-int verify_scratch(void** out, size_t n)
+// Work scratch of the *_dev entry points: one grow-only slab per host thread.  Consecutive calls of a thread
+// reuse it in stream order; if a thread switches streams, the new stream first waits for the previous use.
+struct WorkScratch {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+    bool used = false;
+
+    int acquire(void** out, size_t bytes, hipStream_t stream)
+    {
+        int d = 0;
+        C25519_TRY(hipGetDevice(&d));
+        if (ptr && (d != dev || bytes > cap)) {
+            C25519_TRY(hipDeviceSynchronize());
+            C25519_TRY(hipFree(ptr));
+            ptr = nullptr; cap = 0; used = false;
+        }
+        if (!ptr) {
+            size_t want = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes;
+            C25519_TRY(hipMalloc(&ptr, want));
+            cap = want; dev = d;
+        }
+        if (!done) C25519_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        if (used && stream != last) C25519_TRY(hipStreamWaitEvent(stream, done, 0));
+        *out = ptr;
+        return 0;
+    }
+    int release(hipStream_t stream)
+    {
+        C25519_TRY(hipEventRecord(done, stream));
+        last = stream; used = true;
+        return 0;
+    }
+};
+thread_local WorkScratch tl_work;
+
+inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// words of the projective-result part of the scratch for n elements (a, b, z, prefix; 16-byte aligned parts)
+inline size_t proj_words(size_t n) { return 4 * round_up(SCR_FE * n, 4); }
+
+ProjScratch carve_proj(u32* base, size_t n)
 {
-    const size_t need = ed25519_VerifySignature_scratch_bytes(n);
-    int dev = 0;
-    C25519_TRY(hipGetDevice(&dev));
-    if (tl_qscratch && (dev != tl_qscratch_dev || need > tl_qscratch_cap)) {
-        C25519_TRY(hipFree(tl_qscratch));
-        tl_qscratch = nullptr; tl_qscratch_cap = 0;
-    }
-    if (!tl_qscratch) {
-        C25519_TRY(hipMalloc(&tl_qscratch, need));
-        tl_qscratch_cap = need; tl_qscratch_dev = dev;
-    }
-    *out = tl_qscratch;
+    const size_t part = round_up(SCR_FE * n, 4);
+    return ProjScratch{ base, base + part, base + 2 * part, base + 3 * part };
+}
+
+// how many elements share one inversion: as many as possible while every SIMD still gets two waves
+inline int inversion_k(size_t n)
+{
+    size_t k = n / ((size_t)2 * 1024 * 64);
+    if (k < 1) k = 1;
+    if (k > INV_MAX_K) k = INV_MAX_K;
+    return (int)k;
+}
+
+template <typename Fin>
+int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t stream)
+{
+    const int K = inversion_k(n);
+    const size_t m = (n + K - 1) / K;
+    k_batch_invert<Fin><<<grid_for(m, INV_BLOCK), INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, K, fin);
+    C25519_TRY(hipGetLastError());
     return 0;
 }
 
@@ -425,7 +608,7 @@ int verify_scratch(void** out, size_t n)
 
 extern "C" {
 
-const char* c25519_amd_version(void) { return "curve25519_amd 0.1 (gfx950)"; }
+const char* c25519_amd_version(void) { return "curve25519_amd 0.2 (gfx950)"; }
 const char* c25519_amd_last_error(void) { return c25519_host::last_error().c_str(); }
 
 int c25519_amd_device_count(void)
@@ -441,16 +624,27 @@ int c25519_amd_set_device(int device)
     return 0;
 }
 
+#define C25519_RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
 // ---- device-pointer entry points ----------------------------------------------------------------
+
+static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t stream)
+{
+    void* w = nullptr;
+    C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
+    const ProjScratch scr = carve_proj((u32*)w, n);
+    k_x25519_ladder<<<grid_for(n, X_BLOCK), X_BLOCK, 0, stream>>>(scr, pk, sk, n);
+    C25519_TRY(hipGetLastError());
+    C25519_RC(launch_invert(scr, n, FinishX25519{ scr.a, out, n }, stream));
+    return tl_work.release(stream);
+}
 
 int curve25519_dh_CreateSharedKey_dev(void* shared, const void* pk, void* sk, size_t n, void* stream)
 {
     if (!shared || !pk || !sk) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { shared, pk, sk })) return rc;
     if (n == 0) return 0;
-    k_x25519<<<grid_for(n, X_BLOCK), X_BLOCK, 0, (hipStream_t)stream>>>(shared, pk, sk, n);
-    C25519_TRY(hipGetLastError());
-    return 0;
+    return x25519_dev(shared, pk, sk, n, (hipStream_t)stream);
 }
 
 int curve25519_dh_CalculatePublicKey_dev(void* pk, void* sk, size_t n, void* stream)
@@ -458,70 +652,93 @@ int curve25519_dh_CalculatePublicKey_dev(void* pk, void* sk, size_t n, void* str
     if (!pk || !sk) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { pk, sk })) return rc;
     if (n == 0) return 0;
-    k_x25519<<<grid_for(n, X_BLOCK), X_BLOCK, 0, (hipStream_t)stream>>>(pk, nullptr, sk, n);
-    C25519_TRY(hipGetLastError());
-    return 0;
+    return x25519_dev(pk, nullptr, sk, n, (hipStream_t)stream);
 }
 
-int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void* stream)
+int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void* stream_)
 {
     if (!pk || !sk) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { pk, sk })) return rc;
     if (n == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
-    if (int rc = base_tables(&tbl, nullptr)) return rc;
-    k_x25519_public_fast<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(pk, sk, n, tbl);
+    C25519_RC(base_tables(&tbl, nullptr));
+    void* w = nullptr;
+    C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
+    const ProjScratch scr = carve_proj((u32*)w, n);
+    k_x25519_public_fast_mult<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(scr, sk, n, tbl);
     C25519_TRY(hipGetLastError());
-    return 0;
+    C25519_RC(launch_invert(scr, n, FinishX25519{ scr.a, pk, n }, stream));
+    return tl_work.release(stream);
 }
 
-int ed25519_CreateKeyPair_dev(void* pub, void* priv, const void* sk, size_t n, void* stream)
+int ed25519_CreateKeyPair_dev(void* pub, void* priv, const void* sk, size_t n, void* stream_)
 {
     if (!pub || !priv || !sk) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { pub, priv, sk })) return rc;
     if (n == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
-    if (int rc = base_tables(&tbl, nullptr)) return rc;
-    k_ed25519_keypair<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(pub, priv, sk, n, tbl);
+    C25519_RC(base_tables(&tbl, nullptr));
+    void* w = nullptr;
+    C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
+    const ProjScratch scr = carve_proj((u32*)w, n);
+    k_ed25519_keypair_mult<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(scr, priv, sk, n, tbl);
     C25519_TRY(hipGetLastError());
-    return 0;
+    // pub[e] and priv[e][32..63] <- enc(A)
+    C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, pub, n, 1, 0, priv, 2, 1 }, stream));
+    return tl_work.release(stream);
 }
 
-int ed25519_SignMessage_dev(void* sig, const void* priv, const void* msg, size_t msg_size, size_t n, void* stream)
+int ed25519_SignMessage_dev(void* sig, const void* priv, const void* msg, size_t msg_size, size_t n, void* stream_)
 {
     if (!sig || !priv || (!msg && msg_size)) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { sig, priv })) return rc;
     if (n == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
-    if (int rc = base_tables(&tbl, nullptr)) return rc;
-    k_ed25519_sign<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
-        sig, priv, (const uint8_t*)msg, msg_size, n, tbl);
+    C25519_RC(base_tables(&tbl, nullptr));
+    void* w = nullptr;
+    const size_t sc_words = round_up(8 * n, 4);
+    C25519_RC(tl_work.acquire(&w, (proj_words(n) + 2 * sc_words) * sizeof(u32), stream));
+    const ProjScratch scr = carve_proj((u32*)w, n);
+    u32* a_buf = (u32*)w + proj_words(n);
+    u32* r_buf = a_buf + sc_words;
+    k_ed25519_sign_mult<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, (const uint8_t*)msg,
+                                                                          msg_size, n, tbl);
     C25519_TRY(hipGetLastError());
-    return 0;
+    C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, sig, n, 2, 0, nullptr, 0, 0 }, stream));   // sig[e][0..31] = enc(R)
+    k_ed25519_sign_finish<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(sig, priv, (const uint8_t*)msg, msg_size, n,
+                                                                            a_buf, r_buf);
+    C25519_TRY(hipGetLastError());
+    return tl_work.release(stream);
 }
 
 size_t ed25519_VerifySignature_scratch_bytes(size_t n)
 {
-    return n * QTABLE_LIMB_WORDS * sizeof(u32);
+    return (n * QTABLE_LIMB_WORDS + proj_words(n)) * sizeof(u32);
 }
 
 int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, const void* msg, size_t msg_size,
-                                size_t n, void* stream)
+                                size_t n, void* stream_)
 {
     if (!verdict || !sig || !pk || (!msg && msg_size)) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { sig, pk })) return rc;
     if (n == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
-    if (int rc = base_tables(&tbl, nullptr)) return rc;
-    void* scratch = nullptr;
-    if (int rc = verify_scratch(&scratch, n)) return rc;
-    k_ed25519_verify_init<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
-        pk, n, (u32*)scratch, QTABLE_LIMB_WORDS);
+    C25519_RC(base_tables(&tbl, nullptr));
+    void* w = nullptr;
+    C25519_RC(tl_work.acquire(&w, ed25519_VerifySignature_scratch_bytes(n), stream));
+    const ProjScratch scr = carve_proj((u32*)w, n);
+    u32* tables = (u32*)w + proj_words(n);
+    k_ed25519_verify_init<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(pk, n, tables, QTABLE_LIMB_WORDS);
     C25519_TRY(hipGetLastError());
-    k_ed25519_verify_check<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
-        (int*)verdict, sig, pk, 1, (const uint8_t*)msg, msg_size, n, tbl, (u32*)scratch, QTABLE_LIMB_WORDS);
+    k_ed25519_verify_check<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
+        scr, sig, pk, (const uint8_t*)msg, msg_size, n, tbl, tables, QTABLE_LIMB_WORDS);
     C25519_TRY(hipGetLastError());
-    return 0;
+    C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
+    return tl_work.release(stream);
 }
 
 // two-phase verification on the device: contexts are 2080-byte records (pk || 16 x 128-byte canonical rows),
@@ -539,17 +756,22 @@ int ed25519_Verify_Init_dev(void* ctx, const void* pk, size_t n, void* stream)
 }
 
 int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, const void* msg, size_t msg_size,
-                             size_t n, void* stream)
+                             size_t n, void* stream_)
 {
     if (!verdict || !ctx || !sig || (!msg && msg_size)) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { ctx, sig })) return rc;
     if (n == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
-    if (int rc = base_tables(&tbl, nullptr)) return rc;
-    k_ed25519_verify_check_shared<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
-        (int*)verdict, sig, (const u32*)ctx, (const uint8_t*)msg, msg_size, n, tbl);
+    C25519_RC(base_tables(&tbl, nullptr));
+    void* w = nullptr;
+    C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
+    const ProjScratch scr = carve_proj((u32*)w, n);
+    k_ed25519_verify_check_shared<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
+        scr, sig, (const u32*)ctx, (const uint8_t*)msg, msg_size, n, tbl);
     C25519_TRY(hipGetLastError());
-    return 0;
+    C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
+    return tl_work.release(stream);
 }
 
 int c25519_amd_base_table(unsigned char* out)
@@ -562,8 +784,6 @@ int c25519_amd_base_table(unsigned char* out)
 }
 
 // ---- host-pointer entry points: stage, run the *_dev form, copy back -----------------------------
-
-#define C25519_RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
 static int up(Staging& s, int slot, const void* src, size_t bytes)
 {

@@ -46,8 +46,10 @@ C25519_DEV void ladder_step(fe& SX, fe& SZ, fe& DX, fe& DZ, const fe& base, u32 
     fe_mul(DZ, B, A);                  // z4
 }
 
-// out = clamp(k) * (u : 1), x-only.  k_words are the CLAMPED scalar words.
-C25519_DEV void x25519_ladder(u32 (&out)[8], const u32 (&u)[8], const u32 (&k)[8])
+// (PX : PZ) = clamp(k) * (u : 1), x-only, projective.  k are the CLAMPED scalar words.  The affine result
+// PX/PZ is produced by the shared batched-inversion kernel (engine.hip), which amortises ecp_Inverse
+// (curve25519_dh.c:148) over several elements.
+C25519_DEV void x25519_ladder_xz(fe& PX, fe& PZ, const u32 (&u)[8], const u32 (&k)[8])
 {
     fe X1, SX, SZ, DX, DZ;
     fe_from_words(X1, u);
@@ -87,12 +89,8 @@ C25519_DEV void x25519_ladder(u32 (&out)[8], const u32 (&u)[8], const u32 (&k)[8
     }
     // P = PP[1] is what the reference converts (:148-150): P = S if the last bit was 1, else D
     const u32 m = (u32)0 - prev;
-    fe PX, PZ;
     fe_select(PX, m, SX, DX);
     fe_select(PZ, m, SZ, DZ);
-    fe_invert(PZ, PZ);
-    fe_mul(PX, PX, PZ);
-    fe_to_words(out, PX);
 }
 
 }  // namespace c25519
