@@ -40,16 +40,21 @@ def measured_mad_peak():
         return None
 
 
-def measured_traffic(kernel="k_x25519"):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc runs of
-    this same bench, summarised by tools/rocpd_summary.py): WRITE_SIZE + 2 x FETCH_SIZE, both in KiB --
-    the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section) for wide coalesced reads."""
+X25519_KERNELS = ("k_x25519_ladder", "void k_batch_invert<FinishX25519>")
+
+
+def measured_traffic(kernels=X25519_KERNELS):
+    """HBM bytes per X25519 pass (ladder launch + batched-inversion launch) from the committed rocprofv3 PMC
+    passes (separate --pmc runs of this same bench, summarised by tools/rocpd_summary.py):
+    WRITE_SIZE + 2 x FETCH_SIZE, both in KiB -- the x2 is the gfx950 FETCH_SIZE correction of
+    MI355X_MICROARCH.md (HBM section)."""
     try:
         import glob
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))[-1]
         with open(path) as f:
-            k = json.load(f)[kernel]
-        return int((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024), os.path.basename(path)
+            d = json.load(f)
+        total = sum((2.0 * d[k]["FETCH_SIZE"] + d[k]["WRITE_SIZE"]) * 1024 for k in kernels)
+        return int(total), os.path.basename(path)
     except Exception:
         return None, None
 
@@ -62,7 +67,15 @@ def cpu_baseline(n_per_thread=8192):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle, Reference
     from curve25519_amd import synth
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:                                   # cgroup v2 CPU quota of the container, if any
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+            cores = max(1, min(cores, int(round(quota))))
+    except Exception:
+        pass
     n = n_per_thread * cores
     sk, pk = synth.x25519_inputs(n)
     esk, msg = synth.ed25519_inputs(cores * 256)
@@ -104,6 +117,7 @@ def cpu_baseline(n_per_thread=8192):
                       f"(C thread pool, one contiguous slice each); seeded uniform sk/pk",
             "single_core_ops_per_s": round(single, 1), "ed25519_sign_per_s": round(sign_rate, 1),
             "ed25519_verify_per_s": round(verify_rate, 1), "ed25519_verify_all_valid": bool(ok.all()),
+            "host_logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
             "cpu_model": model}
 
 
@@ -122,7 +136,7 @@ def main():
     import torch
     import torch.distributed as dist
     from curve25519_amd import synth
-    from curve25519_amd.sharded import HipEngine, gather_rows
+    from curve25519_amd.sharded import HipEngine, OverlappedGather
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -157,22 +171,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    og = OverlappedGather(n, 32, dev, root=0) if use_dist else None
+
     def step(ev=None):
+        dst = og.next_buffer() if og else out
         if ev:
             ev[0].record()
-        eng.api.curve25519_dh_CreateSharedKey_dev(out, pk, sk)
+        eng.api.curve25519_dh_CreateSharedKey_dev(dst, pk, sk)
         if ev:
             ev[1].record()
-        if use_dist:
-            gather_rows(out, root=0, always=True)
+        if og:
+            og.submit()                  # async RCCL gather of this batch, overlapped with the next batch
 
     for _ in range(args.warmup):
         step()
+    if og:
+        og.finish()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
+    if og:
+        og.finish()                      # every gather of the timed steps has completed inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -200,9 +221,11 @@ def main():
                        "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_source": f"profiles/{traffic_src}: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch; includes "
-                                           "the 32 B/op clamped-key write-back the reference API requires" if traffic_src else None,
-                         "kernel": "k_x25519", "kernel_ms": round(kernel_ms, 4),
+                         "traffic_source": f"profiles/{traffic_src}: (2*FETCH_SIZE + WRITE_SIZE) KiB, ladder + inversion "
+                                           "launches; = 96 B/op API bytes + 32 B/op clamped-key write-back + the "
+                                           "projective intermediates staged for the batched inversion" if traffic_src else None,
+                         "kernel": "k_x25519_ladder (+ k_batch_invert<FinishX25519>, ~2% of the pass)",
+                         "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": BYTES_PER_OP["x25519"] * n,
                          "note": "VALU-integer bound path: HBM fraction is tiny by construction, see roofline_valu"},
             "roofline_valu": {"bound": "valu v_mad_u64_u32", "achieved": round(achieved_mac / 1e12, 4),

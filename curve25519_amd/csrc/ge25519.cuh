@@ -27,6 +27,9 @@ constexpr int PE_WORDS = 40;
 // p = 2p.  In: X, Y, Z reduced.  Out: all reduced.  4S + 4M.
 //   reference: A=X^2 B=Y^2 C=2Z^2 D=-A H=D-B G=D+B F=G-C E=(X+Y)^2+H ; X3=EF Y3=HG Z3=GF T3=EH
 //   here:      Hn=-H=A+B, Fn=-F=2Z^2+A-B  (both negated -> all four outputs negated: same point)
+// NEED_T = false skips T3 = E*H (one multiplication): T is only read by additions, so inside a run of
+// consecutive doublings (the 3 x 64 doublings of the verify table build) only the last one needs it.
+template <bool NEED_T = true>
 C25519_DEV void ge_double(ge_ext& p)
 {
     fe A, B, Hn, G, E, Fn, t;
@@ -40,10 +43,12 @@ C25519_DEV void ge_double(ge_ext& p)
     fe_mul(p.X, E, Fn);
     fe_mul(p.Y, G, Hn);
     fe_mul(p.Z, G, Fn);
-    fe_mul(p.T, E, Hn);
+    if (NEED_T) fe_mul(p.T, E, Hn);
 }
 
 // p = p + q, q affine precomputed with reduced limbs.  7M.   (edp_AddAffinePoint)
+// NEED_T = false skips T3 = E*H: a doubling (or the final affine conversion) that follows never reads T.
+template <bool NEED_T = true>
 C25519_DEV void ge_add_pa(ge_ext& p, const ge_pa& q)
 {
     fe a, b, c, d, e, f, g, h;
@@ -59,11 +64,12 @@ C25519_DEV void ge_add_pa(ge_ext& p, const ge_pa& q)
     fe_add(g, d, c);                     // G = D+C   beta 3
     fe_mul(p.X, f, e);
     fe_mul(p.Y, g, h);
-    fe_mul(p.T, e, h);
+    if (NEED_T) fe_mul(p.T, e, h);
     fe_mul(p.Z, f, g);
 }
 
 // r = p + q, q projective precomputed with reduced limbs.  8M.   (edp_AddPoint)
+template <bool NEED_T = true>
 C25519_DEV void ge_add_pe(ge_ext& r, const ge_ext& p, const ge_pe& q)
 {
     fe a, b, c, d, e, f, g, h;
@@ -79,7 +85,7 @@ C25519_DEV void ge_add_pe(ge_ext& r, const ge_ext& p, const ge_pe& q)
     fe_add(g, d, c);                     // beta 2
     fe_mul(r.X, e, f);
     fe_mul(r.Y, g, h);
-    fe_mul(r.T, e, h);
+    if (NEED_T) fe_mul(r.T, e, h);
     fe_mul(r.Z, f, g);
 }
 
@@ -182,7 +188,7 @@ C25519_DEV void ge_base_mult(ge_ext& S, u32 (&k)[8], const u32* lds_tbl)
     for (int n = 1; n < 32; n++) {
         ge_double(S);
         lds_load_pa(q, lds_tbl, fold8_next(k));
-        ge_add_pa(S, q);
+        ge_add_pa<false>(S, q);                // next comes a doubling or the affine conversion: T unused
     }
 }
 
@@ -286,7 +292,8 @@ C25519_DEV void qtable_build(const Tbl& tbl, ge_ext& Q)
 #pragma unroll 1
     for (int blk = 1; blk < 4; blk++) {               // Q <- 2^64 Q, then fill rows [2^blk, 2^(blk+1))
 #pragma unroll 1
-        for (int i = 0; i < 64; i++) ge_double(Q);
+        for (int i = 0; i < 63; i++) ge_double<false>(Q);
+        ge_double<true>(Q);
         const int top = 1 << blk;
         ge_to_pe(pe, Q);
         tbl.store(top, pe);
@@ -313,15 +320,15 @@ C25519_DEV void ge_poly_mult(ge_ext& S, u32 (&s)[8], u32 (&h)[8], const Tbl& tbl
     for (int i = 1; i < 32; i++) {
         ge_double(S);
         tbl.load(pe, fold4_next(h, false));
-        ge_add_pe(S, S, pe);
+        ge_add_pe<false>(S, S, pe);
     }
 #pragma unroll 1
     for (int i = 32; i < 64; i++) {
         ge_double(S);
         lds_load_pa(pa, lds_tbl, fold8_next(s));
-        ge_add_pa(S, pa);
+        ge_add_pa<true>(S, pa);                // T feeds the addition that follows
         tbl.load(pe, fold4_next(h, true));
-        ge_add_pe(S, S, pe);
+        ge_add_pe<false>(S, S, pe);
     }
 }
 

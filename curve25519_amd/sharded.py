@@ -45,6 +45,47 @@ def gather_rows(local: torch.Tensor, root: int = 0, group=None, always: bool = F
     return torch.cat([r[:c] for r, c in zip(recv, counts)], dim=0)
 
 
+class OverlappedGather:
+    """The steady-state form of the one gather: equal-size shards, receive buffers allocated once, and the
+    collective issued asynchronously so that it runs (on RCCL's stream, over xGMI) underneath the NEXT
+    batch's kernels -- those are VALU-bound and leave HBM and the links idle.  Two result buffers alternate;
+    a buffer is only reused after the gather that reads it has been waited for (stream-level wait)."""
+
+    def __init__(self, rows: int, width: int, device, root: int = 0, group=None, dtype=torch.uint8):
+        self.root, self.group = root, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.out = [torch.empty((rows, width), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [[torch.empty((rows, width), dtype=dtype, device=device) for _ in range(self.world)]
+                     for _ in range(2)] if self.rank == root else [None, None]
+        self.work = [None, None]
+        self.step = 0
+
+    def next_buffer(self) -> torch.Tensor:
+        """Result buffer for the next batch (waits, on the current stream, for its previous gather)."""
+        b = self.step & 1
+        if self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+        return self.out[b]
+
+    def submit(self):
+        """Start gathering the buffer handed out by the last next_buffer() call."""
+        b = self.step & 1
+        self.work[b] = dist.gather(self.out[b], self.recv[b], dst=self.root, group=self.group, async_op=True)
+        self.step += 1
+
+    def finish(self):
+        for b in range(2):
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
+
+    def gathered(self, buffer_index: int) -> Optional[torch.Tensor]:
+        """On root: the [world*rows, width] result of the given buffer's last gather."""
+        return torch.cat(self.recv[buffer_index], dim=0) if self.rank == self.root else None
+
+
 class HipEngine:
     """Device-resident batches on the current CUDA device, asynchronous on torch's current stream."""
 

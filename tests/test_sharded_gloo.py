@@ -52,8 +52,23 @@ def _worker(rank, world, port, n, q):
         sig = sharded.ed25519_sign_sharded(eng, torch.from_numpy(priv), torch.from_numpy(msg[lo:hi].copy()), root=0)
         sig_l = torch.from_numpy(eng.o.ed25519_sign(priv, msg[lo:hi]))
         ok = sharded.ed25519_verify_sharded(eng, sig_l, torch.from_numpy(pub), torch.from_numpy(msg[lo:hi].copy()), root=0)
+        # the steady-state overlapped gather used by bench.py: 3 batches through 2 alternating buffers
+        rows = max(hi - lo for lo, hi in sharded.shard_bounds(n, world))
+        og = sharded.OverlappedGather(rows, 32, torch.device("cpu"), root=0)
+        seen = []
+        for stepno in range(3):
+            buf = og.next_buffer()
+            buf.zero_()
+            buf[: hi - lo] = torch.from_numpy(eng.o.x25519_shared(pk[lo:hi], sk[lo:hi])[0]) if hi > lo else buf[:0]
+            buf[:, 0] ^= stepno                                  # make every batch distinguishable
+            og.submit()
+            if stepno >= 1:                                        # previous buffer's gather overlaps this batch
+                pass
+        og.finish()
         if rank == 0:
-            q.put((shared.numpy(), sig.numpy(), ok.numpy()))
+            seen = [og.gathered(b).numpy().copy() for b in (0, 1)]
+        if rank == 0:
+            q.put((shared.numpy(), sig.numpy(), ok.numpy(), seen, rows))
         else:
             assert shared is None and sig is None and ok is None
             q.put(None)
@@ -83,7 +98,7 @@ def test_sharded_matches_unsharded(world, n, oracle):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    shared, sig, ok = next(r for r in results if r is not None)
+    shared, sig, ok, seen, rows = next(r for r in results if r is not None)
     sk, pk = synth.x25519_inputs(n)
     exp_shared, _ = oracle.x25519_shared(pk, sk)
     assert np.array_equal(shared, exp_shared)
@@ -91,6 +106,14 @@ def test_sharded_matches_unsharded(world, n, oracle):
     pub, priv = oracle.ed25519_keypair(esk)
     assert np.array_equal(sig, oracle.ed25519_sign(priv, msg))
     assert ok.shape == (n, 1) and ok.all()
+    # buffer 0 last carried batch 2, buffer 1 carried batch 1; rows are rank-major, zero padded to `rows`
+    from curve25519_amd.sharded import shard_bounds
+    for b, stepno in ((0, 2), (1, 1)):
+        got = seen[b].reshape(world, rows, 32)
+        for r, (lo, hi) in enumerate(shard_bounds(n, world)):
+            exp = exp_shared[lo:hi].copy()
+            exp[:, 0] ^= stepno
+            assert np.array_equal(got[r, : hi - lo], exp), (b, r)
 
 
 def test_shard_bounds_cover_exactly():
