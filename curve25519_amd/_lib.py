@@ -20,6 +20,10 @@ SIGNATURES = {
     "ed25519_CreateKeyPair_dev": [_vp, _vp, _vp, _sz, _vp],
     "ed25519_SignMessage_batch": [_vp, _vp, _vp, _sz, _sz],
     "ed25519_SignMessage_dev": [_vp, _vp, _vp, _sz, _sz, _vp],
+    "ed25519_SignMessage_ragged_batch": [_vp, _vp, _vp, _vp, _sz],
+    "ed25519_SignMessage_ragged_dev": [_vp, _vp, _vp, _vp, _sz, _vp],
+    "ed25519_VerifySignature_ragged_batch": [_vp, _vp, _vp, _vp, _vp, _sz],
+    "ed25519_VerifySignature_ragged_dev": [_vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "ed25519_VerifySignature_batch": [_vp, _vp, _vp, _vp, _sz, _sz],
     "ed25519_VerifySignature_dev": [_vp, _vp, _vp, _vp, _sz, _sz, _vp],
     "ed25519_VerifySignature_scratch_bytes": [_sz],

@@ -81,6 +81,41 @@ def ed25519_SignMessage(priv, msg):
     return sig
 
 
+def _ragged(messages):
+    """list of bytes-like -> (concatenated uint8 array, uint64 offsets[n+1])"""
+    lens = np.fromiter((len(m) for m in messages), dtype=np.uint64, count=len(messages))
+    offsets = np.zeros(len(messages) + 1, np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    flat = np.frombuffer(b"".join(bytes(m) for m in messages), np.uint8) if len(messages) else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(flat), offsets
+
+
+def ed25519_SignMessage_ragged(priv, messages):
+    """n x ed25519_SignMessage with per-element message lengths (`messages`: sequence of bytes-like)."""
+    priv = _np(priv, 64, "priv")
+    n = priv.shape[0]
+    if len(messages) != n:
+        raise ValueError("one message per private key")
+    flat, offsets = _ragged(messages)
+    sig = np.empty((n, 64), np.uint8)
+    _lib.check(_lib.load().ed25519_SignMessage_ragged_batch(_ptr(sig), _ptr(priv), _ptr(flat), _ptr(offsets), n),
+               "ed25519_SignMessage_ragged_batch")
+    return sig
+
+
+def ed25519_VerifySignature_ragged(sig, pk, messages):
+    sig = _np(sig, 64, "sig")
+    pk = _np(pk, 32, "pk")
+    n = sig.shape[0]
+    if len(messages) != n or pk.shape[0] != n:
+        raise ValueError("one message and one key per signature")
+    flat, offsets = _ragged(messages)
+    ok = np.empty(n, np.int32)
+    _lib.check(_lib.load().ed25519_VerifySignature_ragged_batch(_ptr(ok), _ptr(sig), _ptr(pk), _ptr(flat), _ptr(offsets), n),
+               "ed25519_VerifySignature_ragged_batch")
+    return ok
+
+
 def ed25519_VerifySignature(sig, pk, msg):
     """n x ed25519_VerifySignature.  Returns int32[n] of 1 (valid) / 0 (invalid)."""
     sig = _np(sig, 64, "sig")

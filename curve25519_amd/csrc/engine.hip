@@ -65,6 +65,15 @@ C25519_DEV void soa_load8(u32 (&v)[8], const u32* base, size_t n, size_t i)
     for (int w = 0; w < 8; w++) v[w] = base[(size_t)w * n + i];
 }
 
+// messages of a batch: fixed stride (offsets == nullptr) or ragged (message i = base[offsets[i] .. offsets[i+1]))
+struct Msgs {
+    const uint8_t* base;
+    size_t fixed;
+    const unsigned long long* offsets;
+    C25519_DEV const uint8_t* ptr(size_t i) const { return base + (offsets ? (size_t)offsets[i] : i * fixed); }
+    C25519_DEV size_t len(size_t i) const { return offsets ? (size_t)(offsets[i + 1] - offsets[i]) : fixed; }
+};
+
 // per-call scratch, carved out of one slab (all sizes in u32 words per element)
 constexpr size_t SCR_FE = 10;
 struct ProjScratch {            // projective result + prefix products of the batched inversion
@@ -214,8 +223,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_x25519_public_fast_mult(ProjScr
 // ed25519_SignMessage (ed25519_sign.c:372-419), blinding == NULL, first part (:385-400):
 // a = clamp(H(sk)[0..31]), r = H(H(sk)[32..63] || m) mod L (canonical), R = r*B projective.
 __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_mult(ProjScratch scr, u32* a_out, u32* r_out,
-                                                                    const void* priv, const uint8_t* msg,
-                                                                    size_t msg_size, size_t n,
+                                                                    const void* priv, Msgs msgs, size_t n,
                                                                     const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
@@ -228,7 +236,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_mult(ProjScratch s
         u32 le[16];
         load32(seed, priv, 2 * i);
         ed_expand_seed(a, b_words, seed);
-        sha512_prefixed<4>(dg, b_words, msg + i * msg_size, msg_size);
+        sha512_prefixed<4>(dg, b_words, msgs.ptr(i), msgs.len(i));
         sha512_digest_le_words(le, dg);
         sc_reduce512(r, le);
         sc_mod(r);
@@ -241,9 +249,8 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_mult(ProjScratch s
 }
 
 // ... last part (:404-414): h = H(enc(R) || pk || m), S = h*a + r mod L.  enc(R) is already in sig[0..31].
-__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_finish(void* sig, const void* priv, const uint8_t* msg,
-                                                                      size_t msg_size, size_t n, const u32* a_in,
-                                                                      const u32* r_in)
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_finish(void* sig, const void* priv, Msgs msgs, size_t n,
+                                                                      const u32* a_in, const u32* r_in)
 {
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -253,7 +260,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_finish(void* sig, 
     load32(pkw, priv, 2 * i + 1);
     sha512_words_from_le32(pre, encR);
     sha512_words_from_le32(pre + 4, pkw);
-    sha512_prefixed<8>(dg, pre, msg + i * msg_size, msg_size);
+    sha512_prefixed<8>(dg, pre, msgs.ptr(i), msgs.len(i));
     sha512_digest_le_words(le, dg);
     sc_reduce512(h, le);
     soa_load8(a, a_in, n, i);
@@ -290,7 +297,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_init(const void*
 // k_batch_invert<FinishVerify>.   pk_stride 1 = one key per element.
 template <typename Tbl>
 C25519_DEV void verify_check_lane(const ProjScratch& scr, size_t n, size_t i, const void* sig, const u32 (&pkw)[8],
-                                  const uint8_t* msg, size_t msg_size, const Tbl& tbl, const u32* lds_tbl)
+                                  const Msgs& msgs, const Tbl& tbl, const u32* lds_tbl)
 {
     u32 Sw[8], h[8];
     {
@@ -299,7 +306,7 @@ C25519_DEV void verify_check_lane(const ProjScratch& scr, size_t n, size_t i, co
         load32(Rw, sig, 2 * i);
         sha512_words_from_le32(pre, Rw);
         sha512_words_from_le32(pre + 4, pkw);
-        sha512_prefixed<8>(dg, pre, msg + i * msg_size, msg_size);
+        sha512_prefixed<8>(dg, pre, msgs.ptr(i), msgs.len(i));
         sha512_digest_le_words(le, dg);
         sc_reduce512(h, le);
         sc_mod(h);
@@ -312,7 +319,7 @@ C25519_DEV void verify_check_lane(const ProjScratch& scr, size_t n, size_t i, co
 
 template <typename Tbl>
 __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check(ProjScratch scr, const void* sig, const void* pk,
-                                                                       const uint8_t* msg, size_t msg_size, size_t n,
+                                                                       Msgs msgs, size_t n,
                                                                        const u32* __restrict__ g_tbl, u32* tables,
                                                                        size_t stride_words)
 {
@@ -323,7 +330,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check(ProjScratc
     u32 pkw[8];
     load32(pkw, pk, i);
     const Tbl tbl{ tables + i * stride_words };
-    verify_check_lane(scr, n, i, sig, pkw, msg, msg_size, tbl, lds_tbl);
+    verify_check_lane(scr, n, i, sig, pkw, msgs, tbl, lds_tbl);
 }
 
 // Same check with ONE key for the whole batch (the reference's two-phase use: Verify_Init once, many
@@ -345,8 +352,7 @@ struct QTableLds {
 };
 
 __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(ProjScratch scr, const void* sig,
-                                                                              const u32* __restrict__ ctx,
-                                                                              const uint8_t* msg, size_t msg_size,
+                                                                              const u32* __restrict__ ctx, Msgs msgs,
                                                                               size_t n, const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
@@ -368,7 +374,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(Pro
 #pragma unroll
     for (int j = 0; j < 8; j++) pkw[j] = ctx[j];
     const QTableLds tbl{ lds_q };
-    verify_check_lane(scr, n, i, sig, pkw, msg, msg_size, tbl, lds_tbl);
+    verify_check_lane(scr, n, i, sig, pkw, msgs, tbl, lds_tbl);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -690,12 +696,10 @@ int ed25519_CreateKeyPair_dev(void* pub, void* priv, const void* sk, size_t n, v
     return tl_work.release(stream);
 }
 
-int ed25519_SignMessage_dev(void* sig, const void* priv, const void* msg, size_t msg_size, size_t n, void* stream_)
+static int sign_dev(void* sig, const void* priv, Msgs msgs, size_t n, hipStream_t stream)
 {
-    if (!sig || !priv || (!msg && msg_size)) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { sig, priv })) return rc;
     if (n == 0) return 0;
-    hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
@@ -704,14 +708,25 @@ int ed25519_SignMessage_dev(void* sig, const void* priv, const void* msg, size_t
     const ProjScratch scr = carve_proj((u32*)w, n);
     u32* a_buf = (u32*)w + proj_words(n);
     u32* r_buf = a_buf + sc_words;
-    k_ed25519_sign_mult<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, (const uint8_t*)msg,
-                                                                          msg_size, n, tbl);
+    k_ed25519_sign_mult<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, sig, n, 2, 0, nullptr, 0, 0 }, stream));   // sig[e][0..31] = enc(R)
-    k_ed25519_sign_finish<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(sig, priv, (const uint8_t*)msg, msg_size, n,
-                                                                            a_buf, r_buf);
+    k_ed25519_sign_finish<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(sig, priv, msgs, n, a_buf, r_buf);
     C25519_TRY(hipGetLastError());
     return tl_work.release(stream);
+}
+
+int ed25519_SignMessage_dev(void* sig, const void* priv, const void* msg, size_t msg_size, size_t n, void* stream)
+{
+    if (!sig || !priv || (!msg && msg_size)) return bad_arg("null pointer");
+    return sign_dev(sig, priv, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, (hipStream_t)stream);
+}
+
+int ed25519_SignMessage_ragged_dev(void* sig, const void* priv, const void* msgs, const uint64_t* offsets, size_t n,
+                                   void* stream)
+{
+    if (!sig || !priv || !offsets) return bad_arg("null pointer");
+    return sign_dev(sig, priv, Msgs{ (const uint8_t*)msgs, 0, (const unsigned long long*)offsets }, n, (hipStream_t)stream);
 }
 
 size_t ed25519_VerifySignature_scratch_bytes(size_t n)
@@ -719,13 +734,10 @@ size_t ed25519_VerifySignature_scratch_bytes(size_t n)
     return (n * QTABLE_LIMB_WORDS + proj_words(n)) * sizeof(u32);
 }
 
-int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, const void* msg, size_t msg_size,
-                                size_t n, void* stream_)
+static int verify_dev(void* verdict, const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t stream)
 {
-    if (!verdict || !sig || !pk || (!msg && msg_size)) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { sig, pk })) return rc;
     if (n == 0) return 0;
-    hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
@@ -735,10 +747,25 @@ int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, 
     k_ed25519_verify_init<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(pk, n, tables, QTABLE_LIMB_WORDS);
     C25519_TRY(hipGetLastError());
     k_ed25519_verify_check<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
-        scr, sig, pk, (const uint8_t*)msg, msg_size, n, tbl, tables, QTABLE_LIMB_WORDS);
+        scr, sig, pk, msgs, n, tbl, tables, QTABLE_LIMB_WORDS);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
     return tl_work.release(stream);
+}
+
+int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, const void* msg, size_t msg_size,
+                                size_t n, void* stream)
+{
+    if (!verdict || !sig || !pk || (!msg && msg_size)) return bad_arg("null pointer");
+    return verify_dev(verdict, sig, pk, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, (hipStream_t)stream);
+}
+
+int ed25519_VerifySignature_ragged_dev(void* verdict, const void* sig, const void* pk, const void* msgs,
+                                       const uint64_t* offsets, size_t n, void* stream)
+{
+    if (!verdict || !sig || !pk || !offsets) return bad_arg("null pointer");
+    return verify_dev(verdict, sig, pk, Msgs{ (const uint8_t*)msgs, 0, (const unsigned long long*)offsets }, n,
+                      (hipStream_t)stream);
 }
 
 // two-phase verification on the device: contexts are 2080-byte records (pk || 16 x 128-byte canonical rows),
@@ -768,7 +795,7 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
     C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     k_ed25519_verify_check_shared<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
-        scr, sig, (const u32*)ctx, (const uint8_t*)msg, msg_size, n, tbl);
+        scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
     return tl_work.release(stream);
@@ -876,6 +903,43 @@ int ed25519_VerifySignature_batch(int* verdict, const unsigned char* sig, const 
     C25519_RC(up(s, 2, msg, msg_size * n));
     C25519_RC(s.reserve(3, sizeof(int) * n));
     C25519_RC(ed25519_VerifySignature_dev(s.ptr[3], s.ptr[0], s.ptr[1], s.ptr[2], msg_size, n, s.stream));
+    C25519_RC(down(s, verdict, 3, sizeof(int) * n));
+    C25519_TRY(hipStreamSynchronize(s.stream));
+    return 0;
+}
+
+// ragged messages: message i is msgs[offsets[i] .. offsets[i+1]); offsets has n+1 entries (host memory)
+int ed25519_SignMessage_ragged_batch(unsigned char* sig, const unsigned char* priv, const unsigned char* msgs,
+                                     const uint64_t* offsets, size_t n)
+{
+    if (!sig || !priv || !offsets) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    Staging& s = staging();
+    C25519_RC(s.ensure_stream());
+    C25519_RC(up(s, 0, priv, 64 * n));
+    C25519_RC(up(s, 1, msgs, (size_t)offsets[n]));
+    C25519_RC(s.reserve(2, 64 * n));
+    C25519_RC(up(s, 3, offsets, sizeof(uint64_t) * (n + 1)));
+    C25519_RC(ed25519_SignMessage_ragged_dev(s.ptr[2], s.ptr[0], s.ptr[1], (const uint64_t*)s.ptr[3], n, s.stream));
+    C25519_RC(down(s, sig, 2, 64 * n));
+    C25519_TRY(hipStreamSynchronize(s.stream));
+    return 0;
+}
+
+int ed25519_VerifySignature_ragged_batch(int* verdict, const unsigned char* sig, const unsigned char* pk,
+                                         const unsigned char* msgs, const uint64_t* offsets, size_t n)
+{
+    if (!verdict || !sig || !pk || !offsets) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    Staging& s = staging();
+    C25519_RC(s.ensure_stream());
+    C25519_RC(up(s, 0, sig, 64 * n));
+    C25519_RC(up(s, 1, pk, 32 * n));
+    C25519_RC(up(s, 2, msgs, (size_t)offsets[n]));
+    C25519_RC(s.reserve(3, sizeof(int) * n));
+    C25519_RC(up(s, 4, offsets, sizeof(uint64_t) * (n + 1)));
+    C25519_RC(ed25519_VerifySignature_ragged_dev(s.ptr[3], s.ptr[0], s.ptr[1], s.ptr[2], (const uint64_t*)s.ptr[4], n,
+                                                 s.stream));
     C25519_RC(down(s, verdict, 3, sizeof(int) * n));
     C25519_TRY(hipStreamSynchronize(s.stream));
     return 0;

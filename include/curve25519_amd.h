@@ -60,11 +60,23 @@ int ed25519_SignMessage_batch(unsigned char *sig, const unsigned char *priv, con
 int ed25519_SignMessage_dev(void *sig, const void *priv, const void *msg, size_t msg_size, size_t n,
                             void *stream);
 
+/* the same with messages of different lengths: message i is msgs[offsets[i] .. offsets[i+1]),
+ * offsets has n+1 entries (host memory for _batch, device memory for _dev) */
+int ed25519_SignMessage_ragged_batch(unsigned char *sig, const unsigned char *priv, const unsigned char *msgs,
+                                     const uint64_t *offsets, size_t n);
+int ed25519_SignMessage_ragged_dev(void *sig, const void *priv, const void *msgs, const uint64_t *offsets,
+                                   size_t n, void *stream);
+
 /* n x ed25519_VerifySignature (reference :67): full Init + Check per element, distinct keys */
 int ed25519_VerifySignature_batch(int *verdict, const unsigned char *sig, const unsigned char *pk,
                                   const unsigned char *msg, size_t msg_size, size_t n);
 int ed25519_VerifySignature_dev(void *verdict, const void *sig, const void *pk, const void *msg,
                                 size_t msg_size, size_t n, void *stream);
+
+int ed25519_VerifySignature_ragged_batch(int *verdict, const unsigned char *sig, const unsigned char *pk,
+                                         const unsigned char *msgs, const uint64_t *offsets, size_t n);
+int ed25519_VerifySignature_ragged_dev(void *verdict, const void *sig, const void *pk, const void *msgs,
+                                       const uint64_t *offsets, size_t n, void *stream);
 
 /* bytes of device scratch ed25519_VerifySignature_dev needs for n elements (per-lane 4-fold tables);
  * the library allocates and caches it per host thread (2560 bytes per element). */

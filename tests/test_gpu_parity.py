@@ -179,6 +179,27 @@ def test_message_lengths(api, oracle, mlen):
         assert not api.ed25519_VerifySignature(sig, pub, msg).any()
 
 
+def test_ragged_message_lengths(api, oracle):
+    """Per-element message lengths in one batch (the reference takes msg_size per call): lengths 0..300 mixed."""
+    n = 700
+    sk = synth.random_bytes((n, 32), 0x8001)
+    pub, priv = oracle.ed25519_keypair(sk, threads=THREADS)
+    lens = synth.random_bytes((n, 2), 0x8002).astype(np.int64)
+    lens = (lens[:, 0] * 256 + lens[:, 1]) % 301
+    lens[:8] = [0, 1, 47, 48, 111, 112, 128, 300]
+    blob = synth.random_bytes((int(lens.sum()) + 1,), 0x8003)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    msgs = [blob[offs[i]:offs[i + 1]].tobytes() for i in range(n)]
+    sig = api.ed25519_SignMessage_ragged(priv, msgs)
+    exp = np.concatenate([oracle.ed25519_sign(priv[i:i + 1], np.frombuffer(msgs[i], np.uint8).reshape(1, -1))
+                          for i in range(n)])
+    assert np.array_equal(sig, exp)
+    assert api.ed25519_VerifySignature_ragged(sig, pub, msgs).all()
+    bad = [m + b"x" if i % 3 == 0 else m for i, m in enumerate(msgs)]
+    ok = api.ed25519_VerifySignature_ragged(sig, pub, bad)
+    assert np.array_equal(ok == 0, np.arange(n) % 3 == 0)
+
+
 # ---- size-independent properties at the full batch size --------------------------------------------------
 
 def test_full_size_properties(api):
