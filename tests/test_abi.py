@@ -44,8 +44,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in curve25519_amd/_lib.py"
     assert b"gfx950" in lib.c25519_amd_version()
-    assert lib.ed25519_VerifySignature_scratch_bytes(64) == 64 * 2560      # 16 rows x 40 limbs per element
-    assert lib.ed25519_VerifySignature_scratch_bytes(65) == 65 * 2560
+    # per element: 16 rows x 40 limbs of 4-fold table + (X, Y, Z, prefix) projective scratch (16-byte aligned parts)
+    for n in (64, 65, 1 << 20):
+        parts = 4 * ((10 * n + 3) // 4 * 4) * 4
+        assert lib.ed25519_VerifySignature_scratch_bytes(n) == n * 2560 + parts
 
 
 def test_headers_compile_as_c_and_cxx(tmp_path):
