@@ -40,10 +40,26 @@ def measured_mad_peak():
         return None
 
 
-X25519_KERNELS = ("k_x25519_ladder", "void k_batch_invert<FinishX25519>")
+PASS_KERNELS = {
+    "x25519": ("k_x25519_ladder", "void k_batch_invert<FinishX25519>"),
+    "sign": ("k_ed25519_sign_mult", "void k_batch_invert<FinishPack>", "k_ed25519_sign_finish"),
+    "verify": ("void k_ed25519_verify_init<c25519::QTableLimbs>", "void k_ed25519_verify_check<c25519::QTableLimbs>",
+               "void k_batch_invert<FinishVerify>"),
+}
+METRIC_NAME = {
+    "x25519": "X25519 shared-key ops/sec (batch=2^20 per GPU, variable-base Montgomery ladder)",
+    "sign": "Ed25519 signs/sec (batch=2^20 per GPU, 8-fold fixed-base walk, 32-byte messages)",
+    "verify": "Ed25519 verifies/sec (batch=2^20 per GPU, distinct keys, 4-fold + 8-fold double-scalar walk)",
+}
+WORKLOAD_NAME = {
+    "x25519": "BASELINE.json configs[1]: batch 2^20 X25519 curve25519_dh_CreateSharedKey per GPU, one keypair per "
+              "lane, inputs resident in HBM",
+    "sign": "BASELINE.json configs[2]: batch 2^20 ed25519_SignMessage per GPU, base table staged in LDS",
+    "verify": "BASELINE.json configs[3]: batch 2^20 ed25519_VerifySignature per GPU (Verify_Init + Verify_Check)",
+}
 
 
-def measured_traffic(kernels=X25519_KERNELS):
+def measured_traffic(kernels):
     """HBM bytes per X25519 pass (ladder launch + batched-inversion launch) from the committed rocprofv3 PMC
     passes (separate --pmc runs of this same bench, summarised by tools/rocpd_summary.py):
     WRITE_SIZE + 2 x FETCH_SIZE, both in KiB -- the x2 is the gfx950 FETCH_SIZE correction of
@@ -129,6 +145,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="operations per GPU per step (default 2^20)")
     ap.add_argument("--no-extra", action="store_true", help="skip the Ed25519 sign/verify side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--workload", choices=("x25519", "sign", "verify"), default="x25519",
+                    help="x25519 = BASELINE.json configs[1] (the default and the driver's contract); sign / verify = "
+                         "configs[2] / configs[3], same batch size, for the side tables of DESIGN.md")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="run the N>1 code path (process group + RCCL gather) with a world of one rank")
     args = ap.parse_args()
@@ -155,15 +174,25 @@ def main():
 
     n = args.batch
     eng = HipEngine(dev)
-    # this rank's shard of the global seeded stream: rows [rank*n, (rank+1)*n)
-    sk_all, pk_all = synth.x25519_inputs(n) if world == 1 else (None, None)
-    if world > 1:
-        import numpy as np
-        sk_all = synth.random_bytes((n, 32), synth.SEED_X25519_SK + 0x100 * rank)
-        pk_all = synth.random_bytes((n, 32), synth.SEED_X25519_PK + 0x100 * rank)
-    sk = torch.from_numpy(sk_all).to(dev)
-    pk = torch.from_numpy(pk_all).to(dev)
-    out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    wl = args.workload
+    seed_shift = 0x100 * rank if world > 1 else 0          # every rank owns its own 2^20 elements (weak scaling)
+    if wl == "x25519":
+        sk = torch.from_numpy(synth.random_bytes((n, 32), synth.SEED_X25519_SK + seed_shift)).to(dev)
+        pk = torch.from_numpy(synth.random_bytes((n, 32), synth.SEED_X25519_PK + seed_shift)).to(dev)
+        width, odtype = 32, torch.uint8
+        launch = lambda dst: eng.api.curve25519_dh_CreateSharedKey_dev(dst, pk, sk)          # noqa: E731
+    else:
+        esk = torch.from_numpy(synth.random_bytes((n, 32), synth.SEED_ED_SK + seed_shift)).to(dev)
+        msg = torch.from_numpy(synth.random_bytes((n, 32), synth.SEED_ED_MSG + seed_shift)).to(dev)
+        pub, priv = eng.ed25519_keypair(esk)
+        if wl == "sign":
+            width, odtype = 64, torch.uint8
+            launch = lambda dst: eng.api.ed25519_SignMessage_dev(dst, priv, msg)             # noqa: E731
+        else:
+            sig = eng.ed25519_sign(priv, msg)
+            width, odtype = 1, torch.int32
+            launch = lambda dst: eng.api.ed25519_VerifySignature_dev(dst, sig, pub, msg)     # noqa: E731
+    out = torch.empty((n, width), dtype=odtype, device=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -171,13 +200,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    og = OverlappedGather(n, 32, dev, root=0) if use_dist else None
+    og = OverlappedGather(n, width, dev, root=0, dtype=odtype) if use_dist else None
 
     def step(ev=None):
         dst = og.next_buffer() if og else out
         if ev:
             ev[0].record()
-        eng.api.curve25519_dh_CreateSharedKey_dev(dst, pk, sk)
+        launch(dst)
         if ev:
             ev[1].record()
         if og:
@@ -206,17 +235,16 @@ def main():
     if rank == 0:
         value = world * n * args.steps / elapsed
         kernel_s = kernel_ms * 1e-3
-        achieved_gbs = BYTES_PER_OP["x25519"] * n / kernel_s / 1e9
+        achieved_gbs = BYTES_PER_OP[wl] * n / kernel_s / 1e9
         peak_mac = measured_mad_peak()
-        traffic, traffic_src = measured_traffic()
-        achieved_mac = MACS_PER_OP["x25519"] * n / kernel_s
+        traffic, traffic_src = measured_traffic(PASS_KERNELS[wl])
+        achieved_mac = MACS_PER_OP[wl] * n / kernel_s
         result = {
-            "metric": "X25519 shared-key ops/sec (batch=2^20 per GPU, variable-base Montgomery ladder)",
+            "metric": METRIC_NAME[wl],
             "value": round(value, 1), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 limbs, u64 accumulators (v_mad_u64_u32)", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: batch 2^20 X25519 curve25519_dh_CreateSharedKey per GPU, "
-                                   "one keypair per lane, inputs resident in HBM",
+            "config": {"workload": WORKLOAD_NAME[wl],
                        "batch_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -224,18 +252,18 @@ def main():
                          "traffic_source": f"profiles/{traffic_src}: (2*FETCH_SIZE + WRITE_SIZE) KiB, ladder + inversion "
                                            "launches; = 96 B/op API bytes + 32 B/op clamped-key write-back + the "
                                            "projective intermediates staged for the batched inversion" if traffic_src else None,
-                         "kernel": "k_x25519_ladder (+ k_batch_invert<FinishX25519>, ~2% of the pass)",
+                         "kernel": " + ".join(PASS_KERNELS[wl]) + " (first one dominates)",
                          "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": BYTES_PER_OP["x25519"] * n,
+                         "algorithmic_bytes_per_launch": BYTES_PER_OP[wl] * n,
                          "note": "VALU-integer bound path: HBM fraction is tiny by construction, see roofline_valu"},
             "roofline_valu": {"bound": "valu v_mad_u64_u32", "achieved": round(achieved_mac / 1e12, 4),
                               "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s",
                               "frac": round(achieved_mac / peak_mac, 4) if peak_mac else None,
-                              "algorithmic_macs_per_op": MACS_PER_OP["x25519"]},
+                              "algorithmic_macs_per_op": MACS_PER_OP[wl]},
         }
 
     # ---- side measurements, outside the timed region (rank 0, single GPU only) ----
-    if rank == 0 and world == 1 and not args.no_extra:
+    if rank == 0 and world == 1 and not args.no_extra and wl == "x25519":
         extra = {}
         esk_np, msg_np = synth.ed25519_inputs(n)
         esk = torch.from_numpy(esk_np).to(dev)

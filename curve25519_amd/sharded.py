@@ -129,3 +129,21 @@ def ed25519_sign_sharded(engine, priv_local, msg_local, root: int = 0, group=Non
 
 def ed25519_verify_sharded(engine, sig_local, pk_local, msg_local, root: int = 0, group=None):
     return gather_rows(engine.ed25519_verify(sig_local, pk_local, msg_local), root, group)
+
+
+# ---- BASELINE.json configs[4]: a mixed X25519 + Ed25519 batch sharded over the ranks -----------------------
+def mixed_thirds(n: int) -> Tuple[Tuple[int, int], Tuple[int, int], Tuple[int, int]]:
+    """Element i of a mixed batch is X25519 / sign / verify by contiguous thirds (the split SURVEY.md 8(d)
+    allows; stated here so fixtures and ranks agree): [0, a) X25519, [a, b) sign, [b, n) verify."""
+    a, b = n // 3, 2 * (n // 3)
+    return (0, a), (a, b), (b, n)
+
+
+def mixed_sharded(engine, x_pk, x_sk, s_priv, s_msg, v_sig, v_pk, v_msg, root: int = 0, group=None):
+    """Each rank holds its contiguous shard of the three sub-batches; results are gathered to `root` with one
+    gather per output type (32-byte secrets, 64-byte signatures, int32 verdicts).  Returns the three
+    gathered tensors on root, (None, None, None) elsewhere."""
+    shared = engine.x25519_shared(x_pk, x_sk)
+    sig = engine.ed25519_sign(s_priv, s_msg)
+    ok = engine.ed25519_verify(v_sig, v_pk, v_msg)
+    return (gather_rows(shared, root, group), gather_rows(sig, root, group), gather_rows(ok, root, group))

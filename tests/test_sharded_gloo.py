@@ -67,6 +67,18 @@ def _worker(rank, world, port, n, q):
         og.finish()
         if rank == 0:
             seen = [og.gathered(b).numpy().copy() for b in (0, 1)]
+        # BASELINE.json configs[4]: mixed batch, contiguous thirds, every third sharded over the ranks
+        (xa, xb), (sa, sb), (va, vb) = sharded.mixed_thirds(n)
+        cut = lambda lo_, hi_: sharded.shard_bounds(hi_ - lo_, world)[rank]  # noqa: E731
+        t = lambda a_: torch.from_numpy(np.ascontiguousarray(a_))  # noqa: E731
+        fpub, fpriv = eng.o.ed25519_keypair(esk)
+        fsig = eng.o.ed25519_sign(fpriv, msg)
+        l0, h0 = cut(xa, xb); l1, h1 = cut(sa, sb); l2, h2 = cut(va, vb)
+        mixed = sharded.mixed_sharded(eng, t(pk[xa + l0:xa + h0]), t(sk[xa + l0:xa + h0].copy()),
+                                      t(fpriv[sa + l1:sa + h1]), t(msg[sa + l1:sa + h1]),
+                                      t(fsig[va + l2:va + h2]), t(fpub[va + l2:va + h2]), t(msg[va + l2:va + h2]))
+        if rank == 0:
+            seen.append([m.numpy() for m in mixed])
         if rank == 0:
             q.put((shared.numpy(), sig.numpy(), ok.numpy(), seen, rows))
         else:
@@ -108,6 +120,11 @@ def test_sharded_matches_unsharded(world, n, oracle):
     assert ok.shape == (n, 1) and ok.all()
     # buffer 0 last carried batch 2, buffer 1 carried batch 1; rows are rank-major, zero padded to `rows`
     from curve25519_amd.sharded import shard_bounds
+    (xa, xb), (sa, sb), (va, vb) = __import__("curve25519_amd.sharded", fromlist=["x"]).mixed_thirds(n)
+    m_shared, m_sig, m_ok = seen[2]
+    assert np.array_equal(m_shared, exp_shared[xa:xb])
+    assert np.array_equal(m_sig, oracle.ed25519_sign(priv, msg)[sa:sb])
+    assert m_ok.shape == (vb - va, 1) and m_ok.all()
     for b, stepno in ((0, 2), (1, 1)):
         got = seen[b].reshape(world, rows, 32)
         for r, (lo, hi) in enumerate(shard_bounds(n, world)):
