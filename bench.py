@@ -289,6 +289,22 @@ def main():
             extra[f"ed25519_{name}_per_s"] = round(n / (ms * 1e-3), 1)
             extra[f"ed25519_{name}_kernel_ms"] = round(ms, 4)
         extra["ed25519_verify_all_valid"] = bool(int(ok.sum().item()) == n)
+        # two-phase verification, ONE key for the whole batch (Verify_Init once, 2^20 Verify_Check)
+        from curve25519_amd import _lib
+        import ctypes as C
+        L = _lib.load()
+        one_priv = priv[:1].repeat(n, 1).contiguous()
+        one_sig = eng.ed25519_sign(one_priv, msg)
+        ctx = torch.empty((1, 2080), dtype=torch.uint8, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.ed25519_Verify_Init_dev(C.c_void_p(ctx.data_ptr()), C.c_void_p(pub[:1].contiguous().data_ptr()), 1, st),
+                   "ed25519_Verify_Init_dev")
+        chk = lambda: _lib.check(L.ed25519_Verify_Check_dev(C.c_void_p(ok.data_ptr()), C.c_void_p(ctx.data_ptr()),  # noqa: E731
+                                                            C.c_void_p(one_sig.data_ptr()), C.c_void_p(msg.data_ptr()),
+                                                            32, n, st), "ed25519_Verify_Check_dev")
+        ms = timeit(chk)
+        extra["ed25519_verify_check_one_key_per_s"] = round(n / (ms * 1e-3), 1)
+        extra["ed25519_verify_check_one_key_all_valid"] = bool(int(ok.sum().item()) == n)
         result["extra"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu:

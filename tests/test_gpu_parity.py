@@ -274,6 +274,40 @@ def test_two_phase_verification(api, oracle):
                               oracle.ed25519_verify(gs, np.repeat(gp[k:k + 1], 256, axis=0), gm))
 
 
+def test_concurrent_host_threads(api, oracle):
+    """The shim is re-entrant like the reference (SURVEY.md 8(b) Threading): host threads calling the batch API
+    at the same time each get their own stream, staging buffers and scratch."""
+    import threading
+    results, errors = {}, []
+
+    def worker(t):
+        try:
+            n = 3000 + 257 * t
+            sk = synth.random_bytes((n, 32), 0x9000 + t)
+            pk = synth.random_bytes((n, 32), 0x9100 + t)
+            msg = synth.random_bytes((n, 20 + t), 0x9200 + t)
+            for _ in range(3):
+                shared, _ = api.curve25519_dh_CreateSharedKey(pk, sk)
+                pub, priv = api.ed25519_CreateKeyPair(sk)
+                sig = api.ed25519_SignMessage(priv, msg)
+                ok = api.ed25519_VerifySignature(sig, pub, msg)
+            results[t] = (sk, pk, msg, shared, pub, sig, ok)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t, (sk, pk, msg, shared, pub, sig, ok) in results.items():
+        assert np.array_equal(shared, oracle.x25519_shared(pk, sk, threads=THREADS)[0]), t
+        epub, epriv = oracle.ed25519_keypair(sk, threads=THREADS)
+        assert np.array_equal(pub, epub) and np.array_equal(sig, oracle.ed25519_sign(epriv, msg, threads=THREADS)), t
+        assert ok.all()
+
+
 def test_single_call_reference_api(api):
     """The eleven reference entry points, one element at a time (a device batch of one each)."""
     from curve25519_amd import _lib
@@ -311,3 +345,17 @@ def test_c_caller_links_and_passes(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "0 failure(s)" in p.stdout
+
+
+def test_reference_harness_runs_on_this_library():
+    """The reference's own test/curve25519_test.c (dh_test, signature_test with the RFC 8032 vector and the
+    blinded path, the donna cross-check and speed_test), built in the build container by
+    `make -C oracle ref-harness` against libcurve25519_amd.so instead of libcurve25519.a.  Its exit code is its
+    failure count.  Skipped where the prebuilt binary did not travel."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_on_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_harness_on_amd not built (needs /root/reference at build time)")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "Signature Verified Successfully" in p.stdout
+    assert "FAILED" not in p.stdout
