@@ -10,8 +10,9 @@
 // (profiles/r01_valu_rates.txt) v_mad_u64_u32 issues at ~30 T lane-op/s, barely slower than
 // v_addc_co_u32 (~35 T/s), so a saturated schoolbook product pays one carry instruction per multiply
 // AND serialises every step on VCC.  With 2^25.5 limbs a product is a pure chain of v_mad_u64_u32 into
-// ten independent 64-bit accumulators (no carries, no VCC), the x19 fold of 2^255 = 19 is absorbed by
-// pre-scaling one operand, and add/sub are ten plain v_add_u32 / v_sub_u32.
+// 64-bit accumulators (no carries, no VCC), the x19 fold of 2^255 = 19 is absorbed by pre-scaling one
+// operand, and add/sub are ten plain v_add_u32 / v_sub_u32.  The carry out of column k is the addend the
+// first MAD of column k+1 starts from, so carry propagation costs a 64-bit shift and a mask per limb.
 //
 // Bound contract (beta = limb / 2^w, w = 26 for even limbs, 25 for odd):
 //   reduced          : output of mul / sqr / mul121665_add / from_bytes, limb < 2^w + 2^17
@@ -111,9 +112,150 @@ C25519_DEV void fe_carry64(fe& r, u64 (&h)[10])
     for (int i = 0; i < 10; i++) r.v[i] = (u32)h[i];
 }
 
+// ---- chained-carry products --------------------------------------------------------------------------------
+// v_mad_u64_u32 adds a 64-bit value for free.  If the chain of MADs of column k+1 STARTS from the carry out of
+// column k, the carry propagation costs a 64-bit shift and a mask per limb and no separate 64-bit add (saves
+// 9 v_lshl_add_u64 per product).  Written with the MAD as an asm statement because the compiler's
+// reassociation otherwise moves the carry back to the end of each chain.
+#ifndef C25519_CHAINED
+#define C25519_CHAINED 1
+#endif
+
+// acc += sum x[t]*y[t]: one asm statement per column, so the compiler cannot reassociate the chain and does
+// not pad every MAD with a wait state (it pads asm boundaries only)
+C25519_DEV u64 mad_chain5(u64 acc, const u32 (&x)[5], const u32 (&y)[5])
+{
+    u64 carry_out;
+    asm(
+        "v_mad_u64_u32 %0, %1, %2, %7, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %3, %8, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %4, %9, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %5, %10, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %11, %0"
+        : "+v"(acc), "=s"(carry_out)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]),
+          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]));
+    return acc;
+}
+
+C25519_DEV u64 mad_chain6(u64 acc, const u32 (&x)[6], const u32 (&y)[6])
+{
+    u64 carry_out;
+    asm(
+        "v_mad_u64_u32 %0, %1, %2, %8, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %3, %9, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %4, %10, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %5, %11, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %12, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %7, %13, %0"
+        : "+v"(acc), "=s"(carry_out)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
+          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]));
+    return acc;
+}
+
+C25519_DEV u64 mad_chain10(u64 acc, const u32 (&x)[10], const u32 (&y)[10])
+{
+    u64 carry_out;
+    asm(
+        "v_mad_u64_u32 %0, %1, %2, %12, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %3, %13, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %4, %14, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %5, %15, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %16, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %7, %17, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %8, %18, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %9, %19, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %10, %20, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %11, %21, %0"
+        : "+v"(acc), "=s"(carry_out)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]),
+          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8]), "v"(y[9]));
+    return acc;
+}
+
+// limbs l[0..9] hold the masked columns, `carry` is what left column 9: fold it back times 19
+C25519_DEV void fe_finish_chain(fe& r, u32 (&l)[10], u64 carry)
+{
+    const u64 t = carry * 19 + l[0];
+    l[0] = (u32)t & M26;
+    l[1] += (u32)(t >> 26);
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = l[i];
+}
+
+C25519_DEV void fe_mul_chained(fe& r, const fe& a, const fe& b)
+{
+    u32 b19[10], a2[10], l[10];
+#pragma unroll
+    for (int j = 1; j < 10; j++) b19[j] = b.v[j] * 19u;
+#pragma unroll
+    for (int i = 1; i < 10; i += 2) a2[i] = dbl32(a.v[i]);
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        u32 x[10], y[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            const bool wrap = i > k;
+            const bool odd2 = (i & 1) && (j & 1);
+            x[i] = odd2 ? a2[i] : a.v[i];
+            y[i] = wrap ? b19[j] : b.v[j];
+        }
+        acc = mad_chain10(acc, x, y);
+        l[k] = (u32)acc & fe_mask(k);
+        acc >>= fe_w(k);
+    }
+    fe_finish_chain(r, l, acc);
+}
+
+template <bool SCALE2, typename Extra>
+C25519_DEV void fe_sqr_chained(fe& r, const fe& a, Extra extra)
+{
+    u32 f2[10], f19[10], f38[10], l[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) f2[i] = dbl32(a.v[i]);
+#pragma unroll
+    for (int j = 5; j < 10; j++) f19[j] = a.v[j] * 19u;
+#pragma unroll
+    for (int j = 5; j < 10; j += 2) f38[j] = a.v[j] * 38u;
+    u64 carry = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        u64 acc = SCALE2 ? 0 : carry + extra(k);
+        u32 x[6], y[6];
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            if (i > j) continue;
+            const bool wrap = (i + j) >= 10;
+            const bool odd2 = (i & 1) && (j & 1);
+            x[cnt] = (i < j) ? f2[i] : a.v[i];
+            y[cnt] = odd2 ? (wrap ? f38[j] : f2[j]) : (wrap ? f19[j] : a.v[j]);
+            cnt++;
+        }
+        if (k & 1) {                                      // odd columns have 5 unordered pairs, even ones 6
+            const u32 x5[5] = { x[0], x[1], x[2], x[3], x[4] }, y5[5] = { y[0], y[1], y[2], y[3], y[4] };
+            acc = mad_chain5(acc, x5, y5);
+        } else {
+            acc = mad_chain6(acc, x, y);
+        }
+        if (SCALE2) acc = 2 * acc + carry + extra(k);
+        l[k] = (u32)acc & fe_mask(k);
+        carry = acc >> fe_w(k);
+    }
+    fe_finish_chain(r, l, carry);
+}
+
 // r = a * b.   beta_a <= 5, beta_b <= 3.3; r may alias a or b.   (ecp_MulReduce)
 C25519_DEV void fe_mul(fe& r, const fe& a, const fe& b)
 {
+#if C25519_CHAINED
+    fe_mul_chained(r, a, b);
+    return;
+#endif
     u32 b19[10], a2[10];
 #pragma unroll
     for (int j = 1; j < 10; j++) b19[j] = b.v[j] * 19u;
@@ -169,6 +311,10 @@ C25519_DEV void fe_sqr_columns(u64 (&h)[10], const fe& a)
 // r = a^2.   beta_a <= 3.3; r may alias a.   (ecp_SqrReduce)
 C25519_DEV void fe_sqr(fe& r, const fe& a)
 {
+#if C25519_CHAINED
+    fe_sqr_chained<false>(r, a, [](int) -> u64 { return 0; });
+    return;
+#endif
     u64 h[10];
     fe_sqr_columns(h, a);
     fe_carry64(r, h);
@@ -178,6 +324,10 @@ C25519_DEV void fe_sqr(fe& r, const fe& a)
 // beta_a <= 3.3, beta_m <= 2 (bias 4p).
 C25519_DEV void fe_sqr_sub(fe& r, const fe& a, const fe& m)
 {
+#if C25519_CHAINED
+    fe_sqr_chained<false>(r, a, [&](int k) -> u64 { return (u64)(2u * fe_2p(k) - m.v[k]); });
+    return;
+#endif
     u64 h[10];
     fe_sqr_columns(h, a);
 #pragma unroll
@@ -189,6 +339,10 @@ C25519_DEV void fe_sqr_sub(fe& r, const fe& a, const fe& m)
 // beta_a <= 2.3 (columns are doubled), p any beta < 8, m reduced (bias 2p).
 C25519_DEV void fe_sqr2_add_sub(fe& r, const fe& a, const fe& p, const fe& m)
 {
+#if C25519_CHAINED
+    fe_sqr_chained<true>(r, a, [&](int k) -> u64 { return (u64)(p.v[k] + fe_2p(k) - m.v[k]); });
+    return;
+#endif
     u64 h[10];
     fe_sqr_columns(h, a);
 #pragma unroll
