@@ -70,17 +70,17 @@ C25519_DEV void fe_neg(fe& r, const fe& a)
     for (int i = 0; i < 10; i++) r.v[i] = fe_2p(i) - a.v[i];
 }
 
-// x + x without letting the compiler turn it back into a shift: on gfx950 v_add_u32 issues at the fast
-// VOP2 rate (~24 lanes/clk/SIMD) while v_lshlrev_b32 runs at the slower VOP3-class rate (~15.8), see
+// 2x as v_add_u32 x, x: on gfx950 v_add_u32 issues at the fast VOP2 rate (~24 lanes/clk/SIMD) while
+// v_lshlrev_b32 -- what the compiler picks for x*2 or x+x -- runs at the slower VOP3-class rate (~15.8), see
 // profiles/r01_valu_rates_select_shift.txt.
 C25519_DEV u32 dbl32(u32 x)
 {
 #ifdef C25519_DBL_BY_SHIFT
     return x * 2u;
 #else
-    u32 t = x;
-    asm("" : "+v"(t));
-    return x + t;
+    u32 r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
 #endif
 }
 
