@@ -591,10 +591,15 @@ ProjScratch carve_proj(u32* base, size_t n)
     return ProjScratch{ base, base + part, base + 2 * part, base + 3 * part };
 }
 
-// how many elements share one inversion: as many as possible while every SIMD still gets two waves
+// how many elements share one inversion: as many as possible while every SIMD still gets a wave
+// (measured at n = 2^20: K = 2 / 4 / 8 / 16 -> 9.52 / 9.39 / 9.33 / 9.29 ms per X25519 pass)
 inline int inversion_k(size_t n)
 {
-    size_t k = n / ((size_t)2 * 1024 * 64);
+    if (const char* e = getenv("C25519_AMD_INV_K")) {      // tuning knob, 1..16
+        int v = atoi(e);
+        if (v >= 1 && v <= INV_MAX_K) return v;
+    }
+    size_t k = n / ((size_t)1024 * 64);
     if (k < 1) k = 1;
     if (k > INV_MAX_K) k = INV_MAX_K;
     return (int)k;
