@@ -41,10 +41,10 @@ def measured_mad_peak():
 
 
 PASS_KERNELS = {
-    "x25519": ("k_x25519_ladder", "void k_batch_invert<FinishX25519>"),
-    "sign": ("k_ed25519_sign_mult", "void k_batch_invert<FinishPack>", "k_ed25519_sign_finish"),
-    "verify": ("void k_ed25519_verify_init<c25519::QTableLimbs>", "void k_ed25519_verify_check<c25519::QTableLimbs>",
-               "void k_batch_invert<FinishVerify>"),
+    "x25519": ("k_x25519_ladder", "k_batch_invert<FinishX25519>"),
+    "sign": ("k_ed25519_sign_mult", "k_batch_invert<FinishPack>", "k_ed25519_sign_finish"),
+    "verify": ("k_ed25519_verify_init<c25519::QTableLimbs>", "k_ed25519_verify_check<c25519::QTableLimbs>",
+               "k_batch_invert<FinishVerify>"),
 }
 METRIC_NAME = {
     "x25519": "X25519 shared-key ops/sec (batch=2^20 per GPU, variable-base Montgomery ladder)",
@@ -69,7 +69,10 @@ def measured_traffic(kernels):
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))[-1]
         with open(path) as f:
             d = json.load(f)
-        total = sum((2.0 * d[k]["FETCH_SIZE"] + d[k]["WRITE_SIZE"]) * 1024 for k in kernels)
+        def rec(name):                      # rocprof prints template kernels as "void name<...>"
+            hits = [v for k, v in d.items() if name in k and "<true>" not in k]
+            return hits[0]
+        total = sum((2.0 * rec(k)["FETCH_SIZE"] + rec(k)["WRITE_SIZE"]) * 1024 for k in kernels)
         return int(total), os.path.basename(path)
     except Exception:
         return None, None

@@ -85,18 +85,19 @@ struct ProjScratch {            // projective result + prefix products of the ba
 // ------------------------------------------------------------------------------------------------
 constexpr int X_BLOCK = 64;
 
-// pk == nullptr: base point u = 9
+// BASE9 (pk == nullptr): ladder on the base point u = 9
+template <bool BASE9>
 __global__ void __launch_bounds__(X_BLOCK) k_x25519_ladder(ProjScratch scr, const void* pk, void* sk, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * X_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8];
-    if (pk) load32(u, pk, i);
+    if (!BASE9) load32(u, pk, i);
     load32(k, sk, i);
     clamp_words(k);
     store32(sk, i, k);                       // the reference clamps in the caller's buffer
     fe PX, PZ;
-    x25519_ladder_xz(PX, PZ, u, k);
+    x25519_ladder_xz<BASE9>(PX, PZ, u, k);
     soa_store_fe(scr.a, n, i, PX);
     soa_store_fe(scr.z, n, i, PZ);
 }
@@ -644,7 +645,8 @@ static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t
     void* w = nullptr;
     C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
-    k_x25519_ladder<<<grid_for(n, X_BLOCK), X_BLOCK, 0, stream>>>(scr, pk, sk, n);
+    if (pk) k_x25519_ladder<false><<<grid_for(n, X_BLOCK), X_BLOCK, 0, stream>>>(scr, pk, sk, n);
+    else    k_x25519_ladder<true><<<grid_for(n, X_BLOCK), X_BLOCK, 0, stream>>>(scr, pk, sk, n);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishX25519{ scr.a, out, n }, stream));
     return tl_work.release(stream);

@@ -365,6 +365,15 @@ C25519_DEV void fe_mul121665_add(fe& r, const fe& a, const fe& b)
     fe_carry64(r, h);
 }
 
+// r = c * a for a small constant c < 2^16 (any beta_a <= 8); reduced out
+C25519_DEV void fe_mul_small(fe& r, const fe& a, u32 c)
+{
+    u64 h[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) h[i] = (u64)a.v[i] * c;
+    fe_carry64(r, h);
+}
+
 // one carry pass over 32-bit limbs: brings any beta < 2^6 back to reduced
 C25519_DEV void fe_carry32(fe& r, const fe& a)
 {

@@ -20,6 +20,9 @@ namespace c25519 {
 
 // one ladder step.  prev_eq = all-ones when this bit equals the previous one.
 //   S' = S + D (difference = base),  D' = 2 * (prev_eq ? D : S)
+// BASE9: the difference point is the curve's base point u = 9 (curve25519_dh_CalculatePublicKey), so the
+// one multiplication by it is a 10-MAD small-constant multiply instead of a full product.
+template <bool BASE9 = false>
 C25519_DEV void ladder_step(fe& SX, fe& SZ, fe& DX, fe& DZ, const fe& base, u32 prev_eq)
 {
     fe A, B, C, Dp, P, M;
@@ -36,7 +39,8 @@ C25519_DEV void ladder_step(fe& SX, fe& SZ, fe& DX, fe& DZ, const fe& base, u32 
     fe_sub(B, A, B);                   // beta 3
     fe_sqr(SX, C);                     // x3
     fe_sqr(A, B);
-    fe_mul(SZ, A, base);               // z3 = (..)^2 * xb
+    if (BASE9) fe_mul_small(SZ, A, 9);  // z3 = (..)^2 * 9
+    else fe_mul(SZ, A, base);          // z3 = (..)^2 * xb
 
     fe_sqr(A, P);                      // (x+z)^2
     fe_sqr(B, M);                      // (x-z)^2
@@ -49,6 +53,7 @@ C25519_DEV void ladder_step(fe& SX, fe& SZ, fe& DX, fe& DZ, const fe& base, u32 
 // (PX : PZ) = clamp(k) * (u : 1), x-only, projective.  k are the CLAMPED scalar words.  The affine result
 // PX/PZ is produced by the shared batched-inversion kernel (engine.hip), which amortises ecp_Inverse
 // (curve25519_dh.c:148) over several elements.
+template <bool BASE9 = false>
 C25519_DEV void x25519_ladder_xz(fe& PX, fe& PZ, const u32 (&u)[8], const u32 (&k)[8])
 {
     fe X1, SX, SZ, DX, DZ;
@@ -83,7 +88,7 @@ C25519_DEV void x25519_ladder_xz(fe& PX, fe& PZ, const u32 (&u)[8], const u32 (&
             const u32 bit = kw >> 31;
             kw <<= 1;
             const u32 eq = (u32)0 - (u32)(bit == prev);
-            ladder_step(SX, SZ, DX, DZ, X1, eq);
+            ladder_step<BASE9>(SX, SZ, DX, DZ, X1, eq);
             prev = bit;
         }
     }
