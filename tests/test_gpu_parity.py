@@ -219,6 +219,29 @@ def test_full_size_properties(api):
     assert not api.ed25519_VerifySignature(sig, np.roll(pub, 1, axis=0), msg).any(), "wrong key rejects"
 
 
+def test_large_odd_batch(api, oracle):
+    """n = 2^22 + 77 (not a multiple of any tile, 4x the benchmark batch): index arithmetic, scratch carving and
+    the batched-inversion tail.  Checked by properties plus an oracle spot check of the first / last rows."""
+    n = (1 << 22) + 77
+    a = synth.random_bytes((n, 32), 0x4441)
+    b = synth.random_bytes((n, 32), 0x4442)
+    pa, _ = api.curve25519_dh_CalculatePublicKey(a, fast=True)
+    pb, _ = api.curve25519_dh_CalculatePublicKey(b, fast=True)
+    s1, _ = api.curve25519_dh_CreateSharedKey(pb, a)
+    s2, _ = api.curve25519_dh_CreateSharedKey(pa, b)
+    assert np.array_equal(s1, s2)
+    rows = np.r_[0:64, n - 64:n]
+    assert np.array_equal(s1[rows], oracle.x25519_shared(pb[rows], a[rows])[0])
+    msg = synth.random_bytes((n, 16), 0x4443)
+    pub, priv = api.ed25519_CreateKeyPair(a)
+    sig = api.ed25519_SignMessage(priv, msg)
+    assert np.array_equal(sig[rows], oracle.ed25519_sign(priv[rows], msg[rows]))
+    ok = api.ed25519_VerifySignature(sig, pub, msg)
+    assert ok.all()
+    sig[n - 1, 0] ^= 1
+    assert api.ed25519_VerifySignature(sig[n - 200:], pub[n - 200:], msg[n - 200:]).sum() == 199
+
+
 # ---- the other faces of the boundary --------------------------------------------------------------------
 
 def test_device_pointer_entry_points(api, oracle):
