@@ -31,12 +31,13 @@ inline int fail(hipError_t err, const char* what, const char* file, int line)
         if (e_ != hipSuccess) return c25519_host::fail(e_, #expr, __FILE__, __LINE__); \
     } while (0)
 
-// Growable device buffers owned by one host thread.  Slots are named by the caller.
+// Growable device buffers owned by one host thread.  Slots 0-3 belong to pipeline lane 0, 4-7 to lane 1.
 struct Staging {
     static constexpr int SLOTS = 8;
     void* ptr[SLOTS] = {};
     size_t cap[SLOTS] = {};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // lane 0
+    hipStream_t stream2 = nullptr;     // lane 1 of the chunked host pipeline
     int device = -1;
 
     int ensure_stream()
@@ -46,6 +47,7 @@ struct Staging {
         if (stream && dev != device) release();
         if (!stream) {
             C25519_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            C25519_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
             device = dev;
         }
         return 0;
@@ -63,7 +65,9 @@ struct Staging {
     {
         for (int i = 0; i < SLOTS; i++) { if (ptr[i]) (void)hipFree(ptr[i]); ptr[i] = nullptr; cap[i] = 0; }
         if (stream) (void)hipStreamDestroy(stream);
+        if (stream2) (void)hipStreamDestroy(stream2);
         stream = nullptr;
+        stream2 = nullptr;
         device = -1;
     }
     ~Staging() { /* process teardown: the HIP runtime may already be gone, do not call into it */ }

@@ -26,6 +26,8 @@
 
 using namespace c25519;
 
+#define C25519_RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
 // ------------------------------------------------------------------------------------------------
 // lane I/O
 // ------------------------------------------------------------------------------------------------
@@ -616,6 +618,49 @@ int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t 
     return 0;
 }
 
+// ---- two-lane host pipeline used by the *_batch entry points ----
+struct Lane {                        // one side of the two-deep pipeline
+    Staging& s;
+    int lane;
+    hipStream_t stream() const { return lane ? s.stream2 : s.stream; }
+    void* ptr(int slot) const { return s.ptr[4 * lane + slot]; }
+    int up(int slot, const void* src, size_t bytes) const
+    {
+        C25519_RC(s.reserve(4 * lane + slot, bytes));
+        if (bytes) C25519_TRY(hipMemcpyAsync(ptr(slot), src, bytes, hipMemcpyHostToDevice, stream()));
+        return 0;
+    }
+    int room(int slot, size_t bytes) const { return s.reserve(4 * lane + slot, bytes); }
+    int down(void* dst, int slot, size_t bytes) const
+    {
+        if (bytes) C25519_TRY(hipMemcpyAsync(dst, ptr(slot), bytes, hipMemcpyDeviceToHost, stream()));
+        return 0;
+    }
+};
+
+// submit(lane, lo, count) uploads a chunk and enqueues its kernels; collect(lane, lo, count) downloads its
+// results.  Chunk i+1 is submitted BEFORE chunk i is collected, so its (host-blocking, pageable) upload and
+// the download of chunk i both run under the kernels of the neighbouring chunk.
+template <typename Submit, typename Collect>
+int pipelined(size_t n, Submit submit, Collect collect)
+{
+    Staging& s = staging();
+    C25519_RC(s.ensure_stream());
+    const size_t chunk = n >= ((size_t)1 << 18) ? round_up((n + 3) / 4, 64) : n;
+    size_t prev_lo = 0, prev_cnt = 0;
+    int lane = 0;
+    for (size_t lo = 0; lo < n; lo += chunk, lane ^= 1) {
+        const size_t cnt = n - lo < chunk ? n - lo : chunk;
+        C25519_RC(submit(Lane{ s, lane }, lo, cnt));
+        if (prev_cnt) C25519_RC(collect(Lane{ s, lane ^ 1 }, prev_lo, prev_cnt));
+        prev_lo = lo; prev_cnt = cnt;
+    }
+    C25519_RC(collect(Lane{ s, lane ^ 1 }, prev_lo, prev_cnt));
+    C25519_TRY(hipStreamSynchronize(s.stream));
+    C25519_TRY(hipStreamSynchronize(s.stream2));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -635,8 +680,6 @@ int c25519_amd_set_device(int device)
     C25519_TRY(hipSetDevice(device));
     return 0;
 }
-
-#define C25519_RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
 // ---- device-pointer entry points ----------------------------------------------------------------
 
@@ -818,7 +861,11 @@ int c25519_amd_base_table(unsigned char* out)
 }
 
 // ---- host-pointer entry points: stage, run the *_dev form, copy back -----------------------------
+// Large batches are cut into four chunks that alternate between two (stream, staging-slot) lanes, so the
+// PCIe copies of one chunk run under the kernels of the other.  Pageable host memory: the copy blocks the
+// calling thread, not the GPU.
 
+// legacy single-lane helpers (ragged entry points)
 static int up(Staging& s, int slot, const void* src, size_t bytes)
 {
     C25519_RC(s.reserve(slot, bytes));
@@ -835,32 +882,34 @@ int curve25519_dh_CreateSharedKey_batch(unsigned char* shared, const unsigned ch
 {
     if (!shared || !pk || !sk) return bad_arg("null pointer");
     if (n == 0) return 0;
-    Staging& s = staging();
-    C25519_RC(s.ensure_stream());
-    C25519_RC(up(s, 0, pk, 32 * n));
-    C25519_RC(up(s, 1, sk, 32 * n));
-    C25519_RC(s.reserve(2, 32 * n));
-    C25519_RC(curve25519_dh_CreateSharedKey_dev(s.ptr[2], s.ptr[0], s.ptr[1], n, s.stream));
-    C25519_RC(down(s, sk, 1, 32 * n));
-    C25519_RC(down(s, shared, 2, 32 * n));
-    C25519_TRY(hipStreamSynchronize(s.stream));
-    return 0;
+    return pipelined(n,
+        [&](const Lane& L, size_t lo, size_t c) -> int {
+            C25519_RC(L.up(0, pk + 32 * lo, 32 * c));
+            C25519_RC(L.up(1, sk + 32 * lo, 32 * c));
+            C25519_RC(L.room(2, 32 * c));
+            return curve25519_dh_CreateSharedKey_dev(L.ptr(2), L.ptr(0), L.ptr(1), c, L.stream());
+        },
+        [&](const Lane& L, size_t lo, size_t c) -> int {
+            C25519_RC(L.down(sk + 32 * lo, 1, 32 * c));
+            return L.down(shared + 32 * lo, 2, 32 * c);
+        });
 }
 
 static int public_batch(unsigned char* pk, unsigned char* sk, size_t n, bool fast)
 {
     if (!pk || !sk) return bad_arg("null pointer");
     if (n == 0) return 0;
-    Staging& s = staging();
-    C25519_RC(s.ensure_stream());
-    C25519_RC(up(s, 1, sk, 32 * n));
-    C25519_RC(s.reserve(2, 32 * n));
-    if (fast) C25519_RC(curve25519_dh_CalculatePublicKey_fast_dev(s.ptr[2], s.ptr[1], n, s.stream));
-    else      C25519_RC(curve25519_dh_CalculatePublicKey_dev(s.ptr[2], s.ptr[1], n, s.stream));
-    C25519_RC(down(s, sk, 1, 32 * n));
-    C25519_RC(down(s, pk, 2, 32 * n));
-    C25519_TRY(hipStreamSynchronize(s.stream));
-    return 0;
+    return pipelined(n,
+        [&](const Lane& L, size_t lo, size_t c) -> int {
+            C25519_RC(L.up(1, sk + 32 * lo, 32 * c));
+            C25519_RC(L.room(2, 32 * c));
+            return fast ? curve25519_dh_CalculatePublicKey_fast_dev(L.ptr(2), L.ptr(1), c, L.stream())
+                        : curve25519_dh_CalculatePublicKey_dev(L.ptr(2), L.ptr(1), c, L.stream());
+        },
+        [&](const Lane& L, size_t lo, size_t c) -> int {
+            C25519_RC(L.down(sk + 32 * lo, 1, 32 * c));
+            return L.down(pk + 32 * lo, 2, 32 * c);
+        });
 }
 
 int curve25519_dh_CalculatePublicKey_batch(unsigned char* pk, unsigned char* sk, size_t n) { return public_batch(pk, sk, n, false); }
@@ -870,16 +919,17 @@ int ed25519_CreateKeyPair_batch(unsigned char* pub, unsigned char* priv, const u
 {
     if (!pub || !priv || !sk) return bad_arg("null pointer");
     if (n == 0) return 0;
-    Staging& s = staging();
-    C25519_RC(s.ensure_stream());
-    C25519_RC(up(s, 0, sk, 32 * n));
-    C25519_RC(s.reserve(1, 32 * n));
-    C25519_RC(s.reserve(2, 64 * n));
-    C25519_RC(ed25519_CreateKeyPair_dev(s.ptr[1], s.ptr[2], s.ptr[0], n, s.stream));
-    C25519_RC(down(s, pub, 1, 32 * n));
-    C25519_RC(down(s, priv, 2, 64 * n));
-    C25519_TRY(hipStreamSynchronize(s.stream));
-    return 0;
+    return pipelined(n,
+        [&](const Lane& L, size_t lo, size_t c) -> int {
+            C25519_RC(L.up(0, sk + 32 * lo, 32 * c));
+            C25519_RC(L.room(1, 32 * c));
+            C25519_RC(L.room(2, 64 * c));
+            return ed25519_CreateKeyPair_dev(L.ptr(1), L.ptr(2), L.ptr(0), c, L.stream());
+        },
+        [&](const Lane& L, size_t lo, size_t c) -> int {
+            C25519_RC(L.down(pub + 32 * lo, 1, 32 * c));
+            return L.down(priv + 64 * lo, 2, 64 * c);
+        });
 }
 
 int ed25519_SignMessage_batch(unsigned char* sig, const unsigned char* priv, const unsigned char* msg,
@@ -887,15 +937,14 @@ int ed25519_SignMessage_batch(unsigned char* sig, const unsigned char* priv, con
 {
     if (!sig || !priv || (!msg && msg_size)) return bad_arg("null pointer");
     if (n == 0) return 0;
-    Staging& s = staging();
-    C25519_RC(s.ensure_stream());
-    C25519_RC(up(s, 0, priv, 64 * n));
-    C25519_RC(up(s, 1, msg, msg_size * n));
-    C25519_RC(s.reserve(2, 64 * n));
-    C25519_RC(ed25519_SignMessage_dev(s.ptr[2], s.ptr[0], s.ptr[1], msg_size, n, s.stream));
-    C25519_RC(down(s, sig, 2, 64 * n));
-    C25519_TRY(hipStreamSynchronize(s.stream));
-    return 0;
+    return pipelined(n,
+        [&](const Lane& L, size_t lo, size_t c) -> int {
+            C25519_RC(L.up(0, priv + 64 * lo, 64 * c));
+            C25519_RC(L.up(1, msg ? msg + msg_size * lo : nullptr, msg_size * c));
+            C25519_RC(L.room(2, 64 * c));
+            return ed25519_SignMessage_dev(L.ptr(2), L.ptr(0), L.ptr(1), msg_size, c, L.stream());
+        },
+        [&](const Lane& L, size_t lo, size_t c) -> int { return L.down(sig + 64 * lo, 2, 64 * c); });
 }
 
 int ed25519_VerifySignature_batch(int* verdict, const unsigned char* sig, const unsigned char* pk,
@@ -903,16 +952,15 @@ int ed25519_VerifySignature_batch(int* verdict, const unsigned char* sig, const 
 {
     if (!verdict || !sig || !pk || (!msg && msg_size)) return bad_arg("null pointer");
     if (n == 0) return 0;
-    Staging& s = staging();
-    C25519_RC(s.ensure_stream());
-    C25519_RC(up(s, 0, sig, 64 * n));
-    C25519_RC(up(s, 1, pk, 32 * n));
-    C25519_RC(up(s, 2, msg, msg_size * n));
-    C25519_RC(s.reserve(3, sizeof(int) * n));
-    C25519_RC(ed25519_VerifySignature_dev(s.ptr[3], s.ptr[0], s.ptr[1], s.ptr[2], msg_size, n, s.stream));
-    C25519_RC(down(s, verdict, 3, sizeof(int) * n));
-    C25519_TRY(hipStreamSynchronize(s.stream));
-    return 0;
+    return pipelined(n,
+        [&](const Lane& L, size_t lo, size_t c) -> int {
+            C25519_RC(L.up(0, sig + 64 * lo, 64 * c));
+            C25519_RC(L.up(1, pk + 32 * lo, 32 * c));
+            C25519_RC(L.up(2, msg ? msg + msg_size * lo : nullptr, msg_size * c));
+            C25519_RC(L.room(3, sizeof(int) * c));
+            return ed25519_VerifySignature_dev(L.ptr(3), L.ptr(0), L.ptr(1), L.ptr(2), msg_size, c, L.stream());
+        },
+        [&](const Lane& L, size_t lo, size_t c) -> int { return L.down(verdict + lo, 3, sizeof(int) * c); });
 }
 
 // ragged messages: message i is msgs[offsets[i] .. offsets[i+1]); offsets has n+1 entries (host memory)

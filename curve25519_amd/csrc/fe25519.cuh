@@ -217,7 +217,7 @@ C25519_DEV void fe_sqr_chained(fe& r, const fe& a, Extra extra)
 #pragma unroll
     for (int i = 0; i < 10; i++) f2[i] = dbl32(a.v[i]);
 #pragma unroll
-    for (int j = 5; j < 10; j++) f19[j] = a.v[j] * 19u;
+    for (int j = 6; j < 10; j += 2) f19[j] = a.v[j] * 19u;
 #pragma unroll
     for (int j = 5; j < 10; j += 2) f38[j] = a.v[j] * 38u;
     u64 carry = 0;
@@ -232,8 +232,15 @@ C25519_DEV void fe_sqr_chained(fe& r, const fe& a, Extra extra)
             if (i > j) continue;
             const bool wrap = (i + j) >= 10;
             const bool odd2 = (i & 1) && (j & 1);
-            x[cnt] = (i < j) ? f2[i] : a.v[i];
-            y[cnt] = odd2 ? (wrap ? f38[j] : f2[j]) : (wrap ? f19[j] : a.v[j]);
+            // coefficient = (i<j ? 2 : 1) * (odd2 ? 2 : 1) * (wrap ? 19 : 1), split over the two operands so
+            // that only 38*f_j (odd j) and 19*f_j (even j) are ever needed
+            if (wrap && (j & 1)) {
+                x[cnt] = (i < j && (i & 1)) ? f2[i] : a.v[i];
+                y[cnt] = f38[j];
+            } else {
+                x[cnt] = (i < j) ? f2[i] : a.v[i];
+                y[cnt] = wrap ? f19[j] : (odd2 ? f2[j] : a.v[j]);
+            }
             cnt++;
         }
         if (k & 1) {                                      // odd columns have 5 unordered pairs, even ones 6
@@ -287,7 +294,7 @@ C25519_DEV void fe_sqr_columns(u64 (&h)[10], const fe& a)
 #pragma unroll
     for (int i = 0; i < 10; i++) f2[i] = dbl32(a.v[i]);
 #pragma unroll
-    for (int j = 5; j < 10; j++) f19[j] = a.v[j] * 19u;
+    for (int j = 6; j < 10; j += 2) f19[j] = a.v[j] * 19u;
 #pragma unroll
     for (int j = 5; j < 10; j += 2) f38[j] = a.v[j] * 38u;
 
@@ -300,8 +307,14 @@ C25519_DEV void fe_sqr_columns(u64 (&h)[10], const fe& a)
             if (i > j) continue;                           // each unordered pair once
             const bool wrap = (i + j) >= 10;
             const bool odd2 = (i & 1) && (j & 1);
-            const u32 x = (i < j) ? f2[i] : a.v[i];        // cross terms doubled
-            const u32 y = odd2 ? (wrap ? f38[j] : f2[j]) : (wrap ? f19[j] : a.v[j]);
+            u32 x, y;
+            if (wrap && (j & 1)) {
+                x = (i < j && (i & 1)) ? f2[i] : a.v[i];
+                y = f38[j];
+            } else {
+                x = (i < j) ? f2[i] : a.v[i];
+                y = wrap ? f19[j] : (odd2 ? f2[j] : a.v[j]);
+            }
             acc += (u64)x * y;
         }
         h[k] = acc;

@@ -72,8 +72,12 @@ def sqr_columns(a, where):
                 continue
             wrap = i + j >= 10
             odd2 = i & 1 and j & 1
-            x = f2[i] if i < j else a[i]
-            y = (f38[j] if wrap else f2[j]) if odd2 else (f19[j] if wrap else a[j])
+            if wrap and j & 1:
+                x = f2[i] if (i < j and i & 1) else a[i]
+                y = f38[j]
+            else:
+                x = f2[i] if i < j else a[i]
+                y = f19[j] if wrap else (f2[j] if odd2 else a[j])
             h[k] += x * y
     return h
 
