@@ -20,6 +20,20 @@ namespace c25519 {
 
 // one ladder step.  prev_eq = all-ones when this bit equals the previous one.
 //   S' = S + D (difference = base),  D' = 2 * (prev_eq ? D : S)
+// (X : Z) <- 2 (X : Z)   (ecp_MontDouble, curve25519_dh.c:40-54)
+C25519_DEV void mont_double(fe& X, fe& Z)
+{
+    fe A, B;
+    fe_add(A, X, Z);                   // beta 2
+    fe_sub(B, X, Z);                   // beta 3
+    fe_sqr(A, A);
+    fe_sqr(B, B);
+    fe_mul(X, A, B);
+    fe_sub(B, A, B);                   // beta 3
+    fe_mul121665_add(A, A, B);
+    fe_mul(Z, B, A);
+}
+
 // BASE9: the difference point is the curve's base point u = 9 (curve25519_dh_CalculatePublicKey), so the
 // one multiplication by it is a 10-MAD small-constant multiply instead of a full product.
 template <bool BASE9 = false>
@@ -62,17 +76,9 @@ C25519_DEV void x25519_ladder_xz(fe& PX, fe& PZ, const u32 (&u)[8], const u32 (&
     // P = (X1 : 1), Q = 2P  (curve25519_dh.c:123-125 with zr = 1); bit 254 is the leading one
     SX = X1;
     fe_set_u32(SZ, 1);
-    {
-        fe A, B;
-        fe_add(A, SX, SZ);
-        fe_sub(B, SX, SZ);
-        fe_sqr(A, A);
-        fe_sqr(B, B);
-        fe_mul(DX, A, B);
-        fe_sub(B, A, B);
-        fe_mul121665_add(A, A, B);
-        fe_mul(DZ, B, A);
-    }
+    DX = SX;
+    DZ = SZ;
+    mont_double(DX, DZ);
 
     // state invariant: previous bit b_prev = 1  <=>  (P,Q) = (S,D); else (P,Q) = (D,S)
     u32 prev = 1;
@@ -82,9 +88,10 @@ C25519_DEV void x25519_ladder_xz(fe& PX, fe& PZ, const u32 (&u)[8], const u32 (&
 #pragma unroll
         for (int t = 1; t < 8; t++) kw = (w == t) ? k[t] : kw;
         const int top = (w == 7) ? 29 : 31;              // bit 254 consumed above, bit 255 is zero
+        const int bottom = (w == 0) ? 3 : 0;             // bits 2..0 are zero after clamping: handled below
         kw <<= (31 - top);
 #pragma unroll 1
-        for (int b = top; b >= 0; b--) {
+        for (int b = top; b >= bottom; b--) {
             const u32 bit = kw >> 31;
             kw <<= 1;
             const u32 eq = (u32)0 - (u32)(bit == prev);
@@ -96,6 +103,10 @@ C25519_DEV void x25519_ladder_xz(fe& PX, fe& PZ, const u32 (&u)[8], const u32 (&
     const u32 m = (u32)0 - prev;
     fe_select(PX, m, SX, DX);
     fe_select(PZ, m, SZ, DZ);
+    // the three clamped-away low bits: a zero bit maps (P, Q) to (2P, P+Q) and only P is ever read again, so
+    // the reference's last three ecp_Mont calls reduce to three doublings of P
+#pragma unroll 1
+    for (int i = 0; i < 3; i++) mont_double(PX, PZ);
 }
 
 }  // namespace c25519
