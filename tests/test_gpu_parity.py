@@ -165,7 +165,7 @@ def test_edge_public_keys_and_garbage(api, oracle):
     assert np.array_equal(api.ed25519_VerifySignature(gs, gp, gm), oracle.ed25519_verify(gs, gp, gm, threads=THREADS))
 
 
-@pytest.mark.parametrize("mlen", [0, 1, 3, 8, 47, 48, 49, 63, 64, 65, 111, 112, 113, 128, 300])
+@pytest.mark.parametrize("mlen", [0, 1, 3, 8, 47, 48, 49, 63, 64, 65, 111, 112, 113, 128, 300, 1021, 5000])
 def test_message_lengths(api, oracle, mlen):
     n = 130
     sk = synth.random_bytes((n, 32), 0x5000 + mlen)
