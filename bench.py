@@ -41,7 +41,7 @@ def measured_mad_peak():
 
 
 PASS_KERNELS = {
-    "x25519": ("k_x25519_ladder", "k_batch_invert<FinishX25519>"),
+    "x25519": ("k_x25519_fused",),
     "sign": ("k_ed25519_sign_mult", "k_batch_invert<FinishPack>", "k_ed25519_sign_finish"),
     "verify": ("k_ed25519_verify_init<c25519::QTableLimbs>", "k_ed25519_verify_check<c25519::QTableLimbs>",
                "k_batch_invert<FinishVerify>"),
@@ -252,10 +252,10 @@ def main():
                        "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_source": f"profiles/{traffic_src}: (2*FETCH_SIZE + WRITE_SIZE) KiB, ladder + inversion "
-                                           "launches; = 96 B/op API bytes + 32 B/op clamped-key write-back + the "
-                                           "projective intermediates staged for the batched inversion" if traffic_src else None,
-                         "kernel": " + ".join(PASS_KERNELS[wl]) + " (first one dominates)",
+                         "traffic_source": f"profiles/{traffic_src}: (2*FETCH_SIZE + WRITE_SIZE) KiB per pass; for X25519 = "
+                                           "96 B/op API bytes + the 32 B/op clamped-key write-back the reference's "
+                                           "IN/OUT sk requires" if traffic_src else None,
+                         "kernel": " + ".join(PASS_KERNELS[wl]),
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": BYTES_PER_OP[wl] * n,
                          "note": "VALU-integer bound path: HBM fraction is tiny by construction, see roofline_valu"},

@@ -104,6 +104,105 @@ __global__ void __launch_bounds__(X_BLOCK) k_x25519_ladder(ProjScratch scr, cons
     soa_store_fe(scr.z, n, i, PZ);
 }
 
+// Single-launch form: the four waves of a workgroup finish their ladders, park (PX, PZ) in LDS, and wave 0
+// inverts all the workgroup's Z's with ONE exponentiation (one element per wave and lane, Montgomery's trick, prefix products in
+// LDS); then every lane finishes its own element.  Same arithmetic as k_x25519_ladder + k_batch_invert with
+// K = 4, but the projective intermediates never leave the CU: HBM traffic is the API's 96 B/op plus the
+// clamped-key write-back.
+#ifndef C25519_XF_BLOCK
+#define C25519_XF_BLOCK 512
+#endif
+constexpr int XF_BLOCK = C25519_XF_BLOCK;     // waves per workgroup = elements per inverting lane
+constexpr int XF_K = XF_BLOCK / 64;
+
+C25519_DEV void lds_put_fe(u32* buf, int stride, int idx, const fe& f)
+{
+#pragma unroll
+    for (int w = 0; w < 10; w++) buf[w * stride + idx] = f.v[w];
+}
+C25519_DEV void lds_get_fe(fe& f, const u32* buf, int stride, int idx)
+{
+#pragma unroll
+    for (int w = 0; w < 10; w++) f.v[w] = buf[w * stride + idx];
+}
+
+template <bool BASE9>
+__global__ void __launch_bounds__(XF_BLOCK, 4) k_x25519_fused(void* out, const void* pk, void* sk, size_t n)
+{
+    __shared__ u32 zbuf[10 * XF_BLOCK];      // PZ, later 1/PZ
+    __shared__ u32 xbuf[10 * XF_BLOCK];      // PX
+    __shared__ u32 pbuf[(XF_K - 1) * 10 * 64];   // prefix products of the inverting wave
+    const int tid = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * XF_BLOCK + tid;
+    const bool active = i < n;
+    {
+        fe PX, PZ;
+        if (active) {
+            u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8];
+            if (!BASE9) load32(u, pk, i);
+            load32(k, sk, i);
+            clamp_words(k);
+            store32(sk, i, k);                   // the reference clamps in the caller's buffer
+            x25519_ladder_xz<BASE9>(PX, PZ, u, k);
+        } else {
+            fe_set_u32(PX, 0);
+            fe_set_u32(PZ, 1);
+        }
+        lds_put_fe(zbuf, XF_BLOCK, tid, PZ);
+        lds_put_fe(xbuf, XF_BLOCK, tid, PX);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        fe acc, z, one, zero;
+        fe_set_u32(one, 1);
+        fe_set_u32(zero, 0);
+        u32 zero_mask = 0;
+#pragma unroll 1
+        for (int t = 0; t < XF_K; t++) {
+            lds_get_fe(z, zbuf, XF_BLOCK, tid + 64 * t);
+            u32 w[8], nz = 0;
+            fe_to_words(w, z);
+#pragma unroll
+            for (int q = 0; q < 8; q++) nz |= w[q];
+            const u32 is_zero = nz ? 0u : 0xffffffffu;
+            zero_mask |= (is_zero & 1u) << t;
+            fe_select(z, is_zero, one, z);
+            if (t == 0) acc = z; else fe_mul(acc, acc, z);
+            if (t < XF_K - 1) lds_put_fe(pbuf + t * 640, 64, tid, acc);
+        }
+        fe inv;
+        fe_invert(inv, acc);
+#pragma unroll 1
+        for (int t = XF_K - 1; t >= 0; t--) {
+            fe zi;
+            if (t > 0) {
+                fe p;
+                lds_get_fe(p, pbuf + (t - 1) * 640, 64, tid);
+                fe_mul(zi, inv, p);
+                lds_get_fe(z, zbuf, XF_BLOCK, tid + 64 * t);
+                const u32 was_zero = ((zero_mask >> t) & 1u) ? 0xffffffffu : 0u;
+                fe_select(z, was_zero, one, z);
+                fe_mul(inv, inv, z);
+                fe_select(zi, was_zero, zero, zi);
+            } else {
+                const u32 was_zero = (zero_mask & 1u) ? 0xffffffffu : 0u;
+                fe_select(zi, was_zero, zero, inv);
+            }
+            lds_put_fe(zbuf, XF_BLOCK, tid + 64 * t, zi);
+        }
+    }
+    __syncthreads();
+    if (active) {
+        fe x, zi;
+        u32 w[8];
+        lds_get_fe(x, xbuf, XF_BLOCK, tid);
+        lds_get_fe(zi, zbuf, XF_BLOCK, tid);
+        fe_mul(x, x, zi);
+        fe_to_words(w, x);
+        store32(out, i, w);                      // written last: `out` may alias `pk`
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 8-fold base table, generated on the device at first use
 // ------------------------------------------------------------------------------------------------
@@ -685,6 +784,13 @@ int c25519_amd_set_device(int device)
 
 static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t stream)
 {
+    static const bool split = getenv("C25519_AMD_X25519_SPLIT") != nullptr;   // A/B knob: two-launch form
+    if (!split) {
+        if (pk) k_x25519_fused<false><<<grid_for(n, XF_BLOCK), XF_BLOCK, 0, stream>>>(out, pk, sk, n);
+        else    k_x25519_fused<true><<<grid_for(n, XF_BLOCK), XF_BLOCK, 0, stream>>>(out, pk, sk, n);
+        C25519_TRY(hipGetLastError());
+        return 0;
+    }
     void* w = nullptr;
     C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
