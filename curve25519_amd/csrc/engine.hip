@@ -210,9 +210,11 @@ __global__ void __launch_bounds__(XF_BLOCK, 4) k_x25519_fused(void* out, const v
 // reference's source/base_folding8.h, derived from B by doubling/adding (the recipe of
 // test/curve25519_selftest.c:498-551).  Written twice: limb-major limbs for LDS staging and 96-byte
 // canonical rows for inspection.
-__global__ void __launch_bounds__(256) k_gen_base_table(u32* tbl_limbs /*[30][256]*/, u32* tbl_bytes /*[256][24]*/)
+// Threads 256..511 produce the companion table T'[j] = 2^16 * T[j] used by the 15-doubling walk (ge_base_mult).
+__global__ void __launch_bounds__(512) k_gen_base_table(u32* tbl_limbs /*[2][30][256]*/, u32* tbl_bytes /*[256][24]*/)
 {
-    const u32 k = threadIdx.x;
+    const u32 k = threadIdx.x & 255u;
+    const bool shifted = threadIdx.x >= 256;
     ge_pa B;
     B.ypx = fe_const(K_BY); B.ymx = fe_const(K_BY);
     {
@@ -227,10 +229,9 @@ __global__ void __launch_bounds__(256) k_gen_base_table(u32* tbl_limbs /*[30][25
 #pragma unroll 1
     for (int i = 7; i >= 0; i--) {            // Horner over the 8 index bits, 32 doublings apart
         if ((k >> i) & 1) ge_add_pa(S, B);
-        if (i) {
+        const int dbl = i ? 32 : (shifted ? 16 : 0);
 #pragma unroll 1
-            for (int j = 0; j < 32; j++) ge_double(S);
-        }
+        for (int j = 0; j < dbl; j++) ge_double(S);
     }
     fe zi, x, y, t;
     fe_invert(zi, S.Z);
@@ -241,6 +242,7 @@ __global__ void __launch_bounds__(256) k_gen_base_table(u32* tbl_limbs /*[30][25
     fe_sub(row[1], y, x);
     fe_mul(t, x, y);
     fe_mul(row[2], t, fe_const(K_2D));
+    u32* limbs = tbl_limbs + (shifted ? PA_WORDS * 256 : 0);
 #pragma unroll
     for (int f = 0; f < 3; f++) {
         u32 w[8];
@@ -248,9 +250,11 @@ __global__ void __launch_bounds__(256) k_gen_base_table(u32* tbl_limbs /*[30][25
         fe c;
         fe_from_words(c, w);                  // canonical value back in limb form
 #pragma unroll
-        for (int l = 0; l < 10; l++) tbl_limbs[(10 * f + l) * 256 + k] = c.v[l];
+        for (int l = 0; l < 10; l++) limbs[(10 * f + l) * 256 + k] = c.v[l];
+        if (!shifted) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) tbl_bytes[k * 24 + 8 * f + j] = w[j];
+            for (int j = 0; j < 8; j++) tbl_bytes[k * 24 + 8 * f + j] = w[j];
+        }
     }
 }
 
@@ -286,8 +290,8 @@ C25519_DEV void store_proj(const ProjScratch& scr, size_t n, size_t i, const ge_
 __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_keypair_mult(ProjScratch scr, void* priv, const void* sk,
                                                                        size_t n, const u32* __restrict__ g_tbl)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
-    lds_stage_base_table(lds_tbl, g_tbl);
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[2 * PA_WORDS * 256];
+    lds_stage_base_table(lds_tbl, g_tbl, 2);
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 seed[8], a[8];
@@ -305,8 +309,8 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_keypair_mult(ProjScratc
 __global__ void __launch_bounds__(ED_BLOCK, 2) k_x25519_public_fast_mult(ProjScratch scr, void* sk, size_t n,
                                                                           const u32* __restrict__ g_tbl)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
-    lds_stage_base_table(lds_tbl, g_tbl);
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[2 * PA_WORDS * 256];
+    lds_stage_base_table(lds_tbl, g_tbl, 2);
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 k[8];
@@ -328,8 +332,8 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_mult(ProjScratch s
                                                                     const void* priv, Msgs msgs, size_t n,
                                                                     const u32* __restrict__ g_tbl)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
-    lds_stage_base_table(lds_tbl, g_tbl);
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[2 * PA_WORDS * 256];
+    lds_stage_base_table(lds_tbl, g_tbl, 2);
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 seed[8], a[8], r[8];
@@ -346,7 +350,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_mult(ProjScratch s
     soa_store8(a_out, n, i, a);
     soa_store8(r_out, n, i, r);
     ge_ext S;
-    ge_base_mult(S, r, lds_tbl);              // consumes r
+    ge_base_mult(S, r, lds_tbl);
     store_proj(scr, n, i, S);
 }
 
@@ -605,16 +609,16 @@ constexpr int MAX_DEVICES = 64;
 struct DeviceTables {
     std::once_flag once;
     int rc = 0;
-    u32* limbs = nullptr;     // [30][256]
+    u32* limbs = nullptr;     // [2][30][256]: T then 2^16 * T
     u32* bytes = nullptr;     // [256][24]
 };
 DeviceTables g_tables[MAX_DEVICES];
 
 int init_tables(DeviceTables& t)
 {
-    C25519_TRY(hipMalloc(&t.limbs, PA_WORDS * 256 * sizeof(u32)));
+    C25519_TRY(hipMalloc(&t.limbs, 2 * PA_WORDS * 256 * sizeof(u32)));
     C25519_TRY(hipMalloc(&t.bytes, 256 * 24 * sizeof(u32)));
-    k_gen_base_table<<<1, 256, 0, nullptr>>>(t.limbs, t.bytes);
+    k_gen_base_table<<<1, 512, 0, nullptr>>>(t.limbs, t.bytes);
     C25519_TRY(hipGetLastError());
     C25519_TRY(hipStreamSynchronize(nullptr));
     return 0;

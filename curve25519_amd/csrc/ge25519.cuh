@@ -169,25 +169,44 @@ C25519_DEV void lds_load_pa(ge_pa& q, const u32* tbl, u32 row)
     }
 }
 
-// cooperative copy of the device-resident limb table into this workgroup's LDS
-C25519_DEV void lds_stage_base_table(u32* lds_tbl, const u32* __restrict__ g_tbl)
+// cooperative copy of `tables` consecutive 256-row limb tables (device resident) into this workgroup's LDS
+C25519_DEV void lds_stage_base_table(u32* lds_tbl, const u32* __restrict__ g_tbl, int tables = 1)
 {
     const uint4* src = reinterpret_cast<const uint4*>(g_tbl);
     uint4* dst = reinterpret_cast<uint4*>(lds_tbl);
-    for (int i = threadIdx.x; i < PA_WORDS * 256 / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < tables * PA_WORDS * 256 / 4; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
 }
 
-// S = k * B by the 8-fold walk: S = T[c0]; S = 2S + T[cn], n = 1..31.   k (8 words) is consumed.
-C25519_DEV void ge_base_mult(ge_ext& S, u32 (&k)[8], const u32* lds_tbl)
+// 8-fold column n of scalar k (not consumed): bit j = bit (31 - n) of word j
+C25519_DEV u32 fold8_at(const u32 (&k)[8], int n)
 {
+    u32 idx = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) idx |= ((k[j] >> (31 - n)) & 1u) << j;
+    return idx;
+}
+
+// S = k * B.  The reference's walk (edp_BasePointMult, ed25519_sign.c:215-244) is S = T[c0]; S = 2S + T[cn],
+// n = 1..31 over one 8-fold table.  With a second table T'[j] = 2^16 * T[j] next to it the same sum
+//     sum_n 2^(31-n) T[c_n]  =  sum_{m=0..15} 2^(15-m) ( T'[c_m] + T[c_(m+16)] )
+// needs 15 doublings and 31 additions instead of 31 doublings and 31 additions -- same point, hence the same
+// canonical bytes after the inversion.  lds_tbl holds T (rows 0..255) then T' (rows 256..511), limb-major each.
+C25519_DEV void ge_base_mult(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl)
+{
+    const u32* t_lo = lds_tbl;
+    const u32* t_hi = lds_tbl + PA_WORDS * 256;
     ge_pa q;
-    lds_load_pa(q, lds_tbl, fold8_next(k));
+    lds_load_pa(q, t_hi, fold8_at(k, 0));
     ge_from_pa(S, q);
+    lds_load_pa(q, t_lo, fold8_at(k, 16));
+    ge_add_pa<false>(S, q);
 #pragma unroll 1
-    for (int n = 1; n < 32; n++) {
+    for (int m = 1; m < 16; m++) {
         ge_double(S);
-        lds_load_pa(q, lds_tbl, fold8_next(k));
+        lds_load_pa(q, t_hi, fold8_at(k, m));
+        ge_add_pa<true>(S, q);                 // T feeds the addition that follows
+        lds_load_pa(q, t_lo, fold8_at(k, m + 16));
         ge_add_pa<false>(S, q);                // next comes a doubling or the affine conversion: T unused
     }
 }
