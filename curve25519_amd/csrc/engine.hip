@@ -3,12 +3,13 @@
 // device.  Entry points are declared in include/curve25519_amd.h, include/curve25519_dh.h and
 // include/ed25519_signature.h (each cites the reference prototype it replaces).
 //
-// Every operation is two or three launches on the caller's stream:
-//   1. a "mult" kernel does the scalar multiplication and leaves the PROJECTIVE result in scratch,
-//   2. k_batch_invert turns projective into the canonical output bytes, sharing one field inversion
-//      (the reference's ecp_Inverse, 254 S + 11 M) between K elements per lane with Montgomery's trick --
-//      the reference pays one inversion per call (curve25519_dh.c:148, ed25519_sign.c:265),
-//   3. (sign only) a finish kernel hashes enc(R) || pk || m and computes S.
+// The reference pays one field inversion (ecp_Inverse, 254 S + 11 M) per call (curve25519_dh.c:148,
+// ed25519_sign.c:265); here it is shared between several elements with Montgomery's trick:
+//   * X25519 is ONE launch (k_x25519_fused): the workgroup's waves park their projective results in LDS and
+//     one wave inverts them all;
+//   * Ed25519 operations are two or three launches on the caller's stream: a "mult" kernel leaves the
+//     projective point in scratch, k_batch_invert (K elements per lane) writes the canonical bytes, and sign
+//     adds a finish kernel that hashes enc(R) || pk || m and computes S.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared engine.hip -o libcurve25519_amd.so
 #include "capi_common.hpp"
@@ -595,6 +596,36 @@ __global__ void __launch_bounds__(INV_BLOCK) k_batch_invert(const u32* Z, u32* p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// field-level self-test hook (the counterpart of the reference's ECP_SELF_TEST unit checks,
+// test/curve25519_selftest.c:640-741): out[i] = canonical( op(a[i], b[i]) ) on 32-byte little-endian values
+// taken mod p.  op: 0 a*b, 1 a^2, 2 a+b, 3 a-b, 4 1/a, 5 a^((p-5)/8), 6 a (canonicalise only),
+// 7 (a-b)*(a+b) with unreduced operands (exercises the beta-3 x beta-2 corner of the bound contract).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_fe_selftest(void* out, const void* a, const void* b, size_t n, int op)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    u32 aw[8], bw[8], ow[8];
+    load32(aw, a, i);
+    load32(bw, b, i);
+    fe x, y, r, t;
+    fe_from_words(x, aw);
+    fe_from_words(y, bw);
+    switch (op) {
+    case 0: fe_mul(r, x, y); break;
+    case 1: fe_sqr(r, x); break;
+    case 2: fe_add(r, x, y); break;
+    case 3: fe_sub(r, x, y); break;
+    case 4: fe_invert(r, x); break;
+    case 5: fe_pow2523(r, x); break;
+    case 6: r = x; break;
+    default: fe_sub(r, x, y); fe_add(t, x, y); fe_mul(r, r, t); break;
+    }
+    fe_to_words(ow, r);
+    store32(out, i, ow);
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -959,6 +990,24 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
     return tl_work.release(stream);
+}
+
+int c25519_amd_fe_selftest(unsigned char* out, const unsigned char* a, const unsigned char* b, size_t n, int op)
+{
+    if (!out || !a || !b) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    Staging& s = staging();
+    C25519_RC(s.ensure_stream());
+    C25519_RC(s.reserve(0, 32 * n));
+    C25519_RC(s.reserve(1, 32 * n));
+    C25519_RC(s.reserve(2, 32 * n));
+    C25519_TRY(hipMemcpyAsync(s.ptr[0], a, 32 * n, hipMemcpyHostToDevice, s.stream));
+    C25519_TRY(hipMemcpyAsync(s.ptr[1], b, 32 * n, hipMemcpyHostToDevice, s.stream));
+    k_fe_selftest<<<grid_for(n, 64), 64, 0, s.stream>>>(s.ptr[2], s.ptr[0], s.ptr[1], n, op);
+    C25519_TRY(hipGetLastError());
+    C25519_TRY(hipMemcpyAsync(out, s.ptr[2], 32 * n, hipMemcpyDeviceToHost, s.stream));
+    C25519_TRY(hipStreamSynchronize(s.stream));
+    return 0;
 }
 
 int c25519_amd_base_table(unsigned char* out)

@@ -55,6 +55,34 @@ def test_base_table_equals_reference_table(api, oracle):
     assert np.array_equal(tbl, oracle.base_table())
 
 
+def test_field_layer_against_big_integers(api):
+    """L0 unit test (the reference's ECP_SELF_TEST field identities, test/curve25519_selftest.c:640-741): the
+    device field ops on adversarial 256-bit patterns against Python big-integer arithmetic mod p."""
+    from curve25519_amd import _lib
+    L = _lib.load()
+    P = 2**255 - 19
+    special = [0, 1, 2, 19, 38, P - 1, P, P + 1, 2 * P - 1, 2 * P, 2 * P + 1, 2**255 - 1, 2**255, 2**256 - 1,
+               2**256 - 38, 2**256 - 39, 2**26 - 1, 2**26, 2**51 - 1, 2**51, (1 << 255) - 20,
+               int("3ffffff" * 9 + "ff", 16) % 2**256, int("aa" * 32, 16), int("55" * 32, 16),
+               121665, 121666, pow(2, (P - 1) // 4, P)]
+    rnd = synth.random_bytes((400, 32), 0xFE01)
+    vals = special + [int.from_bytes(r.tobytes(), "little") for r in rnd]
+    pairs = [(a, b) for a in special for b in special] + list(zip(vals, reversed(vals)))
+    a = np.stack([np.frombuffer(x.to_bytes(32, "little"), np.uint8) for x, _ in pairs])
+    b = np.stack([np.frombuffer(y.to_bytes(32, "little"), np.uint8) for _, y in pairs])
+    n = len(pairs)
+    expect = {0: lambda x, y: x * y, 1: lambda x, y: x * x, 2: lambda x, y: x + y, 3: lambda x, y: x - y,
+              4: lambda x, y: pow(x, P - 2, P), 5: lambda x, y: pow(x, (P - 5) // 8, P), 6: lambda x, y: x,
+              7: lambda x, y: (x - y) * (x + y)}
+    for op, f in expect.items():
+        out = np.empty((n, 32), np.uint8)
+        rc = L.c25519_amd_fe_selftest(out.ctypes.data, a.ctypes.data, b.ctypes.data, n, op)
+        assert rc == 0
+        for i, (x, y) in enumerate(pairs):
+            got = int.from_bytes(out[i].tobytes(), "little")
+            assert got == f(x, y) % P, (op, hex(x), hex(y), hex(got))
+
+
 # ---- known-answer vectors -------------------------------------------------------------------------------
 
 def test_x25519_kats(api):
