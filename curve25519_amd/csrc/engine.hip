@@ -211,11 +211,15 @@ __global__ void __launch_bounds__(XF_BLOCK, 4) k_x25519_fused(void* out, const v
 // reference's source/base_folding8.h, derived from B by doubling/adding (the recipe of
 // test/curve25519_selftest.c:498-551).  Written twice: limb-major limbs for LDS staging and 96-byte
 // canonical rows for inspection.
-// Threads 256..511 produce the companion table T'[j] = 2^16 * T[j] used by the 15-doubling walk (ge_base_mult).
-__global__ void __launch_bounds__(512) k_gen_base_table(u32* tbl_limbs /*[2][30][256]*/, u32* tbl_bytes /*[256][24]*/)
+// Thread group t (256 threads each) produces T_t = 2^((BASE_NT-1-t)*BASE_STEP) * T for the short walk of
+// ge_base_mult; the last group is the reference table T itself.
+__global__ void __launch_bounds__(256 * BASE_NT) k_gen_base_table(u32* tbl_limbs /*[BASE_NT][30][256]*/,
+                                                                  u32* tbl_bytes /*[256][24]*/)
 {
     const u32 k = threadIdx.x & 255u;
-    const bool shifted = threadIdx.x >= 256;
+    const int group = threadIdx.x >> 8;
+    const int extra = (BASE_NT - 1 - group) * BASE_STEP;   // trailing doublings
+    const bool shifted = extra != 0;
     ge_pa B;
     B.ypx = fe_const(K_BY); B.ymx = fe_const(K_BY);
     {
@@ -230,7 +234,7 @@ __global__ void __launch_bounds__(512) k_gen_base_table(u32* tbl_limbs /*[2][30]
 #pragma unroll 1
     for (int i = 7; i >= 0; i--) {            // Horner over the 8 index bits, 32 doublings apart
         if ((k >> i) & 1) ge_add_pa(S, B);
-        const int dbl = i ? 32 : (shifted ? 16 : 0);
+        const int dbl = i ? 32 : extra;
 #pragma unroll 1
         for (int j = 0; j < dbl; j++) ge_double(S);
     }
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(512) k_gen_base_table(u32* tbl_limbs /*[2][30]
     fe_sub(row[1], y, x);
     fe_mul(t, x, y);
     fe_mul(row[2], t, fe_const(K_2D));
-    u32* limbs = tbl_limbs + (shifted ? PA_WORDS * 256 : 0);
+    u32* limbs = tbl_limbs + group * BASE_TBL_WORDS;
 #pragma unroll
     for (int f = 0; f < 3; f++) {
         u32 w[8];
@@ -263,6 +267,7 @@ __global__ void __launch_bounds__(512) k_gen_base_table(u32* tbl_limbs /*[2][30]
 // Ed25519
 // ------------------------------------------------------------------------------------------------
 constexpr int ED_BLOCK = 256;
+constexpr int BM_BLOCK = 1024;            // fixed-base kernels: one 120 KiB table set per 16 waves (4 per SIMD)
 
 // a = clamp(first half of SHA-512(seed)), optionally the second half as 4 big-endian stream words
 C25519_DEV void ed_expand_seed(u32 (&a)[8], u64 (&b_words)[4], const u32 (&seed)[8])
@@ -288,12 +293,12 @@ C25519_DEV void store_proj(const ProjScratch& scr, size_t n, size_t i, const ge_
 
 // ed25519_CreateKeyPair (ed25519_sign.c:344-367), first part: a = clamp(H(sk)), S = a*B projective;
 // privKey[0..31] = sk.  The public key bytes are written by k_batch_invert<FinishKeypair>.
-__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_keypair_mult(ProjScratch scr, void* priv, const void* sk,
+__global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_keypair_mult(ProjScratch scr, void* priv, const void* sk,
                                                                        size_t n, const u32* __restrict__ g_tbl)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds_tbl[2 * PA_WORDS * 256];
-    lds_stage_base_table(lds_tbl, g_tbl, 2);
-    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
+    lds_stage_base_table(lds_tbl, g_tbl, BASE_NT);
+    const size_t i = (size_t)blockIdx.x * BM_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 seed[8], a[8];
     u64 b_words[4];
@@ -307,12 +312,12 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_keypair_mult(ProjScratc
 
 // curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189): S = clamp(sk)*B, u = (Z+Y)/(Z-Y);
 // numerator and denominator go to scratch in the X25519 slots.
-__global__ void __launch_bounds__(ED_BLOCK, 2) k_x25519_public_fast_mult(ProjScratch scr, void* sk, size_t n,
+__global__ void __launch_bounds__(BM_BLOCK, 4) k_x25519_public_fast_mult(ProjScratch scr, void* sk, size_t n,
                                                                           const u32* __restrict__ g_tbl)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds_tbl[2 * PA_WORDS * 256];
-    lds_stage_base_table(lds_tbl, g_tbl, 2);
-    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
+    lds_stage_base_table(lds_tbl, g_tbl, BASE_NT);
+    const size_t i = (size_t)blockIdx.x * BM_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 k[8];
     load32(k, sk, i);
@@ -329,13 +334,13 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_x25519_public_fast_mult(ProjScr
 
 // ed25519_SignMessage (ed25519_sign.c:372-419), blinding == NULL, first part (:385-400):
 // a = clamp(H(sk)[0..31]), r = H(H(sk)[32..63] || m) mod L (canonical), R = r*B projective.
-__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_mult(ProjScratch scr, u32* a_out, u32* r_out,
+__global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_sign_mult(ProjScratch scr, u32* a_out, u32* r_out,
                                                                     const void* priv, Msgs msgs, size_t n,
                                                                     const u32* __restrict__ g_tbl)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds_tbl[2 * PA_WORDS * 256];
-    lds_stage_base_table(lds_tbl, g_tbl, 2);
-    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
+    lds_stage_base_table(lds_tbl, g_tbl, BASE_NT);
+    const size_t i = (size_t)blockIdx.x * BM_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 seed[8], a[8], r[8];
     {
@@ -431,7 +436,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check(ProjScratc
                                                                        size_t stride_words)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
-    lds_stage_base_table(lds_tbl, g_tbl);
+    lds_stage_base_table(lds_tbl, g_tbl + (BASE_NT - 1) * BASE_TBL_WORDS);
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 pkw[8];
@@ -474,7 +479,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(Pro
 #pragma unroll
         for (int l = 0; l < 10; l++) lds_q[(10 * f + l) * 16 + row] = v.v[l];
     }
-    lds_stage_base_table(lds_tbl, g_tbl);                  // ends with __syncthreads()
+    lds_stage_base_table(lds_tbl, g_tbl + (BASE_NT - 1) * BASE_TBL_WORDS);   // ends with __syncthreads()
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 pkw[8];
@@ -640,16 +645,16 @@ constexpr int MAX_DEVICES = 64;
 struct DeviceTables {
     std::once_flag once;
     int rc = 0;
-    u32* limbs = nullptr;     // [2][30][256]: T then 2^16 * T
+    u32* limbs = nullptr;     // [BASE_NT][30][256]: 2^24 T, 2^16 T, 2^8 T, T
     u32* bytes = nullptr;     // [256][24]
 };
 DeviceTables g_tables[MAX_DEVICES];
 
 int init_tables(DeviceTables& t)
 {
-    C25519_TRY(hipMalloc(&t.limbs, 2 * PA_WORDS * 256 * sizeof(u32)));
+    C25519_TRY(hipMalloc(&t.limbs, BASE_NT * BASE_TBL_WORDS * sizeof(u32)));
     C25519_TRY(hipMalloc(&t.bytes, 256 * 24 * sizeof(u32)));
-    k_gen_base_table<<<1, 512, 0, nullptr>>>(t.limbs, t.bytes);
+    k_gen_base_table<<<1, 256 * BASE_NT, 0, nullptr>>>(t.limbs, t.bytes);
     C25519_TRY(hipGetLastError());
     C25519_TRY(hipStreamSynchronize(nullptr));
     return 0;
@@ -863,7 +868,7 @@ int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void
     void* w = nullptr;
     C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
-    k_x25519_public_fast_mult<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(scr, sk, n, tbl);
+    k_x25519_public_fast_mult<<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, sk, n, tbl);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishX25519{ scr.a, pk, n }, stream));
     return tl_work.release(stream);
@@ -880,7 +885,7 @@ int ed25519_CreateKeyPair_dev(void* pub, void* priv, const void* sk, size_t n, v
     void* w = nullptr;
     C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
-    k_ed25519_keypair_mult<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(scr, priv, sk, n, tbl);
+    k_ed25519_keypair_mult<<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, priv, sk, n, tbl);
     C25519_TRY(hipGetLastError());
     // pub[e] and priv[e][32..63] <- enc(A)
     C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, pub, n, 1, 0, priv, 2, 1 }, stream));
@@ -899,7 +904,7 @@ static int sign_dev(void* sig, const void* priv, Msgs msgs, size_t n, hipStream_
     const ProjScratch scr = carve_proj((u32*)w, n);
     u32* a_buf = (u32*)w + proj_words(n);
     u32* r_buf = a_buf + sc_words;
-    k_ed25519_sign_mult<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl);
+    k_ed25519_sign_mult<<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, sig, n, 2, 0, nullptr, 0, 0 }, stream));   // sig[e][0..31] = enc(R)
     k_ed25519_sign_finish<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(sig, priv, msgs, n, a_buf, r_buf);

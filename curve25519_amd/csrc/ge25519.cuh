@@ -188,26 +188,35 @@ C25519_DEV u32 fold8_at(const u32 (&k)[8], int n)
 }
 
 // S = k * B.  The reference's walk (edp_BasePointMult, ed25519_sign.c:215-244) is S = T[c0]; S = 2S + T[cn],
-// n = 1..31 over one 8-fold table.  With a second table T'[j] = 2^16 * T[j] next to it the same sum
-//     sum_n 2^(31-n) T[c_n]  =  sum_{m=0..15} 2^(15-m) ( T'[c_m] + T[c_(m+16)] )
-// needs 15 doublings and 31 additions instead of 31 doublings and 31 additions -- same point, hence the same
-// canonical bytes after the inversion.  lds_tbl holds T (rows 0..255) then T' (rows 256..511), limb-major each.
+// n = 1..31 over one 8-fold table.  With BASE_NT tables T_t = 2^((BASE_NT-1-t)*step) * T, step = 32/BASE_NT,
+// the same sum regroups as
+//     sum_n 2^(31-n) T[c_n]  =  sum_{m<step} 2^(step-1-m) * sum_{t<BASE_NT} T_t[c_(t*step+m)]
+// i.e. step-1 doublings and 31 additions instead of 31 doublings and 31 additions -- the same point, hence the
+// same canonical bytes after the inversion.  BASE_NT = 4: 7 doublings, 120 KiB of LDS (MI355X has 160 KiB per
+// CU), shared by a 512-thread workgroup.  lds_tbl holds T_0 .. T_(BASE_NT-1) (= T itself), limb-major each.
+constexpr int BASE_NT = 4;
+constexpr int BASE_STEP = 32 / BASE_NT;
+constexpr int BASE_TBL_WORDS = PA_WORDS * 256;
+
 C25519_DEV void ge_base_mult(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl)
 {
-    const u32* t_lo = lds_tbl;
-    const u32* t_hi = lds_tbl + PA_WORDS * 256;
     ge_pa q;
-    lds_load_pa(q, t_hi, fold8_at(k, 0));
+    lds_load_pa(q, lds_tbl, fold8_at(k, 0));
     ge_from_pa(S, q);
-    lds_load_pa(q, t_lo, fold8_at(k, 16));
-    ge_add_pa<false>(S, q);
+#pragma unroll
+    for (int t = 1; t < BASE_NT; t++) {
+        lds_load_pa(q, lds_tbl + t * BASE_TBL_WORDS, fold8_at(k, t * BASE_STEP));
+        if (t < BASE_NT - 1) ge_add_pa<true>(S, q); else ge_add_pa<false>(S, q);
+    }
 #pragma unroll 1
-    for (int m = 1; m < 16; m++) {
+    for (int m = 1; m < BASE_STEP; m++) {
         ge_double(S);
-        lds_load_pa(q, t_hi, fold8_at(k, m));
-        ge_add_pa<true>(S, q);                 // T feeds the addition that follows
-        lds_load_pa(q, t_lo, fold8_at(k, m + 16));
-        ge_add_pa<false>(S, q);                // next comes a doubling or the affine conversion: T unused
+#pragma unroll
+        for (int t = 0; t < BASE_NT; t++) {
+            lds_load_pa(q, lds_tbl + t * BASE_TBL_WORDS, fold8_at(k, t * BASE_STEP + m));
+            // T feeds a following addition; a doubling or the affine conversion never reads it
+            if (t < BASE_NT - 1) ge_add_pa<true>(S, q); else ge_add_pa<false>(S, q);
+        }
     }
 }
 
