@@ -246,7 +246,8 @@ def main():
             "metric": METRIC_NAME[wl],
             "value": round(value, 1), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 limbs, u64 accumulators (v_mad_u64_u32)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u64", "dtype_note": "26/25-bit limbs in u32 registers, 32x32+64->64-bit "
+            "integer MACs (v_mad_u64_u32), bit-exact results", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAME[wl],
                        "batch_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
