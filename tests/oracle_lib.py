@@ -125,6 +125,20 @@ class Oracle:
         self.lib.orc_fold4(_p(out), _p(kk))
         return out
 
+    def verify_init_table(self, pk):
+        """ed25519_Verify_Init for n keys: the 16-row 4-fold tables as Python ints mod p, shape [n][16][4]."""
+        pk = np.ascontiguousarray(pk, dtype=np.uint8)
+        self.lib.orc_ed25519_verify_init.argtypes = [C.c_void_p, u8p]
+        P = 2**255 - 19
+        out = []
+        for i in range(pk.shape[0]):
+            ctx = np.zeros(32 + 16 * 4 * 32, np.uint8)
+            self.lib.orc_ed25519_verify_init(ctx.ctypes.data, _p(pk[i]))
+            assert ctx[:32].tobytes() == pk[i].tobytes()
+            rows = ctx[32:].reshape(16, 4, 32)
+            out.append([[int.from_bytes(rows[r, f].tobytes(), "little") % P for f in range(4)] for r in range(16)])
+        return out
+
     def base_table(self):
         """(256, 3, 32) uint8: canonical (Y+X, Y-X, 2dT) rows of the 8-fold table."""
         ptr = self.lib.orc_base_folding8()
@@ -194,6 +208,20 @@ class Reference:
         for i in range(n):
             ok[i] = self.lib.ed25519_VerifySignature(_p(sig[i]), _p(pk[i]), _p(msg[i]), msg.shape[1])
         return ok
+
+    def verify_init_table(self, pk):
+        """ed25519_Verify_Init(NULL, pk): the reference's own q_table, values reduced mod p, [n][16][4]."""
+        pk = np.ascontiguousarray(pk, dtype=np.uint8)
+        self.lib.ed25519_Verify_Init.argtypes = [C.c_void_p, u8p]
+        self.lib.ed25519_Verify_Init.restype = C.c_void_p
+        P = 2**255 - 19
+        out = []
+        for i in range(pk.shape[0]):
+            ctx = np.zeros(2080, np.uint8)
+            assert self.lib.ed25519_Verify_Init(ctx.ctypes.data, _p(pk[i])) == ctx.ctypes.data
+            rows = ctx[32:].reshape(16, 4, 32)
+            out.append([[int.from_bytes(rows[r, f].tobytes(), "little") % P for f in range(4)] for r in range(16)])
+        return out
 
     # threaded drivers (C thread pool in liborc25519.so calling into the dlopen'ed reference)
     def _drv(self):

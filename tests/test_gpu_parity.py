@@ -316,9 +316,22 @@ def test_two_phase_verification(api, oracle):
         assert np.array_equal(got, exp)
         assert np.array_equal(got, api.ed25519_VerifySignature(sig, np.repeat(pub[k:k + 1], n, axis=0), msg))
         assert 0 < got.sum() < n
-    # garbage keys: Verify_Init never rejects, verdicts still match the oracle
+    # garbage keys: Verify_Init never rejects.  For off-curve inputs the table VALUES depend on the order of the
+    # doublings / additions, so comparing them with the oracle pins the device's operation sequence.
     gp = synth.random_bytes((4, 32), 0x7200)
     gctx = api.ed25519_Verify_Init(gp)
+    P = 2**255 - 19
+    for keys, ctxs in ((gp, gctx), (pub, ctx)):
+        exp = oracle.verify_init_table(keys)
+        for k in range(keys.shape[0]):
+            rows = ctxs[k, 32:].reshape(16, 4, 32)
+            got = [[int.from_bytes(rows[r, f].tobytes(), "little") for f in range(4)] for r in range(16)]
+            assert all(v < P for row in got for v in row)        # device rows are canonical
+            for r in range(16):                                  # equal as PROJECTIVE points (Y+X : Y-X : 2dT : 2Z)
+                g, e = got[r], exp[k][r]
+                for f in range(3):
+                    assert (g[f] * e[3] - e[f] * g[3]) % P == 0, (k, r, f)
+                assert (g[3] == 0) == (e[3] == 0)
     gs, gm = synth.random_bytes((256, 64), 0x7201), synth.random_bytes((256, 16), 0x7202)
     for k in range(4):
         assert np.array_equal(api.ed25519_Verify_Check(gctx[k], gs, gm),

@@ -131,3 +131,7 @@ def test_against_reference_build(oracle, reference):
     msg = synth.random_bytes((n, 32), 13)
     assert np.array_equal(oracle.ed25519_verify(gs, gp, msg), reference.ed25519_verify(gs, gp, msg))
     assert np.array_equal(oracle.base_table(), reference.base_table())
+    # Verify_Init tables, valid keys and unvalidated garbage (off-curve "points": the values then depend on the
+    # exact order of doublings / additions, so this pins the operation sequence, not just the group element)
+    keys = np.concatenate([pub[:6], gp[:10], np.zeros((1, 32), np.uint8), np.full((1, 32), 0xff, np.uint8)])
+    assert oracle.verify_init_table(keys) == reference.verify_init_table(keys)
