@@ -33,6 +33,7 @@ SIGNATURES = {
     "ed25519_Verify_Check_dev": [_vp, _vp, _vp, _vp, _sz, _sz, _vp],
     "c25519_amd_base_table": [_vp],
     "c25519_amd_fe_selftest": [_vp, _vp, _vp, _sz, C.c_int],
+    "c25519_amd_verify_point_dev": [_vp, _vp, _vp, _vp, _sz, _sz, _vp],
     "c25519_amd_device_count": [],
     "c25519_amd_set_device": [C.c_int],
     "c25519_amd_version": [],

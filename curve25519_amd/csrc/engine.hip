@@ -949,6 +949,30 @@ static int verify_dev(void* verdict, const void* sig, const void* pk, Msgs msgs,
     return tl_work.release(stream);
 }
 
+// test hook: enc(T) instead of the verdict (what Verify_Check compares with enc(R)); device pointers
+int c25519_amd_verify_point_dev(void* out, const void* sig, const void* pk, const void* msg, size_t msg_size, size_t n,
+                                void* stream_)
+{
+    if (!out || !sig || !pk || (!msg && msg_size)) return bad_arg("null pointer");
+    if (int rc = check_dev_args(n, { out, sig, pk })) return rc;
+    if (n == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    const u32* tbl = nullptr;
+    C25519_RC(base_tables(&tbl, nullptr));
+    void* w = nullptr;
+    C25519_RC(tl_work.acquire(&w, ed25519_VerifySignature_scratch_bytes(n), stream));
+    const ProjScratch scr = carve_proj((u32*)w, n);
+    u32* tables = (u32*)w + proj_words(n);
+    const Msgs msgs{ (const uint8_t*)msg, msg_size, nullptr };
+    k_ed25519_verify_init<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(pk, n, tables, QTABLE_LIMB_WORDS);
+    C25519_TRY(hipGetLastError());
+    k_ed25519_verify_check<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
+        scr, sig, pk, msgs, n, tbl, tables, QTABLE_LIMB_WORDS);
+    C25519_TRY(hipGetLastError());
+    C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, out, n, 1, 0, nullptr, 0, 0 }, stream));
+    return tl_work.release(stream);
+}
+
 int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, const void* msg, size_t msg_size,
                                 size_t n, void* stream)
 {

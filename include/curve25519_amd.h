@@ -100,6 +100,11 @@ int ed25519_Verify_Check_dev(void *verdict, const void *ctx, const void *sig, co
  * the content of reference source/base_folding8.h) to `out` */
 int c25519_amd_base_table(unsigned char *out /* 24576 bytes */);
 
+/* test hook: the encoded point T = s*B + h*(-A) that ed25519_Verify_Check compares with enc(R)
+ * (reference source/ed25519_verify.c:309-310) instead of the verdict; device pointers, out is n x 32 bytes */
+int c25519_amd_verify_point_dev(void *out, const void *sig, const void *pk, const void *msg, size_t msg_size,
+                                size_t n, void *stream);
+
 /* device field arithmetic on n pairs of 32-byte little-endian values taken mod p = 2^255-19 (host pointers):
  * out[i] = canonical(op(a[i], b[i])), op 0 mul, 1 square, 2 add, 3 sub, 4 inverse, 5 a^((p-5)/8),
  * 6 canonicalise, 7 (a-b)*(a+b).  The unit-test hook for the L0 layer (the reference's ECP_SELF_TEST checks). */

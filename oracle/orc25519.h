@@ -78,6 +78,7 @@ void orc_ed25519_sign(uint8_t sig[64], const uint8_t priv[64], const uint8_t *ms
 void orc_ed25519_verify_init(orc_sigv_ctx *ctx, const uint8_t pk[32]);         /* ed25519_Verify_Init */
 int  orc_ed25519_verify_check(const orc_sigv_ctx *ctx, const uint8_t sig[64], const uint8_t *msg, size_t n);
 int  orc_ed25519_verify(const uint8_t sig[64], const uint8_t pk[32], const uint8_t *msg, size_t n);
+void orc_ed25519_verify_point(uint8_t out[32], const uint8_t sig[64], const uint8_t pk[32], const uint8_t *msg, size_t n);
 
 /* ---- batch drivers (contiguous fixed-stride arrays; nthreads<=1 runs inline) ---- */
 void orc_x25519_shared_batch(uint8_t *shared, const uint8_t *pk, uint8_t *sk, size_t n, int nthreads);

@@ -367,6 +367,27 @@ int orc_ed25519_verify_check(const orc_sigv_ctx *ctx, const uint8_t sig[64], con
     return memcmp(md, sig, 32) == 0 ? 1 : 0;
 }
 
+/* test hook: the packed point T = s*B + h*(-A) that ed25519_Verify_Check compares with enc(R) (:309-310) */
+void orc_ed25519_verify_point(uint8_t out[32], const uint8_t sig[64], const uint8_t pk[32], const uint8_t *msg, size_t n)
+{
+    orc_sigv_ctx ctx;
+    orc_sha512_ctx H;
+    uint8_t md[64];
+    uint64_t h[4], s[4];
+    orc_fe x, y;
+    orc_ed25519_verify_init(&ctx, pk);
+    orc_sha512_init(&H);
+    orc_sha512_update(&H, sig, 32);
+    orc_sha512_update(&H, ctx.pk, 32);
+    orc_sha512_update(&H, msg, n);
+    orc_sha512_final(&H, md);
+    orc_sc_from_digest(h, md);
+    orc_sc_mod(h);
+    orc_fe_frombytes(s, sig + 32);
+    poly_mult(x, y, s, h, ctx.q);
+    pack_point(out, y, x[0]);
+}
+
 int orc_ed25519_verify(const uint8_t sig[64], const uint8_t pk[32], const uint8_t *msg, size_t n)  /* :163-173 */
 {
     orc_sigv_ctx ctx;

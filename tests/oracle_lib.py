@@ -125,6 +125,18 @@ class Oracle:
         self.lib.orc_fold4(_p(out), _p(kk))
         return out
 
+    def ed25519_verify_point(self, sig, pk, msg):
+        """enc(T), T = s*B + h*(-A): what Verify_Check compares with enc(R).  uint8[n, 32]."""
+        sig = np.ascontiguousarray(sig, dtype=np.uint8)
+        pk = np.ascontiguousarray(pk, dtype=np.uint8)
+        n = sig.shape[0]
+        msg = _rows(np.ascontiguousarray(msg, dtype=np.uint8), n)
+        self.lib.orc_ed25519_verify_point.argtypes = [u8p, u8p, u8p, u8p, C.c_size_t]
+        out = np.empty((n, 32), np.uint8)
+        for i in range(n):
+            self.lib.orc_ed25519_verify_point(_p(out[i]), _p(sig[i]), _p(pk[i]), _p(msg[i]), msg.shape[1])
+        return out
+
     def verify_init_table(self, pk):
         """ed25519_Verify_Init for n keys: the 16-row 4-fold tables as Python ints mod p, shape [n][16][4]."""
         pk = np.ascontiguousarray(pk, dtype=np.uint8)

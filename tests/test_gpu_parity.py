@@ -372,6 +372,35 @@ def test_concurrent_host_threads(api, oracle):
         assert ok.all()
 
 
+def test_verify_point_on_garbage_keys(api, oracle):
+    """The point T = s*B + h*(-A) itself (not just the 0/1 verdict) for unvalidated garbage keys and signatures:
+    off the curve its value depends on the exact order of the walk's doublings and additions, so equality with
+    the oracle pins the device's Verify_Check sequence, which a verdict of 0 == 0 cannot."""
+    import ctypes as C
+    import torch
+    from curve25519_amd import _lib
+    L = _lib.load()
+    n = 1500
+    sig = synth.random_bytes((n, 64), 0xA501)
+    pk = synth.random_bytes((n, 32), 0xA502)
+    msg = synth.random_bytes((n, 24), 0xA503)
+    good_sk = synth.random_bytes((100, 32), 0xA504)                 # a valid stretch in the middle
+    gpub, gpriv = oracle.ed25519_keypair(good_sk)
+    pk[200:300] = gpub
+    sig[200:300] = oracle.ed25519_sign(gpriv, msg[200:300])
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(a).to(dev) for a in (sig, pk, msg)]
+    out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    _lib.check(L.c25519_amd_verify_point_dev(C.c_void_p(out.data_ptr()), C.c_void_p(d[0].data_ptr()),
+                                             C.c_void_p(d[1].data_ptr()), C.c_void_p(d[2].data_ptr()), 24, n, None),
+               "c25519_amd_verify_point_dev")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    exp = oracle.ed25519_verify_point(sig, pk, msg)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(got[200:300], sig[200:300, :32])            # valid signatures: T encodes to R
+
+
 def test_single_call_reference_api(api):
     """The eleven reference entry points, one element at a time (a device batch of one each)."""
     from curve25519_amd import _lib
