@@ -191,8 +191,9 @@ def main():
         if wl == "sign":
             width, odtype = 64, torch.uint8
             launch = lambda dst: eng.api.ed25519_SignMessage_dev(dst, priv, msg)             # noqa: E731
-        else:
-            sig = eng.ed25519_sign(priv, msg)
+        else:                                       # config 4: valid signatures + the seeded 1/64 corrupted ones
+            sig_np, msg_np, _bad = synth.corrupt_for_verify(eng.ed25519_sign(priv, msg).cpu().numpy(), msg.cpu().numpy())
+            sig, msg = torch.from_numpy(sig_np).to(dev), torch.from_numpy(msg_np).to(dev)
             width, odtype = 1, torch.int32
             launch = lambda dst: eng.api.ed25519_VerifySignature_dev(dst, sig, pub, msg)     # noqa: E731
     out = torch.empty((n, width), dtype=odtype, device=dev)
@@ -285,14 +286,19 @@ def main():
                 best = min(best, a.elapsed_time(b))
             return best
 
+        # config 4's verify set: the signatures above with the seeded 1/64 sprinkle of corrupted entries
+        vsig_np, vmsg_np, bad = synth.corrupt_for_verify(sig.cpu().numpy(), msg_np)
+        vsig, vmsg = torch.from_numpy(vsig_np).to(dev), torch.from_numpy(vmsg_np).to(dev)
         ok = torch.empty((n, 1), dtype=torch.int32, device=dev)
         for name, fn in (("sign", lambda: eng.api.ed25519_SignMessage_dev(sig, priv, msg)),
-                         ("verify", lambda: eng.api.ed25519_VerifySignature_dev(ok, sig, pub, msg)),
+                         ("verify", lambda: eng.api.ed25519_VerifySignature_dev(ok, vsig, pub, vmsg)),
                          ("keypair", lambda: eng.api.ed25519_CreateKeyPair_dev(pub, priv, esk))):
             ms = timeit(fn)
             extra[f"ed25519_{name}_per_s"] = round(n / (ms * 1e-3), 1)
             extra[f"ed25519_{name}_kernel_ms"] = round(ms, 4)
-        extra["ed25519_verify_all_valid"] = bool(int(ok.sum().item()) == n)
+        rejected = (ok.view(-1) == 0).cpu().numpy()
+        extra["ed25519_verify_rejected"] = int(rejected.sum())
+        extra["ed25519_verify_rejects_exactly_the_corrupted"] = bool((rejected == bad).all())
         # two-phase verification, ONE key for the whole batch (Verify_Init once, 2^20 Verify_Check)
         from curve25519_amd import _lib
         import ctypes as C
@@ -309,6 +315,7 @@ def main():
         ms = timeit(chk)
         extra["ed25519_verify_check_one_key_per_s"] = round(n / (ms * 1e-3), 1)
         extra["ed25519_verify_check_one_key_all_valid"] = bool(int(ok.sum().item()) == n)
+        del vsig, vmsg
         result["extra"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu:
