@@ -804,7 +804,7 @@ int pipelined(size_t n, Submit submit, Collect collect)
 
 extern "C" {
 
-const char* c25519_amd_version(void) { return "curve25519_amd 0.2 (gfx950)"; }
+const char* c25519_amd_version(void) { return "curve25519_amd 0.3 (gfx950)"; }
 const char* c25519_amd_last_error(void) { return c25519_host::last_error().c_str(); }
 
 int c25519_amd_device_count(void)
