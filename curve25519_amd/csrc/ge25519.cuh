@@ -203,20 +203,19 @@ C25519_DEV void ge_base_mult(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl)
     ge_pa q;
     lds_load_pa(q, lds_tbl, fold8_at(k, 0));
     ge_from_pa(S, q);
-#pragma unroll
-    for (int t = 1; t < BASE_NT; t++) {
-        lds_load_pa(q, lds_tbl + t * BASE_TBL_WORDS, fold8_at(k, t * BASE_STEP));
-        if (t < BASE_NT - 1) ge_add_pa<true>(S, q); else ge_add_pa<false>(S, q);
-    }
 #pragma unroll 1
-    for (int m = 1; m < BASE_STEP; m++) {
-        ge_double(S);
-#pragma unroll
-        for (int t = 0; t < BASE_NT; t++) {
+    for (int m = 0; m < BASE_STEP; m++) {
+        if (m) ge_double(S);
+        // tables 0 .. BASE_NT-2 (the first one is the starting point when m == 0): T feeds the next addition.
+        // Kept as a loop: one copy of the addition in the instruction cache instead of BASE_NT.
+#pragma unroll 1
+        for (int t = m ? 0 : 1; t < BASE_NT - 1; t++) {
             lds_load_pa(q, lds_tbl + t * BASE_TBL_WORDS, fold8_at(k, t * BASE_STEP + m));
-            // T feeds a following addition; a doubling or the affine conversion never reads it
-            if (t < BASE_NT - 1) ge_add_pa<true>(S, q); else ge_add_pa<false>(S, q);
+            ge_add_pa<true>(S, q);
         }
+        // last table: a doubling or the affine conversion follows, neither reads T
+        lds_load_pa(q, lds_tbl + (BASE_NT - 1) * BASE_TBL_WORDS, fold8_at(k, (BASE_NT - 1) * BASE_STEP + m));
+        ge_add_pa<false>(S, q);
     }
 }
 
