@@ -10,6 +10,7 @@ import hashlib
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -452,3 +453,27 @@ def test_reference_harness_runs_on_this_library():
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "Signature Verified Successfully" in p.stdout
     assert "FAILED" not in p.stdout
+
+
+def test_two_launch_x25519_path_still_matches():
+    """The two-launch form of X25519 (ladder kernel + k_batch_invert, kept behind C25519_AMD_X25519_SPLIT=1 as an
+    A/B knob) must give the same bytes as the default single-launch kernel and the fixtures."""
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+        "from curve25519_amd import api\n"
+        "g = np.load(%r)\n"
+        "s, c = api.curve25519_dh_CreateSharedKey(g['x_pk'], g['x_sk'])\n"
+        "assert np.array_equal(s, g['x_shared']) and np.array_equal(c, g['x_sk_clamped'])\n"
+        "P = 2**255 - 19\n"
+        "pk = np.stack([np.frombuffer(int(v).to_bytes(32, 'little'), np.uint8) for v in (0, 1, P - 1, P, P + 1, 9, 2**256 - 1)])\n"
+        "sk = np.full((7, 32), 0x42, np.uint8)\n"
+        "print(json.dumps([r.tobytes().hex() for r in api.curve25519_dh_CreateSharedKey(pk, sk)[0]]))\n"
+    ) % (ROOT, os.path.join(GOLD, "random_1024.npz"))
+    outs = []
+    for env in ({}, {"C25519_AMD_X25519_SPLIT": "1"}):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                           env={**os.environ, **env})
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    assert outs[0][0] == "00" * 32 and outs[0][3] == "00" * 32          # low-order inputs -> zero bytes in both forms
