@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload x25519|mixed|sign|verify]
 
-A "step" is one pass of the hot path over one batch: 2^20 curve25519_dh_CreateSharedKey operations per
-GPU (BASELINE.json configs[1]), inputs already resident in HBM, followed for N > 1 by the single RCCL
-gather of the 32-byte results to rank 0 that north_star names.  Weak scaling: every rank owns its own
-2^20 keypairs.  Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      -- the X25519 kernel against the HBM roof the contract asks for (frac << 1 by
-                   construction: the path is VALU-integer bound) ...
-  roofline_valu -- ... and against the measured v_mad_u64_u32 issue peak (profiles/r01_valu_rates.json),
-                   which is the roof that actually binds;
-  cpu_baseline  -- the reference's portable-C path (oracle/_ref) or the oracle port timed on this host;
-  extra         -- Ed25519 sign / verify throughput at the same batch size (configs[2], configs[3]).
+With --gpus N > 1 and no WORLD_SIZE in the environment the script re-launches itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU); launched by torchrun it reads
+RANK / LOCAL_RANK / WORLD_SIZE as usual.  Rank 0 prints ONE JSON line.
+
+A "step" is one pass of the hot path over one batch of 2^20 operations per GPU, inputs already resident in HBM,
+followed for N > 1 by the single RCCL gather of the result rows to rank 0 that north_star names (asynchronous,
+overlapped with the next batch; every gather of the timed steps completes inside the timed region).  Weak scaling:
+every rank owns its own 2^20 operations.
+
+BASELINE.json's metric is a pair -- "X25519 shared-key ops/sec + Ed25519 verifies/sec" -- so the default run times
+BOTH, each with its own W warm-up + K timed steps bracketed by barrier + synchronize (mean of steps, max over ranks):
+  value / ms_per_step / roofline  -- X25519 curve25519_dh_CreateSharedKey (configs[1]); `value` is this number;
+  verify                          -- ed25519_VerifySignature on configs[3]'s set (valid + 1/64 corrupted);
+  sign                            -- ed25519_SignMessage (configs[2]);
+roofline.verify / roofline.sign repeat the two side results inside the contract's roofline object.
+--workload mixed times BASELINE.json configs[4]: X25519 + sign + verify by contiguous thirds of each GPU's 2^20,
+one gather per output type.  Each roofline carries the HBM fraction the contract asks for (tiny by construction)
+and `valu`: algorithmic 32x32 MACs against the measured v_mad_u64_u32 issue peak, the roof that binds.
+cpu_baseline: the reference's portable-C path (oracle/_ref) or the oracle port on this host's cores.
 """
 import argparse
+import glob
 import json
 import os
+import socket
 import sys
 import time
 
@@ -29,17 +39,6 @@ BYTES_PER_OP = {"x25519": 96, "sign": 160, "verify": 132}
 MACS_PER_OP = {"x25519": 184104, "sign": 52992, "verify": 245664}  # SURVEY.md 8(a), 32x32 MACs at 72/mul
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md
 
-
-def measured_mad_peak():
-    """lane-MAC/s of v_mad_u64_u32 measured by tools/ubench/valu_rates on MI355X (committed summary)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_valu_rates.json")) as f:
-            rates = json.load(f)["rates"]
-        return max(v for k, v in rates.items() if k.startswith("v_mad_u64_u32"))
-    except Exception:
-        return None
-
-
 PASS_KERNELS = {
     "x25519": ("k_x25519_fused",),
     "sign": ("k_ed25519_sign_mult", "k_batch_invert<FinishPack>", "k_ed25519_sign_finish"),
@@ -47,26 +46,45 @@ PASS_KERNELS = {
                "k_batch_invert<FinishVerify>"),
 }
 METRIC_NAME = {
-    "x25519": "X25519 shared-key ops/sec (batch=2^20 per GPU, variable-base Montgomery ladder)",
+    "x25519": "X25519 shared-key ops/sec (batch=2^20 per GPU, variable-base Montgomery ladder) [+ Ed25519 verifies/sec "
+              "in `verify`]",
     "sign": "Ed25519 signs/sec (batch=2^20 per GPU, 8-fold fixed-base walk, 32-byte messages)",
     "verify": "Ed25519 verifies/sec (batch=2^20 per GPU, distinct keys, 4-fold + 8-fold double-scalar walk)",
+    "mixed": "mixed X25519 + Ed25519 sign + verify ops/sec (contiguous thirds of 2^20 per GPU)",
 }
 WORKLOAD_NAME = {
     "x25519": "BASELINE.json configs[1]: batch 2^20 X25519 curve25519_dh_CreateSharedKey per GPU, one keypair per "
               "lane, inputs resident in HBM",
     "sign": "BASELINE.json configs[2]: batch 2^20 ed25519_SignMessage per GPU, base table staged in LDS",
-    "verify": "BASELINE.json configs[3]: batch 2^20 ed25519_VerifySignature per GPU (Verify_Init + Verify_Check)",
+    "verify": "BASELINE.json configs[3]: batch 2^20 ed25519_VerifySignature per GPU (Verify_Init + Verify_Check), "
+              "config-3 signatures with the seeded 1/64 corrupted entries",
+    "mixed": "BASELINE.json configs[4]: 2^20 per GPU (2^23 over 8) as contiguous thirds X25519 / sign / verify, "
+             "one RCCL gather per output type",
 }
 
 
-def measured_traffic(kernels):
-    """HBM bytes per X25519 pass (ladder launch + batched-inversion launch) from the committed rocprofv3 PMC
-    passes (separate --pmc runs of this same bench, summarised by tools/rocpd_summary.py):
-    WRITE_SIZE + 2 x FETCH_SIZE, both in KiB -- the x2 is the gfx950 FETCH_SIZE correction of
-    MI355X_MICROARCH.md (HBM section)."""
+def latest_profile(pattern):
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return hits[-1] if hits else None
+
+
+def measured_mad_peak():
+    """lane-MAC/s of v_mad_u64_u32 measured by tools/ubench/valu_rates on MI355X (committed summary)."""
     try:
-        import glob
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))[-1]
+        path = latest_profile("r[0-9][0-9]_valu_rates.json")
+        with open(path) as f:
+            rates = json.load(f)["rates"]
+        return max(v for k, v in rates.items() if k.startswith("v_mad_u64_u32")), os.path.basename(path)
+    except Exception:
+        return None, None
+
+
+def measured_traffic(kernels):
+    """HBM bytes per pass from the committed rocprofv3 PMC passes (separate --pmc runs of this same bench,
+    summarised by tools/rocpd_summary.py): WRITE_SIZE + 2 x FETCH_SIZE, both in KiB -- the x2 is the gfx950
+    FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section)."""
+    try:
+        path = latest_profile("r[0-9][0-9]_pmc.json")
         with open(path) as f:
             d = json.load(f)
         def rec(name):                      # rocprof prints template kernels as "void name<...>"
@@ -78,11 +96,33 @@ def measured_traffic(kernels):
         return None, None
 
 
-def cpu_baseline(n_per_thread=8192):
+def roofline_for(wl, n, kernel_ms):
+    """The contract's roofline object for one pass of workload `wl` (n operations, mean kernel time kernel_ms)."""
+    kernel_s = kernel_ms * 1e-3
+    achieved_gbs = BYTES_PER_OP[wl] * n / kernel_s / 1e9
+    peak_mac, peak_src = measured_mad_peak()
+    traffic, traffic_src = measured_traffic(PASS_KERNELS[wl])
+    achieved_mac = MACS_PER_OP[wl] * n / kernel_s
+    return {
+        "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
+        "traffic_source": f"profiles/{traffic_src}: (2*FETCH_SIZE + WRITE_SIZE) KiB per pass" if traffic_src else None,
+        "kernel": " + ".join(PASS_KERNELS[wl]), "kernel_ms": round(kernel_ms, 4),
+        "algorithmic_bytes_per_launch": BYTES_PER_OP[wl] * n,
+        "note": "VALU-integer bound path: the HBM fraction is tiny by construction, `valu` is the roof that binds",
+        "valu": {"bound": "valu v_mad_u64_u32 issue", "achieved": round(achieved_mac / 1e12, 4),
+                 "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s",
+                 "frac": round(achieved_mac / peak_mac, 4) if peak_mac else None,
+                 "algorithmic_macs_per_op": MACS_PER_OP[wl],
+                 "peak_source": f"profiles/{peak_src}" if peak_src else None},
+    }
+
+
+def cpu_baseline(quick=False):
     """Time curve25519_dh_CreateSharedKey (plus Ed25519 sign / verify) on the host cores: the real reference
     (portable-C build, oracle/_ref) when its prebuilt library travelled with the repo, else the oracle port.
     A C thread pool fans one contiguous slice per core; bounded sample, same input distribution as the GPU
-    workload."""
+    workload.  quick: the shorter sample used beside multi-GPU runs."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle, Reference
     from curve25519_amd import synth
@@ -95,9 +135,11 @@ def cpu_baseline(n_per_thread=8192):
             cores = max(1, min(cores, int(round(quota))))
     except Exception:
         pass
-    n = n_per_thread * cores
+    budget_s = 3.0 if quick else 10.0
+    n = (2048 if quick else 8192) * cores
+    n_ed = cores * (1024 if quick else 4096)               # sign / verify samples of a few hundred ms, not 30 ms
     sk, pk = synth.x25519_inputs(n)
-    esk, msg = synth.ed25519_inputs(cores * 256)
+    esk, msg = synth.ed25519_inputs(n_ed)
     orc = Oracle()
     pub, priv = orc.ed25519_keypair(esk, threads=cores)
     if Reference.available():
@@ -116,15 +158,16 @@ def cpu_baseline(n_per_thread=8192):
         out = fn()
         return count / (time.perf_counter() - t0), out
 
-    single, _ = rate(lambda: shared(pk[:4096], sk[:4096], 1), 4096)         # config 1: 4096 sequential calls
-    # all cores, in rounds of 1024 per thread, until the sample is used up or ~10 s have gone by
+    n1 = 1024 if quick else 4096
+    single, _ = rate(lambda: shared(pk[:n1], sk[:n1], 1), n1)              # config 1: sequential calls, one core
+    # all cores, in rounds of 1024 per thread, until the sample is used up or the time budget has gone by
     done, t0, chunk = 0, time.perf_counter(), 1024 * cores
-    while done < n and time.perf_counter() - t0 < 10.0:
+    while done < n and time.perf_counter() - t0 < budget_s:
         shared(pk[done:done + chunk], sk[done:done + chunk], cores)
         done += chunk
     multi, n = done / (time.perf_counter() - t0), done
-    sign_rate, sig = rate(lambda: sign(cores), cores * 256)
-    verify_rate, ok = rate(lambda: verify(sig, cores), cores * 256)
+    sign_rate, sig = rate(lambda: sign(cores), n_ed)
+    verify_rate, ok = rate(lambda: verify(sig, cores), n_ed)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -132,12 +175,34 @@ def cpu_baseline(n_per_thread=8192):
     except Exception:
         pass
     return {"value": round(multi, 1), "unit": "X25519 shared-key ops/s", "cores": cores, "kind": kind,
-            "sample": f"{n} curve25519_dh_CreateSharedKey calls over {cores} threads "
-                      f"(C thread pool, one contiguous slice each); seeded uniform sk/pk",
+            "sample": f"{n} curve25519_dh_CreateSharedKey calls over {cores} threads (C thread pool, one contiguous "
+                      f"slice each), seeded uniform sk/pk; {n_ed} signs and {n_ed} verifies the same way",
             "single_core_ops_per_s": round(single, 1), "ed25519_sign_per_s": round(sign_rate, 1),
             "ed25519_verify_per_s": round(verify_rate, 1), "ed25519_verify_all_valid": bool(ok.all()),
             "host_logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
             "cpu_model": model}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py ...`."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this machine exposes {have} GPU(s) to this process "
+                         "(the launcher is fine; the devices are missing)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def main():
@@ -146,25 +211,29 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH, help="operations per GPU per step (default 2^20)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the Ed25519 sign/verify side measurements")
+    ap.add_argument("--no-side", "--no-extra", action="store_true", dest="no_side",
+                    help="time the primary workload only (skip the verify / sign / keypair / one-key measurements)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
-    ap.add_argument("--workload", choices=("x25519", "sign", "verify"), default="x25519",
-                    help="x25519 = BASELINE.json configs[1] (the default and the driver's contract); sign / verify = "
-                         "configs[2] / configs[3], same batch size, for the side tables of DESIGN.md")
+    ap.add_argument("--workload", choices=("x25519", "sign", "verify", "mixed"), default="x25519",
+                    help="x25519 = BASELINE.json configs[1] (the default and the driver's contract; also times verify and "
+                         "sign); sign / verify = configs[2] / configs[3] alone; mixed = configs[4]")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="run the N>1 code path (process group + RCCL gather) with a world of one rank")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                              # does not return
+
     import torch
     import torch.distributed as dist
     from curve25519_amd import synth
-    from curve25519_amd.sharded import HipEngine, OverlappedGather
+    from curve25519_amd.sharded import HipEngine, OverlappedGather, mixed_thirds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -177,26 +246,8 @@ def main():
 
     n = args.batch
     eng = HipEngine(dev)
-    wl = args.workload
     seed_shift = 0x100 * rank if world > 1 else 0          # every rank owns its own 2^20 elements (weak scaling)
-    if wl == "x25519":
-        sk = torch.from_numpy(synth.random_bytes((n, 32), synth.SEED_X25519_SK + seed_shift)).to(dev)
-        pk = torch.from_numpy(synth.random_bytes((n, 32), synth.SEED_X25519_PK + seed_shift)).to(dev)
-        width, odtype = 32, torch.uint8
-        launch = lambda dst: eng.api.curve25519_dh_CreateSharedKey_dev(dst, pk, sk)          # noqa: E731
-    else:
-        esk = torch.from_numpy(synth.random_bytes((n, 32), synth.SEED_ED_SK + seed_shift)).to(dev)
-        msg = torch.from_numpy(synth.random_bytes((n, 32), synth.SEED_ED_MSG + seed_shift)).to(dev)
-        pub, priv = eng.ed25519_keypair(esk)
-        if wl == "sign":
-            width, odtype = 64, torch.uint8
-            launch = lambda dst: eng.api.ed25519_SignMessage_dev(dst, priv, msg)             # noqa: E731
-        else:                                       # config 4: valid signatures + the seeded 1/64 corrupted ones
-            sig_np, msg_np, _bad = synth.corrupt_for_verify(eng.ed25519_sign(priv, msg).cpu().numpy(), msg.cpu().numpy())
-            sig, msg = torch.from_numpy(sig_np).to(dev), torch.from_numpy(msg_np).to(dev)
-            width, odtype = 1, torch.int32
-            launch = lambda dst: eng.api.ed25519_VerifySignature_dev(dst, sig, pub, msg)     # noqa: E731
-    out = torch.empty((n, width), dtype=odtype, device=dev)
+    up = lambda a: torch.from_numpy(a).to(dev)             # noqa: E731
 
     def barrier():
         torch.cuda.synchronize()
@@ -204,129 +255,192 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    og = OverlappedGather(n, width, dev, root=0, dtype=odtype) if use_dist else None
+    # ---- resident inputs and one launch closure per pass --------------------------------------------------
+    def make_x25519(m, lo=0):
+        sk = up(synth.random_bytes((n, 32), synth.SEED_X25519_SK + seed_shift)[lo:lo + m])
+        pk = up(synth.random_bytes((n, 32), synth.SEED_X25519_PK + seed_shift)[lo:lo + m])
+        return {"wl": "x25519", "n": m, "width": 32, "dtype": torch.uint8,
+                "launch": lambda dst: eng.api.curve25519_dh_CreateSharedKey_dev(dst, pk, sk)}
 
-    def step(ev=None):
-        dst = og.next_buffer() if og else out
-        if ev:
-            ev[0].record()
-        launch(dst)
-        if ev:
-            ev[1].record()
-        if og:
-            og.submit()                  # async RCCL gather of this batch, overlapped with the next batch
+    ed_cache = {}
 
-    for _ in range(args.warmup):
-        step()
-    if og:
-        og.finish()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    if og:
-        og.finish()                      # every gather of the timed steps has completed inside the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+    def ed_material():
+        if not ed_cache:
+            esk = up(synth.random_bytes((n, 32), synth.SEED_ED_SK + seed_shift))
+            msg_np = synth.random_bytes((n, 32), synth.SEED_ED_MSG + seed_shift)
+            msg = up(msg_np)
+            pub, priv = eng.ed25519_keypair(esk)
+            sig = eng.ed25519_sign(priv, msg)
+            vsig_np, vmsg_np, bad = synth.corrupt_for_verify(sig.cpu().numpy(), msg_np)
+            ed_cache.update(esk=esk, msg=msg, pub=pub, priv=priv, sig=sig, vsig=up(vsig_np), vmsg=up(vmsg_np), bad=bad)
+        return ed_cache
+
+    def make_sign(m, lo=0):
+        e = ed_material()
+        priv, msg = e["priv"][lo:lo + m], e["msg"][lo:lo + m]
+        return {"wl": "sign", "n": m, "width": 64, "dtype": torch.uint8,
+                "launch": lambda dst: eng.api.ed25519_SignMessage_dev(dst, priv, msg)}
+
+    def make_verify(m, lo=0):
+        e = ed_material()
+        vsig, pub, vmsg = e["vsig"][lo:lo + m], e["pub"][lo:lo + m], e["vmsg"][lo:lo + m]
+        return {"wl": "verify", "n": m, "width": 1, "dtype": torch.int32, "bad": e["bad"][lo:lo + m],
+                "launch": lambda dst: eng.api.ed25519_VerifySignature_dev(dst, vsig, pub, vmsg)}
+
+    def run_timed(passes):
+        """W warm-up + K timed steps of the given passes (each step launches every pass once, then starts its
+        gathers).  Returns (elapsed_s max over ranks, [mean kernel ms per pass], last result buffers)."""
+        outs = [torch.empty((p["n"], p["width"]), dtype=p["dtype"], device=dev) for p in passes]
+        ogs = [OverlappedGather(p["n"], p["width"], dev, root=0, dtype=p["dtype"]) if use_dist else None for p in passes]
+
+        def step(evs=None):
+            for j, p in enumerate(passes):
+                dst = ogs[j].next_buffer() if ogs[j] else outs[j]
+                if evs:
+                    evs[j][0].record()
+                p["launch"](dst)
+                if evs:
+                    evs[j][1].record()
+                if ogs[j]:
+                    ogs[j].submit()          # async RCCL gather of this batch, overlapped with what follows
+                    outs[j] = dst
+
+        def finish():
+            for og in ogs:
+                if og:
+                    og.finish()
+
+        for _ in range(args.warmup):
+            step()
+        finish()
+        events = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in passes]
+                  for _ in range(args.steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(events[k])
+        finish()                             # every gather of the timed steps has completed inside the timed region
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kms = [sum(events[k][j][0].elapsed_time(events[k][j][1]) for k in range(args.steps)) / max(1, args.steps)
+               for j in range(len(passes))]
+        return elapsed, kms, outs
+
+    def summarize(p, elapsed, kernel_ms, out):
+        r = {"value": round(world * p["n"] * args.steps / elapsed, 1), "unit": "ops/s",
+             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "steps": args.steps, "warmup": args.warmup,
+             "n_gpus": world, "batch_per_gpu": p["n"], "workload": WORKLOAD_NAME[p["wl"]],
+             "roofline": roofline_for(p["wl"], p["n"], kernel_ms)}
+        if p["wl"] == "verify":
+            rejected = (out.view(-1) == 0).cpu().numpy()
+            r["rejected"] = int(rejected.sum())
+            r["rejects_exactly_the_corrupted"] = bool((rejected == p["bad"]).all())
+        return r
+
+    wl = args.workload
+    side = {}
+    if wl == "mixed":
+        (x0, x1), (s0, s1), (v0, v1) = mixed_thirds(n)
+        passes = [make_x25519(x1 - x0, x0), make_sign(s1 - s0, s0), make_verify(v1 - v0, v0)]
+        elapsed, kms, outs = run_timed(passes)
+        parts = [summarize(p, elapsed, k, o) for p, k, o in zip(passes, kms, outs)]
+        kernel_ms = sum(kms)
+        bytes_per_launch = sum(BYTES_PER_OP[p["wl"]] * p["n"] for p in passes)
+        macs = sum(MACS_PER_OP[p["wl"]] * p["n"] for p in passes)
+        peak_mac, peak_src = measured_mad_peak()
+        gbs = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 6), "traffic": None,
+                "kernel": "k_x25519_fused + sign pass + verify pass (see parts)", "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "valu": {"bound": "valu v_mad_u64_u32 issue", "achieved": round(macs / (kernel_ms * 1e-3) / 1e12, 4),
+                         "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s",
+                         "frac": round(macs / (kernel_ms * 1e-3) / peak_mac, 4) if peak_mac else None},
+                "parts": {p["wl"]: {"n": p["n"], "kernel_ms": round(k, 4)} for p, k in zip(passes, kms)}}
+        primary = {"value": round(world * n * args.steps / elapsed, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                   "roofline": roof}
+        side["verify_rejects_exactly_the_corrupted"] = parts[2]["rejects_exactly_the_corrupted"]
+    else:
+        make = {"x25519": make_x25519, "sign": make_sign, "verify": make_verify}[wl]
+        p = make(n)
+        elapsed, kms, outs = run_timed([p])
+        primary = summarize(p, elapsed, kms[0], outs[0])
+        if wl == "x25519" and not args.no_side:
+            # the second half of BASELINE.json's metric, and config 3, with the same protocol
+            for name, mk in (("verify", make_verify), ("sign", make_sign)):
+                q = mk(n)
+                e2, k2, o2 = run_timed([q])
+                side[name] = summarize(q, e2, k2[0], o2[0])
 
     result = None
     if rank == 0:
-        value = world * n * args.steps / elapsed
-        kernel_s = kernel_ms * 1e-3
-        achieved_gbs = BYTES_PER_OP[wl] * n / kernel_s / 1e9
-        peak_mac = measured_mad_peak()
-        traffic, traffic_src = measured_traffic(PASS_KERNELS[wl])
-        achieved_mac = MACS_PER_OP[wl] * n / kernel_s
+        roof = primary["roofline"]
+        for name in ("verify", "sign"):
+            if name in side and isinstance(side[name], dict):
+                s = side[name]
+                roof[name] = {"value": s["value"], "unit": "ops/s", "ms_per_step": s["ms_per_step"],
+                              "kernel_ms": s["roofline"]["kernel_ms"], "hbm_frac": s["roofline"]["frac"],
+                              "achieved_GBps": s["roofline"]["achieved"], "traffic": s["roofline"]["traffic"],
+                              "algorithmic_bytes_per_launch": s["roofline"]["algorithmic_bytes_per_launch"],
+                              "valu_frac": s["roofline"]["valu"]["frac"], "kernel": s["roofline"]["kernel"]}
         result = {
             "metric": METRIC_NAME[wl],
-            "value": round(value, 1), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "value": primary["value"], "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": primary["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "dtype_note": "26/25-bit limbs in u32 registers, 32x32+64->64-bit "
             "integer MACs (v_mad_u64_u32), bit-exact results", "data": "synthetic",
-            "config": {"workload": WORKLOAD_NAME[wl],
-                       "batch_per_gpu": n, "global_batch": n * world,
-                       "parallelism": f"shard{world}" + ("+rccl_gather" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_source": f"profiles/{traffic_src}: (2*FETCH_SIZE + WRITE_SIZE) KiB per pass; for X25519 = "
-                                           "96 B/op API bytes + the 32 B/op clamped-key write-back the reference's "
-                                           "IN/OUT sk requires" if traffic_src else None,
-                         "kernel": " + ".join(PASS_KERNELS[wl]),
-                         "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": BYTES_PER_OP[wl] * n,
-                         "note": "VALU-integer bound path: HBM fraction is tiny by construction, see roofline_valu"},
-            "roofline_valu": {"bound": "valu v_mad_u64_u32", "achieved": round(achieved_mac / 1e12, 4),
-                              "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s",
-                              "frac": round(achieved_mac / peak_mac, 4) if peak_mac else None,
-                              "algorithmic_macs_per_op": MACS_PER_OP[wl]},
+            "config": {"workload": WORKLOAD_NAME[wl], "batch_per_gpu": n, "global_batch": n * world,
+                       "parallelism": f"shard{world}" + ("+rccl_gather" if use_dist else "")},
+            "roofline": roof,
         }
+        result.update(side)
 
-    # ---- side measurements, outside the timed region (rank 0, single GPU only) ----
-    if rank == 0 and world == 1 and not args.no_extra and wl == "x25519":
+    # ---- extra measurements outside the protocol above (rank 0, single GPU, default workload only) ----
+    if rank == 0 and world == 1 and not args.no_side and wl == "x25519":
         extra = {}
-        esk_np, msg_np = synth.ed25519_inputs(n)
-        esk = torch.from_numpy(esk_np).to(dev)
-        msg = torch.from_numpy(msg_np).to(dev)
-        pub, priv = eng.ed25519_keypair(esk)
-        sig = eng.ed25519_sign(priv, msg)
-        torch.cuda.synchronize()
+        e = ed_material()
 
-        def timeit(fn, reps=3):
+        def timeit(fn, reps=5):
             fn(); torch.cuda.synchronize()
-            best = 1e30
+            tot = 0.0
             for _ in range(reps):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(); fn(); b.record(); torch.cuda.synchronize()
-                best = min(best, a.elapsed_time(b))
-            return best
+                tot += a.elapsed_time(b)
+            return tot / reps
 
-        # config 4's verify set: the signatures above with the seeded 1/64 sprinkle of corrupted entries
-        vsig_np, vmsg_np, bad = synth.corrupt_for_verify(sig.cpu().numpy(), msg_np)
-        vsig, vmsg = torch.from_numpy(vsig_np).to(dev), torch.from_numpy(vmsg_np).to(dev)
-        ok = torch.empty((n, 1), dtype=torch.int32, device=dev)
-        for name, fn in (("sign", lambda: eng.api.ed25519_SignMessage_dev(sig, priv, msg)),
-                         ("verify", lambda: eng.api.ed25519_VerifySignature_dev(ok, vsig, pub, vmsg)),
-                         ("keypair", lambda: eng.api.ed25519_CreateKeyPair_dev(pub, priv, esk))):
-            ms = timeit(fn)
-            extra[f"ed25519_{name}_per_s"] = round(n / (ms * 1e-3), 1)
-            extra[f"ed25519_{name}_kernel_ms"] = round(ms, 4)
-        rejected = (ok.view(-1) == 0).cpu().numpy()
-        extra["ed25519_verify_rejected"] = int(rejected.sum())
-        extra["ed25519_verify_rejects_exactly_the_corrupted"] = bool((rejected == bad).all())
+        pub2, priv2 = torch.empty_like(e["pub"]), torch.empty_like(e["priv"])
+        ms = timeit(lambda: eng.api.ed25519_CreateKeyPair_dev(pub2, priv2, e["esk"]))
+        extra["ed25519_keypair_per_s"] = round(n / (ms * 1e-3), 1)
+        extra["ed25519_keypair_kernel_ms"] = round(ms, 4)
         # two-phase verification, ONE key for the whole batch (Verify_Init once, 2^20 Verify_Check)
         from curve25519_amd import _lib
         import ctypes as C
         L = _lib.load()
-        one_priv = priv[:1].repeat(n, 1).contiguous()
-        one_sig = eng.ed25519_sign(one_priv, msg)
+        ok = torch.empty((n, 1), dtype=torch.int32, device=dev)
+        one_priv = e["priv"][:1].repeat(n, 1).contiguous()
+        one_sig = eng.ed25519_sign(one_priv, e["msg"])
         ctx = torch.empty((1, 2080), dtype=torch.uint8, device=dev)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(L.ed25519_Verify_Init_dev(C.c_void_p(ctx.data_ptr()), C.c_void_p(pub[:1].contiguous().data_ptr()), 1, st),
+        _lib.check(L.ed25519_Verify_Init_dev(C.c_void_p(ctx.data_ptr()), C.c_void_p(e["pub"][:1].contiguous().data_ptr()), 1, st),
                    "ed25519_Verify_Init_dev")
         chk = lambda: _lib.check(L.ed25519_Verify_Check_dev(C.c_void_p(ok.data_ptr()), C.c_void_p(ctx.data_ptr()),  # noqa: E731
-                                                            C.c_void_p(one_sig.data_ptr()), C.c_void_p(msg.data_ptr()),
+                                                            C.c_void_p(one_sig.data_ptr()), C.c_void_p(e["msg"].data_ptr()),
                                                             32, n, st), "ed25519_Verify_Check_dev")
         ms = timeit(chk)
         extra["ed25519_verify_check_one_key_per_s"] = round(n / (ms * 1e-3), 1)
         extra["ed25519_verify_check_one_key_all_valid"] = bool(int(ok.sum().item()) == n)
-        del vsig, vmsg
         result["extra"] = extra
 
-    if rank == 0 and world == 1 and not args.no_cpu:
-        result["cpu_baseline"] = cpu_baseline()
-    elif rank == 0:
-        result["cpu_baseline"] = None
-
-    if rank == 0:
-        print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        result["cpu_baseline"] = None if args.no_cpu else cpu_baseline(quick=world > 1)
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

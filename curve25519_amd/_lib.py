@@ -31,7 +31,15 @@ SIGNATURES = {
     "ed25519_Verify_Init_dev": [_vp, _vp, _sz, _vp],
     "ed25519_Verify_Check_batch": [_vp, _vp, _vp, _vp, _sz, _sz],
     "ed25519_Verify_Check_dev": [_vp, _vp, _vp, _vp, _sz, _sz, _vp],
+    "ed25519_Blinding_Init_dev": [_vp, _vp, _sz, _vp],
+    "ed25519_CreateKeyPair_blinded_batch": [_vp, _vp, _vp, _vp, _sz],
+    "ed25519_CreateKeyPair_blinded_dev": [_vp, _vp, _vp, _vp, _sz, _vp],
+    "ed25519_SignMessage_blinded_batch": [_vp, _vp, _vp, _vp, _sz, _sz],
+    "ed25519_SignMessage_blinded_dev": [_vp, _vp, _vp, _vp, _sz, _sz, _vp],
     "c25519_amd_base_table": [_vp],
+    "c25519_amd_sc_selftest": [_vp, _vp, _vp, _sz, C.c_int],
+    "c25519_amd_fold_selftest": [_vp, _vp, _sz],
+    "c25519_amd_thread_release": [],
     "c25519_amd_fe_selftest": [_vp, _vp, _vp, _sz, C.c_int],
     "c25519_amd_verify_point_dev": [_vp, _vp, _vp, _vp, _sz, _sz, _vp],
     "c25519_amd_device_count": [],
@@ -64,6 +72,7 @@ _RESTYPE = {
     "ed25519_SignMessage": None,
     "ed25519_Blinding_Finish": None,
     "ed25519_Verify_Finish": None,
+    "c25519_amd_thread_release": None,
 }
 
 _lib = None

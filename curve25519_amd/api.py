@@ -164,51 +164,75 @@ def device_count() -> int:
 
 
 # ---- device-memory (torch CUDA tensors) interface --------------------------------------------------
-# torch is only plumbing here: it owns the HBM buffers and the stream.
+# torch is only plumbing here: it owns the HBM buffers and the stream.  Every tensor is checked (CUDA, dtype,
+# contiguous, shape, same row count, same device) before its data_ptr() is handed to the C ABI, and the call runs
+# with that device current -- a short or strided tensor is a ValueError here, not an out-of-bounds access there.
 
-def _dev(t, width, name):
+def _check(t, width, name, n=None, dtype=None, device=None):
     import torch
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
-        raise ValueError(f"{name} must be a contiguous uint8 CUDA tensor")
-    if t.dim() != 2 or t.shape[1] != width:
+    dtype = torch.uint8 if dtype is None else dtype
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous {dtype} CUDA tensor")
+    if t.dim() != 2 or (width is not None and t.shape[1] != width):
         raise ValueError(f"{name} must have shape (n, {width}), got {tuple(t.shape)}")
+    if n is not None and t.shape[0] != n:
+        raise ValueError(f"{name} must have {n} rows like the other arguments, got {t.shape[0]}")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name} is on {t.device}, the other arguments on {device}")
     return C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+class _on:
+    """`with _on(t):` = torch.cuda.device(t.device) + the current stream of that device as a void*."""
+
+    def __init__(self, t):
+        import torch
+        self.ctx = torch.cuda.device(t.device)
+
+    def __enter__(self):
+        import torch
+        self.ctx.__enter__()
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def __exit__(self, *a):
+        return self.ctx.__exit__(*a)
 
 
 def curve25519_dh_CreateSharedKey_dev(shared, pk, sk):
     """In-place device form: writes `shared`, clamps `sk`; asynchronous on torch's current stream."""
-    n = pk.shape[0]
-    _lib.check(_lib.load().curve25519_dh_CreateSharedKey_dev(_dev(shared, 32, "shared"), _dev(pk, 32, "pk"),
-                                                           _dev(sk, 32, "sk"), n, _stream()),
-               "curve25519_dh_CreateSharedKey_dev")
+    n, d = pk.shape[0], pk.device
+    args = (_check(shared, 32, "shared", n, device=d), _check(pk, 32, "pk"), _check(sk, 32, "sk", n, device=d))
+    with _on(pk) as st:
+        _lib.check(_lib.load().curve25519_dh_CreateSharedKey_dev(*args, n, st), "curve25519_dh_CreateSharedKey_dev")
 
 
 def curve25519_dh_CalculatePublicKey_dev(pk, sk, fast=False):
     L = _lib.load()
     fn = L.curve25519_dh_CalculatePublicKey_fast_dev if fast else L.curve25519_dh_CalculatePublicKey_dev
-    _lib.check(fn(_dev(pk, 32, "pk"), _dev(sk, 32, "sk"), sk.shape[0], _stream()), "curve25519_dh_CalculatePublicKey_dev")
+    n, d = sk.shape[0], sk.device
+    args = (_check(pk, 32, "pk", n, device=d), _check(sk, 32, "sk"))
+    with _on(sk) as st:
+        _lib.check(fn(*args, n, st), "curve25519_dh_CalculatePublicKey_dev")
 
 
 def ed25519_CreateKeyPair_dev(pub, priv, sk):
-    _lib.check(_lib.load().ed25519_CreateKeyPair_dev(_dev(pub, 32, "pub"), _dev(priv, 64, "priv"), _dev(sk, 32, "sk"),
-                                                   sk.shape[0], _stream()), "ed25519_CreateKeyPair_dev")
+    n, d = sk.shape[0], sk.device
+    args = (_check(pub, 32, "pub", n, device=d), _check(priv, 64, "priv", n, device=d), _check(sk, 32, "sk"))
+    with _on(sk) as st:
+        _lib.check(_lib.load().ed25519_CreateKeyPair_dev(*args, n, st), "ed25519_CreateKeyPair_dev")
 
 
 def ed25519_SignMessage_dev(sig, priv, msg):
-    n = priv.shape[0]
-    _lib.check(_lib.load().ed25519_SignMessage_dev(_dev(sig, 64, "sig"), _dev(priv, 64, "priv"),
-                                                 C.c_void_p(msg.data_ptr()), msg.shape[1] if n else 0, n, _stream()),
-               "ed25519_SignMessage_dev")
+    n, d = priv.shape[0], priv.device
+    args = (_check(sig, 64, "sig", n, device=d), _check(priv, 64, "priv"), _check(msg, None, "msg", n, device=d))
+    with _on(priv) as st:
+        _lib.check(_lib.load().ed25519_SignMessage_dev(*args, msg.shape[1], n, st), "ed25519_SignMessage_dev")
 
 
 def ed25519_VerifySignature_dev(verdict, sig, pk, msg):
-    n = sig.shape[0]
-    _lib.check(_lib.load().ed25519_VerifySignature_dev(C.c_void_p(verdict.data_ptr()), _dev(sig, 64, "sig"),
-                                                     _dev(pk, 32, "pk"), C.c_void_p(msg.data_ptr()),
-                                                     msg.shape[1] if n else 0, n, _stream()),
-               "ed25519_VerifySignature_dev")
+    import torch
+    n, d = sig.shape[0], sig.device
+    args = (_check(verdict, 1, "verdict", n, dtype=torch.int32, device=d), _check(sig, 64, "sig"),
+            _check(pk, 32, "pk", n, device=d), _check(msg, None, "msg", n, device=d))
+    with _on(sig) as st:
+        _lib.check(_lib.load().ed25519_VerifySignature_dev(*args, msg.shape[1], n, st), "ed25519_VerifySignature_dev")

@@ -1,8 +1,9 @@
-// curve25519_amd/csrc/capi_common.hpp -- host-side plumbing shared by the C-ABI entry points:
-// per-thread error text, per-thread stream + growable device staging buffers.  No torch types, no
-// CPU arithmetic: everything that computes is a HIP kernel.
+// curve25519_amd/csrc/capi_common.hpp -- host-side plumbing shared by the C-ABI entry points: per-thread error
+// text, and the per-thread device resources (streams, pinned + device staging, work scratch) with their release.
+// No torch types, no CPU arithmetic: everything that computes is a HIP kernel.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -31,53 +32,7 @@ inline int fail(hipError_t err, const char* what, const char* file, int line)
         if (e_ != hipSuccess) return c25519_host::fail(e_, #expr, __FILE__, __LINE__); \
     } while (0)
 
-// Growable device buffers owned by one host thread.  Slots 0-3 belong to pipeline lane 0, 4-7 to lane 1.
-struct Staging {
-    static constexpr int SLOTS = 8;
-    void* ptr[SLOTS] = {};
-    size_t cap[SLOTS] = {};
-    hipStream_t stream = nullptr;      // lane 0
-    hipStream_t stream2 = nullptr;     // lane 1 of the chunked host pipeline
-    int device = -1;
-
-    int ensure_stream()
-    {
-        int dev = 0;
-        C25519_TRY(hipGetDevice(&dev));
-        if (stream && dev != device) release();
-        if (!stream) {
-            C25519_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-            C25519_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-            device = dev;
-        }
-        return 0;
-    }
-    int reserve(int slot, size_t bytes)
-    {
-        if (bytes <= cap[slot]) return 0;
-        if (ptr[slot]) { C25519_TRY(hipFree(ptr[slot])); ptr[slot] = nullptr; cap[slot] = 0; }
-        size_t want = bytes < 4096 ? 4096 : bytes;
-        C25519_TRY(hipMalloc(&ptr[slot], want));
-        cap[slot] = want;
-        return 0;
-    }
-    void release()
-    {
-        for (int i = 0; i < SLOTS; i++) { if (ptr[i]) (void)hipFree(ptr[i]); ptr[i] = nullptr; cap[i] = 0; }
-        if (stream) (void)hipStreamDestroy(stream);
-        if (stream2) (void)hipStreamDestroy(stream2);
-        stream = nullptr;
-        stream2 = nullptr;
-        device = -1;
-    }
-    ~Staging() { /* process teardown: the HIP runtime may already be gone, do not call into it */ }
-};
-
-inline Staging& staging()
-{
-    static thread_local Staging s;
-    return s;
-}
+#define C25519_RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -95,6 +50,138 @@ inline int bad_arg(const char* msg)
                     "curve25519_amd: this library has no CPU fallback; a gfx950 device is required.\n",
             fn, rc, last_error().c_str());
     abort();
+}
+
+// Set to false by an atexit handler registered after the first HIP call (so it runs before the HIP runtime's own
+// teardown): thread-exit destructors that fire later must not call into a runtime that is already gone.
+inline std::atomic<bool>& runtime_alive()
+{
+    static std::atomic<bool> alive{ true };
+    return alive;
+}
+inline void arm_exit_guard()
+{
+    static std::atomic<bool> armed{ false };
+    if (!armed.exchange(true)) atexit([] { runtime_alive().store(false); });
+}
+
+// Per-host-thread device resources.  Everything belongs to ONE device (`device`); when the thread calls in with
+// another current device, the old device's resources are released first (on that device).  Released by
+// c25519_amd_thread_release(), or when the thread exits while the runtime is still alive.
+struct ThreadState {
+    static constexpr int LANES = 3;        // pipeline depth of the host-pointer (*_batch) entry points
+    static constexpr int SLOTS = 5;        // arrays per lane (inputs, outputs, in/out)
+    int device = -1;
+    hipStream_t stream[LANES] = {};
+    hipEvent_t done[LANES] = {};           // end of a lane's last download
+    void* dbuf[LANES][SLOTS] = {};         // device staging
+    size_t dcap[LANES][SLOTS] = {};
+    void* hbuf[LANES][SLOTS] = {};         // pinned host staging (hipHostMalloc)
+    size_t hcap[LANES][SLOTS] = {};
+    // work scratch of the *_dev entry points: one grow-only slab; consecutive calls reuse it in stream order, a call
+    // on another stream first waits for the previous use
+    void* work = nullptr;
+    size_t work_cap = 0;
+    hipEvent_t work_done = nullptr;
+    hipStream_t work_last = nullptr;
+    bool work_used = false;
+
+    // bind to the current device (creating streams/events on first use)
+    int ensure()
+    {
+        int dev = 0;
+        C25519_TRY(hipGetDevice(&dev));
+        arm_exit_guard();
+        if (device >= 0 && dev != device) {
+            release();
+            C25519_TRY(hipSetDevice(dev));
+        }
+        if (device < 0) {
+            for (int l = 0; l < LANES; l++) {
+                C25519_TRY(hipStreamCreateWithFlags(&stream[l], hipStreamNonBlocking));
+                C25519_TRY(hipEventCreateWithFlags(&done[l], hipEventDisableTiming));
+            }
+            C25519_TRY(hipEventCreateWithFlags(&work_done, hipEventDisableTiming));
+            device = dev;
+        }
+        return 0;
+    }
+    int reserve_dev(int lane, int slot, size_t bytes)
+    {
+        if (bytes <= dcap[lane][slot]) return 0;
+        if (dbuf[lane][slot]) { C25519_TRY(hipFree(dbuf[lane][slot])); dbuf[lane][slot] = nullptr; dcap[lane][slot] = 0; }
+        const size_t want = bytes < 4096 ? 4096 : bytes;
+        C25519_TRY(hipMalloc(&dbuf[lane][slot], want));
+        dcap[lane][slot] = want;
+        return 0;
+    }
+    int reserve_host(int lane, int slot, size_t bytes)
+    {
+        if (bytes <= hcap[lane][slot]) return 0;
+        if (hbuf[lane][slot]) { C25519_TRY(hipHostFree(hbuf[lane][slot])); hbuf[lane][slot] = nullptr; hcap[lane][slot] = 0; }
+        const size_t want = bytes < 4096 ? 4096 : bytes;
+        C25519_TRY(hipHostMalloc(&hbuf[lane][slot], want, hipHostMallocDefault));
+        hcap[lane][slot] = want;
+        return 0;
+    }
+    int acquire_work(void** out, size_t bytes, hipStream_t s)
+    {
+        C25519_RC(ensure());
+        if (work && bytes > work_cap) {
+            C25519_TRY(hipDeviceSynchronize());
+            C25519_TRY(hipFree(work));
+            work = nullptr; work_cap = 0; work_used = false;
+        }
+        if (!work) {
+            const size_t want = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes;
+            C25519_TRY(hipMalloc(&work, want));
+            work_cap = want;
+        }
+        if (work_used && s != work_last) C25519_TRY(hipStreamWaitEvent(s, work_done, 0));
+        *out = work;
+        return 0;
+    }
+    int release_work(hipStream_t s)
+    {
+        C25519_TRY(hipEventRecord(work_done, s));
+        work_last = s; work_used = true;
+        return 0;
+    }
+    // free everything on the owning device (the buffers held staged secrets: they are zeroed first)
+    void release()
+    {
+        if (device < 0) return;
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        for (int l = 0; l < LANES; l++) {
+            for (int i = 0; i < SLOTS; i++) {
+                if (dbuf[l][i]) { (void)hipMemset(dbuf[l][i], 0, dcap[l][i]); (void)hipFree(dbuf[l][i]); }
+                if (hbuf[l][i]) { memset(hbuf[l][i], 0, hcap[l][i]); (void)hipHostFree(hbuf[l][i]); }
+                dbuf[l][i] = hbuf[l][i] = nullptr; dcap[l][i] = hcap[l][i] = 0;
+            }
+            if (stream[l]) (void)hipStreamDestroy(stream[l]);
+            if (done[l]) (void)hipEventDestroy(done[l]);
+            stream[l] = nullptr; done[l] = nullptr;
+        }
+        if (work) { (void)hipMemset(work, 0, work_cap); (void)hipFree(work); }
+        if (work_done) (void)hipEventDestroy(work_done);
+        work = nullptr; work_cap = 0; work_done = nullptr; work_last = nullptr; work_used = false;
+        (void)hipGetLastError();
+        if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+        device = -1;
+    }
+    ~ThreadState()
+    {
+        if (runtime_alive().load()) release();     // else: process teardown, the HIP runtime may already be gone
+    }
+};
+
+inline ThreadState& tls()
+{
+    static thread_local ThreadState s;
+    return s;
 }
 
 }  // namespace c25519_host

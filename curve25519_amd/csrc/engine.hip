@@ -13,103 +13,32 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared engine.hip -o libcurve25519_amd.so
 #include "capi_common.hpp"
-#include "fe25519.cuh"
-#include "ge25519.cuh"
-#include "sc25519.cuh"
-#include "sha512.cuh"
-#include "x25519.cuh"
+#include "lanes.cuh"
 
 #include "../../include/curve25519_amd.h"
 #include "../../include/curve25519_dh.h"
 #include "../../include/ed25519_signature.h"
 
+#include <condition_variable>
+#include <initializer_list>
 #include <mutex>
+#include <thread>
 
 using namespace c25519;
-
-#define C25519_RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
-
-// ------------------------------------------------------------------------------------------------
-// lane I/O
-// ------------------------------------------------------------------------------------------------
-// 32-byte API records as two 16-byte accesses (a wave covers 2 KiB of contiguous memory)
-C25519_DEV void load32(u32 (&w)[8], const void* base, size_t i)
-{
-    const uint4* p = reinterpret_cast<const uint4*>(base) + 2 * i;
-    const uint4 a = p[0], b = p[1];
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-}
-C25519_DEV void store32(void* base, size_t i, const u32 (&w)[8])
-{
-    uint4* p = reinterpret_cast<uint4*>(base) + 2 * i;
-    p[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    p[1] = make_uint4(w[4], w[5], w[6], w[7]);
-}
-// scratch arrays are struct-of-arrays: word w of element i at base[w*n + i], so every access by a wave
-// is one contiguous 256-byte segment whichever element -> lane mapping a kernel uses
-C25519_DEV void soa_store_fe(u32* base, size_t n, size_t i, const fe& f)
-{
-#pragma unroll
-    for (int w = 0; w < 10; w++) base[(size_t)w * n + i] = f.v[w];
-}
-C25519_DEV void soa_load_fe(fe& f, const u32* base, size_t n, size_t i)
-{
-#pragma unroll
-    for (int w = 0; w < 10; w++) f.v[w] = base[(size_t)w * n + i];
-}
-C25519_DEV void soa_store8(u32* base, size_t n, size_t i, const u32 (&v)[8])
-{
-#pragma unroll
-    for (int w = 0; w < 8; w++) base[(size_t)w * n + i] = v[w];
-}
-C25519_DEV void soa_load8(u32 (&v)[8], const u32* base, size_t n, size_t i)
-{
-#pragma unroll
-    for (int w = 0; w < 8; w++) v[w] = base[(size_t)w * n + i];
-}
-
-// messages of a batch: fixed stride (offsets == nullptr) or ragged (message i = base[offsets[i] .. offsets[i+1]))
-struct Msgs {
-    const uint8_t* base;
-    size_t fixed;
-    const unsigned long long* offsets;
-    C25519_DEV const uint8_t* ptr(size_t i) const { return base + (offsets ? (size_t)offsets[i] : i * fixed); }
-    C25519_DEV size_t len(size_t i) const { return offsets ? (size_t)(offsets[i + 1] - offsets[i]) : fixed; }
-};
 
 // per-call scratch, carved out of one slab (all sizes in u32 words per element)
 constexpr size_t SCR_FE = 10;
 struct ProjScratch {            // projective result + prefix products of the batched inversion
-    u32 *a, *b, *z, *prefix;    // X25519: a = PX, z = PZ.  Edwards: a = X, b = Y, z = Z.
+    u32 *a, *b, *z, *prefix;    // X25519 public_fast: a = numerator, z = denominator.  Edwards: a = X, b = Y, z = Z.
 };
 
 // ------------------------------------------------------------------------------------------------
 // X25519   (curve25519_dh_CreateSharedKey / curve25519_dh_CalculatePublicKey)
 // ------------------------------------------------------------------------------------------------
-constexpr int X_BLOCK = 64;
-
-// BASE9 (pk == nullptr): ladder on the base point u = 9
-template <bool BASE9>
-__global__ void __launch_bounds__(X_BLOCK) k_x25519_ladder(ProjScratch scr, const void* pk, void* sk, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * X_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8];
-    if (!BASE9) load32(u, pk, i);
-    load32(k, sk, i);
-    clamp_words(k);
-    store32(sk, i, k);                       // the reference clamps in the caller's buffer
-    fe PX, PZ;
-    x25519_ladder_xz<BASE9>(PX, PZ, u, k);
-    soa_store_fe(scr.a, n, i, PX);
-    soa_store_fe(scr.z, n, i, PZ);
-}
-
-// Single-launch form: the four waves of a workgroup finish their ladders, park (PX, PZ) in LDS, and wave 0
-// inverts all the workgroup's Z's with ONE exponentiation (one element per wave and lane, Montgomery's trick, prefix products in
-// LDS); then every lane finishes its own element.  Same arithmetic as k_x25519_ladder + k_batch_invert with
-// K = 4, but the projective intermediates never leave the CU: HBM traffic is the API's 96 B/op plus the
-// clamped-key write-back.
+// Single launch: the eight waves of a workgroup finish their ladders, park (PX, PZ) in LDS, and wave 0 inverts all
+// the workgroup's Z's with ONE exponentiation (eight elements per lane, Montgomery's trick, prefix products in LDS);
+// then every lane finishes its own element.  The projective intermediates never leave the CU: HBM traffic is the
+// API's 96 B/op plus the clamped-key write-back.   BASE9 (pk == nullptr): ladder on the base point u = 9.
 #ifndef C25519_XF_BLOCK
 #define C25519_XF_BLOCK 512
 #endif
@@ -125,6 +54,21 @@ C25519_DEV void lds_get_fe(fe& f, const u32* buf, int stride, int idx)
 {
 #pragma unroll
     for (int w = 0; w < 10; w++) f.v[w] = buf[w * stride + idx];
+}
+
+// z <- 1 where z == 0 (mod p), returns all-ones in that case: a zero takes no part in a shared inversion and its
+// "inverse" is forced to 0 afterwards, which is what the reference's z^(p-2) gives (curve25519_dh.c:148)
+C25519_DEV u32 fe_zero_to_one(fe& z)
+{
+    u32 w[8], nz = 0;
+    fe_to_words(w, z);
+#pragma unroll
+    for (int q = 0; q < 8; q++) nz |= w[q];
+    const u32 is_zero = nz ? 0u : 0xffffffffu;
+    fe one;
+    fe_set_u32(one, 1);
+    fe_select(z, is_zero, one, z);
+    return is_zero;
 }
 
 template <bool BASE9>
@@ -154,20 +98,13 @@ __global__ void __launch_bounds__(XF_BLOCK, 4) k_x25519_fused(void* out, const v
     }
     __syncthreads();
     if (tid < 64) {
-        fe acc, z, one, zero;
-        fe_set_u32(one, 1);
+        fe acc, z, zero;
         fe_set_u32(zero, 0);
         u32 zero_mask = 0;
 #pragma unroll 1
         for (int t = 0; t < XF_K; t++) {
             lds_get_fe(z, zbuf, XF_BLOCK, tid + 64 * t);
-            u32 w[8], nz = 0;
-            fe_to_words(w, z);
-#pragma unroll
-            for (int q = 0; q < 8; q++) nz |= w[q];
-            const u32 is_zero = nz ? 0u : 0xffffffffu;
-            zero_mask |= (is_zero & 1u) << t;
-            fe_select(z, is_zero, one, z);
+            zero_mask |= (fe_zero_to_one(z) & 1u) << t;
             if (t == 0) acc = z; else fe_mul(acc, acc, z);
             if (t < XF_K - 1) lds_put_fe(pbuf + t * 640, 64, tid, acc);
         }
@@ -176,17 +113,18 @@ __global__ void __launch_bounds__(XF_BLOCK, 4) k_x25519_fused(void* out, const v
 #pragma unroll 1
         for (int t = XF_K - 1; t >= 0; t--) {
             fe zi;
+            const u32 was_zero = ((zero_mask >> t) & 1u) ? 0xffffffffu : 0u;
             if (t > 0) {
                 fe p;
                 lds_get_fe(p, pbuf + (t - 1) * 640, 64, tid);
                 fe_mul(zi, inv, p);
                 lds_get_fe(z, zbuf, XF_BLOCK, tid + 64 * t);
-                const u32 was_zero = ((zero_mask >> t) & 1u) ? 0xffffffffu : 0u;
+                fe one;
+                fe_set_u32(one, 1);
                 fe_select(z, was_zero, one, z);
                 fe_mul(inv, inv, z);
                 fe_select(zi, was_zero, zero, zi);
             } else {
-                const u32 was_zero = (zero_mask & 1u) ? 0xffffffffu : 0u;
                 fe_select(zi, was_zero, zero, inv);
             }
             lds_put_fe(zbuf, XF_BLOCK, tid + 64 * t, zi);
@@ -219,46 +157,18 @@ __global__ void __launch_bounds__(256 * BASE_NT) k_gen_base_table(u32* tbl_limbs
     const u32 k = threadIdx.x & 255u;
     const int group = threadIdx.x >> 8;
     const int extra = (BASE_NT - 1 - group) * BASE_STEP;   // trailing doublings
-    const bool shifted = extra != 0;
-    ge_pa B;
-    B.ypx = fe_const(K_BY); B.ymx = fe_const(K_BY);
-    {
-        fe t;
-        fe_add(t, B.ypx, fe_const(K_BX)); fe_carry32(B.ypx, t);
-        fe_sub(t, B.ymx, fe_const(K_BX)); fe_carry32(B.ymx, t);
-    }
-    B.t2d = fe_const(K_BT2D);
-
-    ge_ext S;                                 // neutral element (0 : 1 : 1 : 0)
-    fe_set_u32(S.X, 0); fe_set_u32(S.Y, 1); fe_set_u32(S.Z, 1); fe_set_u32(S.T, 0);
-#pragma unroll 1
-    for (int i = 7; i >= 0; i--) {            // Horner over the 8 index bits, 32 doublings apart
-        if ((k >> i) & 1) ge_add_pa(S, B);
-        const int dbl = i ? 32 : extra;
-#pragma unroll 1
-        for (int j = 0; j < dbl; j++) ge_double(S);
-    }
-    fe zi, x, y, t;
-    fe_invert(zi, S.Z);
-    fe_mul(x, S.X, zi);
-    fe_mul(y, S.Y, zi);
-    fe row[3];
-    fe_add(row[0], y, x);
-    fe_sub(row[1], y, x);
-    fe_mul(t, x, y);
-    fe_mul(row[2], t, fe_const(K_2D));
+    u32 rows[3][8];
+    ge_base_table_row(rows, k, extra);
     u32* limbs = tbl_limbs + group * BASE_TBL_WORDS;
 #pragma unroll
     for (int f = 0; f < 3; f++) {
-        u32 w[8];
-        fe_to_words(w, row[f]);
         fe c;
-        fe_from_words(c, w);                  // canonical value back in limb form
+        fe_from_words(c, rows[f]);            // canonical value back in limb form
 #pragma unroll
         for (int l = 0; l < 10; l++) limbs[(10 * f + l) * 256 + k] = c.v[l];
-        if (!shifted) {
+        if (extra == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) tbl_bytes[k * 24 + 8 * f + j] = w[j];
+            for (int j = 0; j < 8; j++) tbl_bytes[k * 24 + 8 * f + j] = rows[f][j];
         }
     }
 }
@@ -269,21 +179,6 @@ __global__ void __launch_bounds__(256 * BASE_NT) k_gen_base_table(u32* tbl_limbs
 constexpr int ED_BLOCK = 256;
 constexpr int BM_BLOCK = 1024;            // fixed-base kernels: one 120 KiB table set per 16 waves (4 per SIMD)
 
-// a = clamp(first half of SHA-512(seed)), optionally the second half as 4 big-endian stream words
-C25519_DEV void ed_expand_seed(u32 (&a)[8], u64 (&b_words)[4], const u32 (&seed)[8])
-{
-    u64 pre[4], dg[8];
-    sha512_words_from_le32(pre, seed);
-    sha512_prefixed<4>(dg, pre, nullptr, 0);
-    u32 le[16];
-    sha512_digest_le_words(le, dg);
-#pragma unroll
-    for (int i = 0; i < 8; i++) a[i] = le[i];
-    clamp_words(a);
-#pragma unroll
-    for (int i = 0; i < 4; i++) b_words[i] = dg[4 + i];
-}
-
 C25519_DEV void store_proj(const ProjScratch& scr, size_t n, size_t i, const ge_ext& S)
 {
     soa_store_fe(scr.a, n, i, S.X);
@@ -291,10 +186,26 @@ C25519_DEV void store_proj(const ProjScratch& scr, size_t n, size_t i, const ge_
     soa_store_fe(scr.z, n, i, S.Z);
 }
 
+// S = k*B by the LDS walk; with a blinding context (wave-uniform, 48 words in global memory) as
+// (k + bl)*B + BP from a randomised starting point   (edp_BasePointMultiply, ed25519_sign.c:246-268)
+template <bool BLIND>
+C25519_DEV void base_mult_maybe_blinded(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl, const u32* blind_ctx)
+{
+    if (BLIND) {
+        ge_blinding b;
+        blinding_from_words(b, blind_ctx);
+        ge_base_mult_blinded(S, k, b, lds_tbl);
+    } else {
+        ge_base_mult(S, k, lds_tbl);
+    }
+}
+
 // ed25519_CreateKeyPair (ed25519_sign.c:344-367), first part: a = clamp(H(sk)), S = a*B projective;
-// privKey[0..31] = sk.  The public key bytes are written by k_batch_invert<FinishKeypair>.
+// privKey[0..31] = sk.  The public key bytes are written by k_batch_invert<FinishPack>.
+template <bool BLIND>
 __global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_keypair_mult(ProjScratch scr, void* priv, const void* sk,
-                                                                       size_t n, const u32* __restrict__ g_tbl)
+                                                                       size_t n, const u32* __restrict__ g_tbl,
+                                                                       const u32* __restrict__ blind_ctx)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
     lds_stage_base_table(lds_tbl, g_tbl, BASE_NT);
@@ -306,7 +217,7 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_keypair_mult(ProjScratc
     store32(priv, 2 * i, seed);
     ed_expand_seed(a, b_words, seed);
     ge_ext S;
-    ge_base_mult(S, a, lds_tbl);
+    base_mult_maybe_blinded<BLIND>(S, a, lds_tbl, blind_ctx);
     store_proj(scr, n, i, S);
 }
 
@@ -332,55 +243,57 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_x25519_public_fast_mult(ProjScr
     soa_store_fe(scr.z, n, i, den);
 }
 
-// ed25519_SignMessage (ed25519_sign.c:372-419), blinding == NULL, first part (:385-400):
+// ed25519_SignMessage (ed25519_sign.c:372-419), first part (:385-400):
 // a = clamp(H(sk)[0..31]), r = H(H(sk)[32..63] || m) mod L (canonical), R = r*B projective.
+template <bool BLIND>
 __global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_sign_mult(ProjScratch scr, u32* a_out, u32* r_out,
                                                                     const void* priv, Msgs msgs, size_t n,
-                                                                    const u32* __restrict__ g_tbl)
+                                                                    const u32* __restrict__ g_tbl,
+                                                                    const u32* __restrict__ blind_ctx)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
     lds_stage_base_table(lds_tbl, g_tbl, BASE_NT);
     const size_t i = (size_t)blockIdx.x * BM_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 seed[8], a[8], r[8];
-    {
-        u64 b_words[4], dg[8];
-        u32 le[16];
-        load32(seed, priv, 2 * i);
-        ed_expand_seed(a, b_words, seed);
-        sha512_prefixed<4>(dg, b_words, msgs.ptr(i), msgs.len(i));
-        sha512_digest_le_words(le, dg);
-        sc_reduce512(r, le);
-        sc_mod(r);
-    }
+    load32(seed, priv, 2 * i);
+    ed_sign_nonce(a, r, seed, msgs.ptr(i), msgs.len(i));
     soa_store8(a_out, n, i, a);
     soa_store8(r_out, n, i, r);
     ge_ext S;
-    ge_base_mult(S, r, lds_tbl);
+    base_mult_maybe_blinded<BLIND>(S, r, lds_tbl, blind_ctx);
     store_proj(scr, n, i, S);
 }
 
 // ... last part (:404-414): h = H(enc(R) || pk || m), S = h*a + r mod L.  enc(R) is already in sig[0..31].
+// The scratch copies of a and r are zeroed behind the read (the reference clears its a and r, :416-417).
 __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_finish(void* sig, const void* priv, Msgs msgs, size_t n,
-                                                                      const u32* a_in, const u32* r_in)
+                                                                      u32* a_in, u32* r_in)
 {
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
-    u32 encR[8], pkw[8], a[8], r[8], h[8], s[8], le[16];
-    u64 pre[8], dg[8];
+    u32 encR[8], pkw[8], a[8], r[8], s[8];
+    const u32 zero[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     load32(encR, sig, 2 * i);
     load32(pkw, priv, 2 * i + 1);
-    sha512_words_from_le32(pre, encR);
-    sha512_words_from_le32(pre + 4, pkw);
-    sha512_prefixed<8>(dg, pre, msgs.ptr(i), msgs.len(i));
-    sha512_digest_le_words(le, dg);
-    sc_reduce512(h, le);
     soa_load8(a, a_in, n, i);
     soa_load8(r, r_in, n, i);
-    sc_mul(s, h, a);
-    sc_add(s, s, r);
-    sc_mod(s);
+    soa_store8(a_in, n, i, zero);
+    soa_store8(r_in, n, i, zero);
+    ed_sign_s(s, encR, pkw, msgs.ptr(i), msgs.len(i), a, r);
     store32(sig, 2 * i + 1, s);
+}
+
+// ed25519_Blinding_Init (ed25519_sign.c:289-331) for one context: digest = SHA-512(domain || seed),
+// t = digest[0..31] mod L, bl = L - t, zr = digest[32..63], BP = PE(t*B).  One lane does the arithmetic; the
+// workgroup only stages the base tables.  The domain string replaces the reference's compiled-in custom blinder
+// (custom_blind.c), which likewise only seeds the derivation.
+__global__ void __launch_bounds__(256) k_ed25519_blinding_init(u32* ctx, const uint8_t* seed, size_t seed_len,
+                                                                const u32* __restrict__ g_tbl)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
+    lds_stage_base_table(lds_tbl, g_tbl, BASE_NT);
+    if (threadIdx.x == 0) ed_blinding_init_lane(ctx, seed, seed_len, lds_tbl);
 }
 
 // ed25519_Verify_Init (ed25519_verify.c:179-232): decompress -A (inverted parity :192-195, no validation) and
@@ -391,38 +304,25 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_init(const void*
 {
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
-    u32 yw[8];
-    load32(yw, pk, i);
-    const u32 parity = yw[7] >> 31;
-    yw[7] &= 0x7fffffffu;
+    u32 pkw[8];
+    load32(pkw, pk, i);
     ge_ext Q;
-    fe_from_words(Q.Y, yw);
-    ge_calc_x(Q.X, Q.Y, ~parity);
-    fe_mul(Q.T, Q.X, Q.Y);
-    fe_set_u32(Q.Z, 1);
+    ed_decode_neg_key(Q, pkw);
     const Tbl tbl{ tables + i * stride_words };
     qtable_build(tbl, Q);
 }
 
 // ed25519_Verify_Check (ed25519_verify.c:287-313), first part: h = H(enc(R) || pk || m) mod L canonical;
 // s = raw 256 bits (no s < L check, :308); T = s*B + h*(-A) projective.  The comparison with enc(R) happens in
-// k_batch_invert<FinishVerify>.   pk_stride 1 = one key per element.
+// k_batch_invert<FinishVerify>.
 template <typename Tbl>
 C25519_DEV void verify_check_lane(const ProjScratch& scr, size_t n, size_t i, const void* sig, const u32 (&pkw)[8],
                                   const Msgs& msgs, const Tbl& tbl, const u32* lds_tbl)
 {
-    u32 Sw[8], h[8];
-    {
-        u32 Rw[8], le[16];
-        u64 pre[8], dg[8];
-        load32(Rw, sig, 2 * i);
-        sha512_words_from_le32(pre, Rw);
-        sha512_words_from_le32(pre + 4, pkw);
-        sha512_prefixed<8>(dg, pre, msgs.ptr(i), msgs.len(i));
-        sha512_digest_le_words(le, dg);
-        sc_reduce512(h, le);
-        sc_mod(h);
-    }
+    u32 Sw[8], h[8], Rw[8];
+    load32(Rw, sig, 2 * i);
+    ed_hram(h, Rw, pkw, msgs.ptr(i), msgs.len(i));
+    sc_mod(h);
     load32(Sw, sig, 2 * i + 1);
     ge_ext T;
     ge_poly_mult(T, Sw, h, tbl, lds_tbl);
@@ -494,10 +394,10 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(Pro
 // ------------------------------------------------------------------------------------------------
 // Lane j owns elements j, j+m, j+2m, ... (m = number of lanes, so every access stays coalesced) and inverts
 // their Z's with ONE exponentiation: prefix products forward, z^(p-2) once, then unwinding backwards
-// (Montgomery's trick).  A zero Z (low-order X25519 input, garbage Ed25519 key) must come out as 0 exactly like
-// the reference's z^(p-2) does, so zeros are replaced by 1 in the product and their inverse is forced to 0.
+// (Montgomery's trick).  A zero Z (garbage Ed25519 key) must come out as 0 exactly like the reference's z^(p-2)
+// does, so zeros are replaced by 1 in the product and their inverse is forced to 0.
 // Fin::emit(e, zinv) turns element e's projective value and 1/Z into the operation's output bytes.
-struct FinishX25519 {                       // out = canonical(PX / PZ)           (curve25519_dh.c:148-150)
+struct FinishX25519 {                       // out = canonical(num / den)           (curve25519_dh.c:175-178)
     const u32* px; void* out; size_t n;
     C25519_DEV void emit(size_t e, const fe& zinv) const
     {
@@ -560,15 +460,7 @@ __global__ void __launch_bounds__(INV_BLOCK) k_batch_invert(const u32* Z, u32* p
         const size_t e = j + (size_t)t * m;
         if (e >= n) break;
         soa_load_fe(z, Z, n, e);
-        u32 w[8], nz = 0;
-        fe_to_words(w, z);
-#pragma unroll
-        for (int q = 0; q < 8; q++) nz |= w[q];
-        const u32 is_zero = nz ? 0u : 0xffffffffu;
-        zero_mask |= (is_zero & 1u) << t;
-        fe one;
-        fe_set_u32(one, 1);
-        fe_select(z, is_zero, one, z);                     // z == 0 (mod p) takes no part in the product
+        zero_mask |= (fe_zero_to_one(z) & 1u) << t;        // z == 0 (mod p) takes no part in the product
         fe_mul(acc, acc, z);
         soa_store_fe(prefix, n, e, acc);
     }
@@ -602,10 +494,8 @@ __global__ void __launch_bounds__(INV_BLOCK) k_batch_invert(const u32* Z, u32* p
 }
 
 // ------------------------------------------------------------------------------------------------
-// field-level self-test hook (the counterpart of the reference's ECP_SELF_TEST unit checks,
-// test/curve25519_selftest.c:640-741): out[i] = canonical( op(a[i], b[i]) ) on 32-byte little-endian values
-// taken mod p.  op: 0 a*b, 1 a^2, 2 a+b, 3 a-b, 4 1/a, 5 a^((p-5)/8), 6 a (canonicalise only),
-// 7 (a-b)*(a+b) with unreduced operands (exercises the beta-3 x beta-2 corner of the bound contract).
+// unit-test hooks (the counterpart of the reference's ECP_SELF_TEST unit checks,
+// test/curve25519_selftest.c:624-741): one lane per input record, operations defined in lanes.cuh
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_fe_selftest(void* out, const void* a, const void* b, size_t n, int op)
 {
@@ -614,21 +504,31 @@ __global__ void __launch_bounds__(64) k_fe_selftest(void* out, const void* a, co
     u32 aw[8], bw[8], ow[8];
     load32(aw, a, i);
     load32(bw, b, i);
-    fe x, y, r, t;
-    fe_from_words(x, aw);
-    fe_from_words(y, bw);
-    switch (op) {
-    case 0: fe_mul(r, x, y); break;
-    case 1: fe_sqr(r, x); break;
-    case 2: fe_add(r, x, y); break;
-    case 3: fe_sub(r, x, y); break;
-    case 4: fe_invert(r, x); break;
-    case 5: fe_pow2523(r, x); break;
-    case 6: r = x; break;
-    default: fe_sub(r, x, y); fe_add(t, x, y); fe_mul(r, r, t); break;
-    }
-    fe_to_words(ow, r);
+    fe_selftest_op(ow, aw, bw, op);
     store32(out, i, ow);
+}
+
+__global__ void __launch_bounds__(64) k_sc_selftest(void* out, const void* a, const void* b, size_t n, int op)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    u32 lo[8], hi[8], aw[16], bw[8], ow[8];
+    load32(lo, a, 2 * i);
+    load32(hi, a, 2 * i + 1);
+    load32(bw, b, i);
+#pragma unroll
+    for (int j = 0; j < 8; j++) { aw[j] = lo[j]; aw[8 + j] = hi[j]; }
+    sc_selftest_op(ow, aw, bw, op);
+    store32(out, i, ow);
+}
+
+__global__ void __launch_bounds__(64) k_fold_selftest(uint8_t* out /* n x 128 */, const void* k, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    u32 kw[8];
+    load32(kw, k, i);
+    fold_selftest_op(out + 128 * i, kw);
 }
 
 // ================================================================================================
@@ -636,10 +536,10 @@ __global__ void __launch_bounds__(64) k_fe_selftest(void* out, const void* a, co
 // ================================================================================================
 namespace {
 
-using c25519_host::Staging;
+using c25519_host::ThreadState;
 using c25519_host::aligned16;
 using c25519_host::bad_arg;
-using c25519_host::staging;
+using c25519_host::tls;
 
 constexpr int MAX_DEVICES = 64;
 struct DeviceTables {
@@ -676,51 +576,31 @@ int base_tables(const u32** limbs, const u32** bytes)
 
 inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
+// *_dev arguments: n in range, pointers 16-byte aligned and -- unless C25519_AMD_NO_PTR_CHECK is set -- device (or
+// managed) memory of the CURRENT device: a pointer of another GPU or a host pointer is an error here, not a fault
+// inside a kernel.
 int check_dev_args(size_t n, std::initializer_list<const void*> ptrs)
 {
+    static const bool check_owner = getenv("C25519_AMD_NO_PTR_CHECK") == nullptr;
     if (n > ((size_t)1 << 31)) return bad_arg("batch too large (n > 2^31)");
-    for (const void* p : ptrs)
-        if (p && !aligned16(p)) return bad_arg("device pointers must be 16-byte aligned");
+    int dev = 0;
+    if (check_owner && n) C25519_TRY(hipGetDevice(&dev));
+    for (const void* p : ptrs) {
+        if (!p) continue;
+        if (!aligned16(p)) return bad_arg("device pointers must be 16-byte aligned");
+        if (!check_owner || n == 0) continue;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return bad_arg("*_dev entry points take device pointers (this one is unknown to the HIP runtime)");
+        }
+        if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)
+            return bad_arg("*_dev entry points take device pointers (got host memory)");
+        if (attr.type == hipMemoryTypeDevice && attr.device != dev)
+            return bad_arg("device pointer belongs to another device than the current one");
+    }
     return 0;
 }
-
-// Work scratch of the *_dev entry points: one grow-only slab per host thread.  Consecutive calls of a thread
-// reuse it in stream order; if a thread switches streams, the new stream first waits for the previous use.
-struct WorkScratch {
-    void* ptr = nullptr;
-    size_t cap = 0;
-    int dev = -1;
-    hipEvent_t done = nullptr;
-    hipStream_t last = nullptr;
-    bool used = false;
-
-    int acquire(void** out, size_t bytes, hipStream_t stream)
-    {
-        int d = 0;
-        C25519_TRY(hipGetDevice(&d));
-        if (ptr && (d != dev || bytes > cap)) {
-            C25519_TRY(hipDeviceSynchronize());
-            C25519_TRY(hipFree(ptr));
-            ptr = nullptr; cap = 0; used = false;
-        }
-        if (!ptr) {
-            size_t want = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes;
-            C25519_TRY(hipMalloc(&ptr, want));
-            cap = want; dev = d;
-        }
-        if (!done) C25519_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        if (used && stream != last) C25519_TRY(hipStreamWaitEvent(stream, done, 0));
-        *out = ptr;
-        return 0;
-    }
-    int release(hipStream_t stream)
-    {
-        C25519_TRY(hipEventRecord(done, stream));
-        last = stream; used = true;
-        return 0;
-    }
-};
-thread_local WorkScratch tl_work;
 
 inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -734,7 +614,7 @@ ProjScratch carve_proj(u32* base, size_t n)
 }
 
 // how many elements share one inversion: as many as possible while every SIMD still gets a wave
-// (measured at n = 2^20: K = 2 / 4 / 8 / 16 -> 9.52 / 9.39 / 9.33 / 9.29 ms per X25519 pass)
+// (measured at n = 2^20: K = 2 / 4 / 8 / 16 -> 9.52 / 9.39 / 9.33 / 9.29 ms per two-launch X25519 pass)
 inline int inversion_k(size_t n)
 {
     if (const char* e = getenv("C25519_AMD_INV_K")) {      // tuning knob, 1..16
@@ -757,54 +637,153 @@ int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t 
     return 0;
 }
 
-// ---- two-lane host pipeline used by the *_batch entry points ----
-struct Lane {                        // one side of the two-deep pipeline
-    Staging& s;
-    int lane;
-    hipStream_t stream() const { return lane ? s.stream2 : s.stream; }
-    void* ptr(int slot) const { return s.ptr[4 * lane + slot]; }
-    int up(int slot, const void* src, size_t bytes) const
-    {
-        C25519_RC(s.reserve(4 * lane + slot, bytes));
-        if (bytes) C25519_TRY(hipMemcpyAsync(ptr(slot), src, bytes, hipMemcpyHostToDevice, stream()));
-        return 0;
-    }
-    int room(int slot, size_t bytes) const { return s.reserve(4 * lane + slot, bytes); }
-    int down(void* dst, int slot, size_t bytes) const
-    {
-        if (bytes) C25519_TRY(hipMemcpyAsync(dst, ptr(slot), bytes, hipMemcpyDeviceToHost, stream()));
-        return 0;
-    }
+// ---- host-pointer pipeline used by the *_batch entry points -------------------------------------------------------
+// A call is cut into chunks that rotate over LANES (stream, pinned host buffers, device buffers) sets:
+//     stage-in  : CPU copies the caller's (pageable) arrays into the lane's pinned buffers
+//     enqueue   : H2D copies, the *_dev kernels, D2H copies into pinned buffers, all asynchronous on the lane's stream
+//     stage-out : once the lane's event has fired, CPU copies the results into the caller's arrays
+// Stage-out runs on a helper thread, stage-in on the calling thread, so that both CPU copies and both PCIe directions
+// ride under the kernels of the neighbouring chunks (pinned memory: hipMemcpyAsync is a real DMA, not a staged copy).
+struct Arr {
+    const void* in;      // caller's source (nullptr: output only)
+    void* out;           // caller's destination (nullptr: input only); in and out may both be set (IN/OUT array)
+    size_t elem;         // bytes per element
 };
 
-// submit(lane, lo, count) uploads a chunk and enqueues its kernels; collect(lane, lo, count) downloads its
-// results.  Chunk i+1 is submitted BEFORE chunk i is collected, so its (host-blocking, pageable) upload and
-// the download of chunk i both run under the kernels of the neighbouring chunk.
-template <typename Submit, typename Collect>
-int pipelined(size_t n, Submit submit, Collect collect)
+template <typename Launch>
+int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
 {
-    Staging& s = staging();
-    C25519_RC(s.ensure_stream());
-    const size_t chunk = n >= ((size_t)1 << 18) ? round_up((n + 3) / 4, 64) : n;
-    size_t prev_lo = 0, prev_cnt = 0;
-    int lane = 0;
-    for (size_t lo = 0; lo < n; lo += chunk, lane ^= 1) {
-        const size_t cnt = n - lo < chunk ? n - lo : chunk;
-        C25519_RC(submit(Lane{ s, lane }, lo, cnt));
-        if (prev_cnt) C25519_RC(collect(Lane{ s, lane ^ 1 }, prev_lo, prev_cnt));
-        prev_lo = lo; prev_cnt = cnt;
+    ThreadState& t = tls();
+    C25519_RC(t.ensure());
+    const Arr* arr = arrays.begin();
+    const int na = (int)arrays.size();
+    if (na > ThreadState::SLOTS) return bad_arg("internal: too many arrays");
+    size_t row = 0;
+    for (int a = 0; a < na; a++) row += arr[a].elem;
+    // chunking: big batches in >= 8 pieces so that three can be in flight; small ones in one piece
+    size_t chunk = n;
+    if (n >= ((size_t)1 << 17)) chunk = round_up((n + 7) / 8, 256);
+    const size_t max_chunk_bytes = (size_t)256 << 20;
+    while (chunk > 256 && chunk * row > max_chunk_bytes) chunk = round_up(chunk / 2, 256);
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    const int lanes = nchunks < (size_t)ThreadState::LANES ? (int)nchunks : ThreadState::LANES;
+    for (int l = 0; l < lanes; l++)
+        for (int a = 0; a < na; a++) {
+            C25519_RC(t.reserve_dev(l, a, arr[a].elem * chunk));
+            C25519_RC(t.reserve_host(l, a, arr[a].elem * chunk));
+        }
+
+    // stage-out worker: consumes chunk indices in order
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t submitted = 0, drained = 0;
+    int worker_rc = 0;
+    bool abort_all = false;
+    auto drain_one = [&](size_t c) -> int {
+        const int l = (int)(c % lanes);
+        const size_t lo = c * chunk, cnt = (n - lo < chunk) ? n - lo : chunk;
+        C25519_TRY(hipEventSynchronize(t.done[l]));
+        for (int a = 0; a < na; a++)
+            if (arr[a].out) memcpy((char*)arr[a].out + lo * arr[a].elem, t.hbuf[l][a], cnt * arr[a].elem);
+        return 0;
+    };
+    const bool threaded = nchunks > 1;
+    std::thread worker;
+    if (threaded)
+        worker = std::thread([&] {
+            for (size_t c = 0; c < nchunks; c++) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return submitted > c || abort_all; });
+                    if (abort_all) return;
+                }
+                const int rc = drain_one(c);
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc && !worker_rc) worker_rc = rc;
+                drained = c + 1;
+                cv.notify_all();
+            }
+        });
+    auto stop_worker = [&](int rc) {
+        if (threaded) {
+            { std::lock_guard<std::mutex> lk(mu); abort_all = true; }
+            cv.notify_all();
+            worker.join();
+        }
+        return rc;
+    };
+
+    int rc = 0;
+    for (size_t c = 0; c < nchunks && !rc; c++) {
+        const int l = (int)(c % lanes);
+        const size_t lo = c * chunk, cnt = (n - lo < chunk) ? n - lo : chunk;
+        if (threaded && c >= (size_t)lanes) {           // the lane's previous chunk must have left its pinned buffers
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return drained > c - lanes || worker_rc; });
+            if (worker_rc) { rc = worker_rc; break; }
+        }
+        hipStream_t st = t.stream[l];
+        void* dptr[ThreadState::SLOTS] = {};
+        for (int a = 0; a < na; a++) {
+            dptr[a] = t.dbuf[l][a];
+            if (arr[a].in && cnt * arr[a].elem) {
+                memcpy(t.hbuf[l][a], (const char*)arr[a].in + lo * arr[a].elem, cnt * arr[a].elem);
+                if (hipMemcpyAsync(dptr[a], t.hbuf[l][a], cnt * arr[a].elem, hipMemcpyHostToDevice, st) != hipSuccess)
+                    rc = c25519_host::fail(hipGetLastError(), "hipMemcpyAsync(H2D)", __FILE__, __LINE__);
+            }
+        }
+        if (!rc) rc = launch(dptr, cnt, lo, st);
+        for (int a = 0; a < na && !rc; a++)
+            if (arr[a].out && cnt * arr[a].elem &&
+                hipMemcpyAsync(t.hbuf[l][a], dptr[a], cnt * arr[a].elem, hipMemcpyDeviceToHost, st) != hipSuccess)
+                rc = c25519_host::fail(hipGetLastError(), "hipMemcpyAsync(D2H)", __FILE__, __LINE__);
+        if (!rc && hipEventRecord(t.done[l], st) != hipSuccess)
+            rc = c25519_host::fail(hipGetLastError(), "hipEventRecord", __FILE__, __LINE__);
+        if (rc) break;
+        if (threaded) {
+            { std::lock_guard<std::mutex> lk(mu); submitted = c + 1; }
+            cv.notify_all();
+        } else {
+            rc = drain_one(c);
+        }
     }
-    C25519_RC(collect(Lane{ s, lane ^ 1 }, prev_lo, prev_cnt));
-    C25519_TRY(hipStreamSynchronize(s.stream));
-    C25519_TRY(hipStreamSynchronize(s.stream2));
+    if (rc) return stop_worker(rc);
+    if (threaded) {
+        worker.join();
+        if (worker_rc) return worker_rc;
+    }
     return 0;
+}
+
+inline size_t verify_scratch_bytes(size_t n)
+{
+    return (n * QTABLE_LIMB_WORDS + proj_words(n)) * sizeof(u32);
+}
+
+// Init + Check on per-lane tables; Fin decides what leaves: the verdict, or enc(T) for the test hook
+template <typename MakeFin>
+int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t stream, MakeFin make_fin)
+{
+    const u32* tbl = nullptr;
+    C25519_RC(base_tables(&tbl, nullptr));
+    void* w = nullptr;
+    C25519_RC(tls().acquire_work(&w, verify_scratch_bytes(n), stream));
+    const ProjScratch scr = carve_proj((u32*)w, n);
+    u32* tables = (u32*)w + proj_words(n);
+    k_ed25519_verify_init<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(pk, n, tables, QTABLE_LIMB_WORDS);
+    C25519_TRY(hipGetLastError());
+    k_ed25519_verify_check<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
+        scr, sig, pk, msgs, n, tbl, tables, QTABLE_LIMB_WORDS);
+    C25519_TRY(hipGetLastError());
+    C25519_RC(launch_invert(scr, n, make_fin(scr), stream));
+    return tls().release_work(stream);
 }
 
 }  // namespace
 
 extern "C" {
 
-const char* c25519_amd_version(void) { return "curve25519_amd 0.3 (gfx950)"; }
+const char* c25519_amd_version(void) { return "curve25519_amd 0.4 (gfx950)"; }
 const char* c25519_amd_last_error(void) { return c25519_host::last_error().c_str(); }
 
 int c25519_amd_device_count(void)
@@ -820,25 +799,17 @@ int c25519_amd_set_device(int device)
     return 0;
 }
 
+// frees the calling thread's streams, staging buffers (zeroed first) and work scratch
+void c25519_amd_thread_release(void) { tls().release(); }
+
 // ---- device-pointer entry points ----------------------------------------------------------------
 
 static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t stream)
 {
-    static const bool split = getenv("C25519_AMD_X25519_SPLIT") != nullptr;   // A/B knob: two-launch form
-    if (!split) {
-        if (pk) k_x25519_fused<false><<<grid_for(n, XF_BLOCK), XF_BLOCK, 0, stream>>>(out, pk, sk, n);
-        else    k_x25519_fused<true><<<grid_for(n, XF_BLOCK), XF_BLOCK, 0, stream>>>(out, pk, sk, n);
-        C25519_TRY(hipGetLastError());
-        return 0;
-    }
-    void* w = nullptr;
-    C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
-    const ProjScratch scr = carve_proj((u32*)w, n);
-    if (pk) k_x25519_ladder<false><<<grid_for(n, X_BLOCK), X_BLOCK, 0, stream>>>(scr, pk, sk, n);
-    else    k_x25519_ladder<true><<<grid_for(n, X_BLOCK), X_BLOCK, 0, stream>>>(scr, pk, sk, n);
+    if (pk) k_x25519_fused<false><<<grid_for(n, XF_BLOCK), XF_BLOCK, 0, stream>>>(out, pk, sk, n);
+    else    k_x25519_fused<true><<<grid_for(n, XF_BLOCK), XF_BLOCK, 0, stream>>>(out, pk, sk, n);
     C25519_TRY(hipGetLastError());
-    C25519_RC(launch_invert(scr, n, FinishX25519{ scr.a, out, n }, stream));
-    return tl_work.release(stream);
+    return 0;
 }
 
 int curve25519_dh_CreateSharedKey_dev(void* shared, const void* pk, void* sk, size_t n, void* stream)
@@ -866,111 +837,122 @@ int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
-    C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
+    C25519_RC(tls().acquire_work(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     k_x25519_public_fast_mult<<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, sk, n, tbl);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishX25519{ scr.a, pk, n }, stream));
-    return tl_work.release(stream);
+    return tls().release_work(stream);
 }
 
-int ed25519_CreateKeyPair_dev(void* pub, void* priv, const void* sk, size_t n, void* stream_)
+static int keypair_dev(void* pub, void* priv, const void* sk, const void* blinding, size_t n, hipStream_t stream)
 {
     if (!pub || !priv || !sk) return bad_arg("null pointer");
-    if (int rc = check_dev_args(n, { pub, priv, sk })) return rc;
+    if (int rc = check_dev_args(n, { pub, priv, sk, blinding })) return rc;
     if (n == 0) return 0;
-    hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
-    C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
+    C25519_RC(tls().acquire_work(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
-    k_ed25519_keypair_mult<<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, priv, sk, n, tbl);
+    if (blinding)
+        k_ed25519_keypair_mult<true><<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, priv, sk, n, tbl, (const u32*)blinding);
+    else
+        k_ed25519_keypair_mult<false><<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, priv, sk, n, tbl, nullptr);
     C25519_TRY(hipGetLastError());
     // pub[e] and priv[e][32..63] <- enc(A)
     C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, pub, n, 1, 0, priv, 2, 1 }, stream));
-    return tl_work.release(stream);
+    return tls().release_work(stream);
 }
 
-static int sign_dev(void* sig, const void* priv, Msgs msgs, size_t n, hipStream_t stream)
+int ed25519_CreateKeyPair_dev(void* pub, void* priv, const void* sk, size_t n, void* stream)
 {
-    if (int rc = check_dev_args(n, { sig, priv })) return rc;
+    return keypair_dev(pub, priv, sk, nullptr, n, (hipStream_t)stream);
+}
+
+int ed25519_CreateKeyPair_blinded_dev(void* pub, void* priv, const void* blinding, const void* sk, size_t n, void* stream)
+{
+    if (!blinding) return bad_arg("null blinding context");
+    return keypair_dev(pub, priv, sk, blinding, n, (hipStream_t)stream);
+}
+
+static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs, size_t n, hipStream_t stream)
+{
+    if (int rc = check_dev_args(n, { sig, priv, blinding })) return rc;
     if (n == 0) return 0;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
     const size_t sc_words = round_up(8 * n, 4);
-    C25519_RC(tl_work.acquire(&w, (proj_words(n) + 2 * sc_words) * sizeof(u32), stream));
+    C25519_RC(tls().acquire_work(&w, (proj_words(n) + 2 * sc_words) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     u32* a_buf = (u32*)w + proj_words(n);
     u32* r_buf = a_buf + sc_words;
-    k_ed25519_sign_mult<<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl);
+    if (blinding)
+        k_ed25519_sign_mult<true><<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl,
+                                                                               (const u32*)blinding);
+    else
+        k_ed25519_sign_mult<false><<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl,
+                                                                                nullptr);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, sig, n, 2, 0, nullptr, 0, 0 }, stream));   // sig[e][0..31] = enc(R)
     k_ed25519_sign_finish<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(sig, priv, msgs, n, a_buf, r_buf);
     C25519_TRY(hipGetLastError());
-    return tl_work.release(stream);
+    return tls().release_work(stream);
 }
 
 int ed25519_SignMessage_dev(void* sig, const void* priv, const void* msg, size_t msg_size, size_t n, void* stream)
 {
     if (!sig || !priv || (!msg && msg_size)) return bad_arg("null pointer");
-    return sign_dev(sig, priv, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, (hipStream_t)stream);
+    return sign_dev(sig, priv, nullptr, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, (hipStream_t)stream);
+}
+
+int ed25519_SignMessage_blinded_dev(void* sig, const void* priv, const void* blinding, const void* msg, size_t msg_size,
+                                    size_t n, void* stream)
+{
+    if (!sig || !priv || !blinding || (!msg && msg_size)) return bad_arg("null pointer");
+    return sign_dev(sig, priv, blinding, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, (hipStream_t)stream);
 }
 
 int ed25519_SignMessage_ragged_dev(void* sig, const void* priv, const void* msgs, const uint64_t* offsets, size_t n,
                                    void* stream)
 {
     if (!sig || !priv || !offsets) return bad_arg("null pointer");
-    return sign_dev(sig, priv, Msgs{ (const uint8_t*)msgs, 0, (const unsigned long long*)offsets }, n, (hipStream_t)stream);
+    return sign_dev(sig, priv, nullptr, Msgs{ (const uint8_t*)msgs, 0, (const unsigned long long*)offsets }, n,
+                    (hipStream_t)stream);
 }
 
-size_t ed25519_VerifySignature_scratch_bytes(size_t n)
+// one 192-byte blinding context from seed[0..seed_len) (device pointers)
+int ed25519_Blinding_Init_dev(void* ctx, const void* seed, size_t seed_len, void* stream)
 {
-    return (n * QTABLE_LIMB_WORDS + proj_words(n)) * sizeof(u32);
+    if (!ctx || (!seed && seed_len)) return bad_arg("null pointer");
+    if (int rc = check_dev_args(1, { ctx })) return rc;
+    const u32* tbl = nullptr;
+    C25519_RC(base_tables(&tbl, nullptr));
+    k_ed25519_blinding_init<<<1, 256, 0, (hipStream_t)stream>>>((u32*)ctx, (const uint8_t*)seed, seed_len, tbl);
+    C25519_TRY(hipGetLastError());
+    return 0;
 }
+
+size_t ed25519_VerifySignature_scratch_bytes(size_t n) { return verify_scratch_bytes(n); }
 
 static int verify_dev(void* verdict, const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t stream)
 {
-    if (int rc = check_dev_args(n, { sig, pk })) return rc;
+    if (int rc = check_dev_args(n, { verdict, sig, pk })) return rc;
     if (n == 0) return 0;
-    const u32* tbl = nullptr;
-    C25519_RC(base_tables(&tbl, nullptr));
-    void* w = nullptr;
-    C25519_RC(tl_work.acquire(&w, ed25519_VerifySignature_scratch_bytes(n), stream));
-    const ProjScratch scr = carve_proj((u32*)w, n);
-    u32* tables = (u32*)w + proj_words(n);
-    k_ed25519_verify_init<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(pk, n, tables, QTABLE_LIMB_WORDS);
-    C25519_TRY(hipGetLastError());
-    k_ed25519_verify_check<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
-        scr, sig, pk, msgs, n, tbl, tables, QTABLE_LIMB_WORDS);
-    C25519_TRY(hipGetLastError());
-    C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
-    return tl_work.release(stream);
+    return verify_run(sig, pk, msgs, n, stream,
+                      [&](const ProjScratch& scr) { return FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }; });
 }
 
 // test hook: enc(T) instead of the verdict (what Verify_Check compares with enc(R)); device pointers
 int c25519_amd_verify_point_dev(void* out, const void* sig, const void* pk, const void* msg, size_t msg_size, size_t n,
-                                void* stream_)
+                                void* stream)
 {
     if (!out || !sig || !pk || (!msg && msg_size)) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { out, sig, pk })) return rc;
     if (n == 0) return 0;
-    hipStream_t stream = (hipStream_t)stream_;
-    const u32* tbl = nullptr;
-    C25519_RC(base_tables(&tbl, nullptr));
-    void* w = nullptr;
-    C25519_RC(tl_work.acquire(&w, ed25519_VerifySignature_scratch_bytes(n), stream));
-    const ProjScratch scr = carve_proj((u32*)w, n);
-    u32* tables = (u32*)w + proj_words(n);
-    const Msgs msgs{ (const uint8_t*)msg, msg_size, nullptr };
-    k_ed25519_verify_init<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(pk, n, tables, QTABLE_LIMB_WORDS);
-    C25519_TRY(hipGetLastError());
-    k_ed25519_verify_check<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
-        scr, sig, pk, msgs, n, tbl, tables, QTABLE_LIMB_WORDS);
-    C25519_TRY(hipGetLastError());
-    C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, out, n, 1, 0, nullptr, 0, 0 }, stream));
-    return tl_work.release(stream);
+    return verify_run(sig, pk, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, (hipStream_t)stream,
+                      [&](const ProjScratch& scr) { return FinishPack{ scr.a, scr.b, out, n, 1, 0, nullptr, 0, 0 }; });
 }
 
 int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, const void* msg, size_t msg_size,
@@ -1006,37 +988,56 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
                              size_t n, void* stream_)
 {
     if (!verdict || !ctx || !sig || (!msg && msg_size)) return bad_arg("null pointer");
-    if (int rc = check_dev_args(n, { ctx, sig })) return rc;
+    if (int rc = check_dev_args(n, { verdict, ctx, sig })) return rc;
     if (n == 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
-    C25519_RC(tl_work.acquire(&w, proj_words(n) * sizeof(u32), stream));
+    C25519_RC(tls().acquire_work(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     k_ed25519_verify_check_shared<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
         scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
-    return tl_work.release(stream);
+    return tls().release_work(stream);
 }
 
+// ---- unit-test hooks (host pointers) ---------------------------------------------------------------
 int c25519_amd_fe_selftest(unsigned char* out, const unsigned char* a, const unsigned char* b, size_t n, int op)
 {
     if (!out || !a || !b) return bad_arg("null pointer");
     if (n == 0) return 0;
-    Staging& s = staging();
-    C25519_RC(s.ensure_stream());
-    C25519_RC(s.reserve(0, 32 * n));
-    C25519_RC(s.reserve(1, 32 * n));
-    C25519_RC(s.reserve(2, 32 * n));
-    C25519_TRY(hipMemcpyAsync(s.ptr[0], a, 32 * n, hipMemcpyHostToDevice, s.stream));
-    C25519_TRY(hipMemcpyAsync(s.ptr[1], b, 32 * n, hipMemcpyHostToDevice, s.stream));
-    k_fe_selftest<<<grid_for(n, 64), 64, 0, s.stream>>>(s.ptr[2], s.ptr[0], s.ptr[1], n, op);
-    C25519_TRY(hipGetLastError());
-    C25519_TRY(hipMemcpyAsync(out, s.ptr[2], 32 * n, hipMemcpyDeviceToHost, s.stream));
-    C25519_TRY(hipStreamSynchronize(s.stream));
-    return 0;
+    return run_batch(n, { Arr{ a, nullptr, 32 }, Arr{ b, nullptr, 32 }, Arr{ nullptr, out, 32 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         k_fe_selftest<<<grid_for(c, 64), 64, 0, st>>>(d[2], d[0], d[1], c, op);
+                         C25519_TRY(hipGetLastError());
+                         return 0;
+                     });
+}
+
+int c25519_amd_sc_selftest(unsigned char* out, const unsigned char* a, const unsigned char* b, size_t n, int op)
+{
+    if (!out || !a || !b) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    return run_batch(n, { Arr{ a, nullptr, 64 }, Arr{ b, nullptr, 32 }, Arr{ nullptr, out, 32 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         k_sc_selftest<<<grid_for(c, 64), 64, 0, st>>>(d[2], d[0], d[1], c, op);
+                         C25519_TRY(hipGetLastError());
+                         return 0;
+                     });
+}
+
+int c25519_amd_fold_selftest(unsigned char* out, const unsigned char* k, size_t n)
+{
+    if (!out || !k) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    return run_batch(n, { Arr{ k, nullptr, 32 }, Arr{ nullptr, out, 128 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         k_fold_selftest<<<grid_for(c, 64), 64, 0, st>>>((uint8_t*)d[1], d[0], c);
+                         C25519_TRY(hipGetLastError());
+                         return 0;
+                     });
 }
 
 int c25519_amd_base_table(unsigned char* out)
@@ -1048,91 +1049,91 @@ int c25519_amd_base_table(unsigned char* out)
     return 0;
 }
 
-// ---- host-pointer entry points: stage, run the *_dev form, copy back -----------------------------
-// Large batches are cut into four chunks that alternate between two (stream, staging-slot) lanes, so the
-// PCIe copies of one chunk run under the kernels of the other.  Pageable host memory: the copy blocks the
-// calling thread, not the GPU.
-
-// legacy single-lane helpers (ragged entry points)
-static int up(Staging& s, int slot, const void* src, size_t bytes)
-{
-    C25519_RC(s.reserve(slot, bytes));
-    if (bytes) C25519_TRY(hipMemcpyAsync(s.ptr[slot], src, bytes, hipMemcpyHostToDevice, s.stream));
-    return 0;
-}
-static int down(Staging& s, void* dst, int slot, size_t bytes)
-{
-    if (bytes) C25519_TRY(hipMemcpyAsync(dst, s.ptr[slot], bytes, hipMemcpyDeviceToHost, s.stream));
-    return 0;
-}
+// ---- host-pointer entry points: stage, run the *_dev form, copy back (run_batch above) ---------------
 
 int curve25519_dh_CreateSharedKey_batch(unsigned char* shared, const unsigned char* pk, unsigned char* sk, size_t n)
 {
     if (!shared || !pk || !sk) return bad_arg("null pointer");
     if (n == 0) return 0;
-    return pipelined(n,
-        [&](const Lane& L, size_t lo, size_t c) -> int {
-            C25519_RC(L.up(0, pk + 32 * lo, 32 * c));
-            C25519_RC(L.up(1, sk + 32 * lo, 32 * c));
-            C25519_RC(L.room(2, 32 * c));
-            return curve25519_dh_CreateSharedKey_dev(L.ptr(2), L.ptr(0), L.ptr(1), c, L.stream());
-        },
-        [&](const Lane& L, size_t lo, size_t c) -> int {
-            C25519_RC(L.down(sk + 32 * lo, 1, 32 * c));
-            return L.down(shared + 32 * lo, 2, 32 * c);
-        });
+    return run_batch(n, { Arr{ pk, nullptr, 32 }, Arr{ sk, sk, 32 }, Arr{ nullptr, shared, 32 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return curve25519_dh_CreateSharedKey_dev(d[2], d[0], d[1], c, st);
+                     });
 }
 
 static int public_batch(unsigned char* pk, unsigned char* sk, size_t n, bool fast)
 {
     if (!pk || !sk) return bad_arg("null pointer");
     if (n == 0) return 0;
-    return pipelined(n,
-        [&](const Lane& L, size_t lo, size_t c) -> int {
-            C25519_RC(L.up(1, sk + 32 * lo, 32 * c));
-            C25519_RC(L.room(2, 32 * c));
-            return fast ? curve25519_dh_CalculatePublicKey_fast_dev(L.ptr(2), L.ptr(1), c, L.stream())
-                        : curve25519_dh_CalculatePublicKey_dev(L.ptr(2), L.ptr(1), c, L.stream());
-        },
-        [&](const Lane& L, size_t lo, size_t c) -> int {
-            C25519_RC(L.down(sk + 32 * lo, 1, 32 * c));
-            return L.down(pk + 32 * lo, 2, 32 * c);
-        });
+    return run_batch(n, { Arr{ sk, sk, 32 }, Arr{ nullptr, pk, 32 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return fast ? curve25519_dh_CalculatePublicKey_fast_dev(d[1], d[0], c, st)
+                                     : curve25519_dh_CalculatePublicKey_dev(d[1], d[0], c, st);
+                     });
 }
 
 int curve25519_dh_CalculatePublicKey_batch(unsigned char* pk, unsigned char* sk, size_t n) { return public_batch(pk, sk, n, false); }
 int curve25519_dh_CalculatePublicKey_fast_batch(unsigned char* pk, unsigned char* sk, size_t n) { return public_batch(pk, sk, n, true); }
 
-int ed25519_CreateKeyPair_batch(unsigned char* pub, unsigned char* priv, const unsigned char* sk, size_t n)
+// the blinding context of a host-pointer call: 192 bytes uploaded once per call into the thread's scratch lane
+static int upload_blinding(void** dctx, const void* blinding)
+{
+    ThreadState& t = tls();
+    C25519_RC(t.ensure());
+    C25519_RC(t.reserve_dev(ThreadState::LANES - 1, ThreadState::SLOTS - 1, 4 * BLIND_WORDS));
+    *dctx = t.dbuf[ThreadState::LANES - 1][ThreadState::SLOTS - 1];
+    C25519_TRY(hipMemcpy(*dctx, blinding, 4 * BLIND_WORDS, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int keypair_batch(unsigned char* pub, unsigned char* priv, const void* blinding, const unsigned char* sk, size_t n)
 {
     if (!pub || !priv || !sk) return bad_arg("null pointer");
     if (n == 0) return 0;
-    return pipelined(n,
-        [&](const Lane& L, size_t lo, size_t c) -> int {
-            C25519_RC(L.up(0, sk + 32 * lo, 32 * c));
-            C25519_RC(L.room(1, 32 * c));
-            C25519_RC(L.room(2, 64 * c));
-            return ed25519_CreateKeyPair_dev(L.ptr(1), L.ptr(2), L.ptr(0), c, L.stream());
-        },
-        [&](const Lane& L, size_t lo, size_t c) -> int {
-            C25519_RC(L.down(pub + 32 * lo, 1, 32 * c));
-            return L.down(priv + 64 * lo, 2, 64 * c);
-        });
+    void* dctx = nullptr;
+    if (blinding) C25519_RC(upload_blinding(&dctx, blinding));
+    return run_batch(n, { Arr{ sk, nullptr, 32 }, Arr{ nullptr, pub, 32 }, Arr{ nullptr, priv, 64 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return keypair_dev(d[1], d[2], d[0], dctx, c, st);
+                     });
+}
+
+int ed25519_CreateKeyPair_batch(unsigned char* pub, unsigned char* priv, const unsigned char* sk, size_t n)
+{
+    return keypair_batch(pub, priv, nullptr, sk, n);
+}
+
+int ed25519_CreateKeyPair_blinded_batch(unsigned char* pub, unsigned char* priv, const void* blinding,
+                                        const unsigned char* sk, size_t n)
+{
+    if (!blinding) return bad_arg("null blinding context");
+    return keypair_batch(pub, priv, blinding, sk, n);
+}
+
+static int sign_batch(unsigned char* sig, const unsigned char* priv, const void* blinding, const unsigned char* msg,
+                      size_t msg_size, size_t n)
+{
+    if (!sig || !priv || (!msg && msg_size)) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    void* dctx = nullptr;
+    if (blinding) C25519_RC(upload_blinding(&dctx, blinding));
+    return run_batch(n, { Arr{ priv, nullptr, 64 }, Arr{ msg, nullptr, msg_size }, Arr{ nullptr, sig, 64 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return sign_dev(d[2], d[0], dctx, Msgs{ (const uint8_t*)d[1], msg_size, nullptr }, c, st);
+                     });
 }
 
 int ed25519_SignMessage_batch(unsigned char* sig, const unsigned char* priv, const unsigned char* msg,
                               size_t msg_size, size_t n)
 {
-    if (!sig || !priv || (!msg && msg_size)) return bad_arg("null pointer");
-    if (n == 0) return 0;
-    return pipelined(n,
-        [&](const Lane& L, size_t lo, size_t c) -> int {
-            C25519_RC(L.up(0, priv + 64 * lo, 64 * c));
-            C25519_RC(L.up(1, msg ? msg + msg_size * lo : nullptr, msg_size * c));
-            C25519_RC(L.room(2, 64 * c));
-            return ed25519_SignMessage_dev(L.ptr(2), L.ptr(0), L.ptr(1), msg_size, c, L.stream());
-        },
-        [&](const Lane& L, size_t lo, size_t c) -> int { return L.down(sig + 64 * lo, 2, 64 * c); });
+    return sign_batch(sig, priv, nullptr, msg, msg_size, n);
+}
+
+int ed25519_SignMessage_blinded_batch(unsigned char* sig, const unsigned char* priv, const void* blinding,
+                                      const unsigned char* msg, size_t msg_size, size_t n)
+{
+    if (!blinding) return bad_arg("null blinding context");
+    return sign_batch(sig, priv, blinding, msg, msg_size, n);
 }
 
 int ed25519_VerifySignature_batch(int* verdict, const unsigned char* sig, const unsigned char* pk,
@@ -1140,32 +1141,45 @@ int ed25519_VerifySignature_batch(int* verdict, const unsigned char* sig, const 
 {
     if (!verdict || !sig || !pk || (!msg && msg_size)) return bad_arg("null pointer");
     if (n == 0) return 0;
-    return pipelined(n,
-        [&](const Lane& L, size_t lo, size_t c) -> int {
-            C25519_RC(L.up(0, sig + 64 * lo, 64 * c));
-            C25519_RC(L.up(1, pk + 32 * lo, 32 * c));
-            C25519_RC(L.up(2, msg ? msg + msg_size * lo : nullptr, msg_size * c));
-            C25519_RC(L.room(3, sizeof(int) * c));
-            return ed25519_VerifySignature_dev(L.ptr(3), L.ptr(0), L.ptr(1), L.ptr(2), msg_size, c, L.stream());
-        },
-        [&](const Lane& L, size_t lo, size_t c) -> int { return L.down(verdict + lo, 3, sizeof(int) * c); });
+    return run_batch(n, { Arr{ sig, nullptr, 64 }, Arr{ pk, nullptr, 32 }, Arr{ msg, nullptr, msg_size },
+                          Arr{ nullptr, verdict, sizeof(int) } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return ed25519_VerifySignature_dev(d[3], d[0], d[1], d[2], msg_size, c, st);
+                     });
 }
 
-// ragged messages: message i is msgs[offsets[i] .. offsets[i+1]); offsets has n+1 entries (host memory)
+// ragged messages: message i is msgs[offsets[i] .. offsets[i+1]); offsets has n+1 entries (host memory).
+// One piece: the message bytes and the offsets are uploaded whole.
+static int ragged_upload(ThreadState& t, void** d_msgs, void** d_off, const unsigned char* msgs, const uint64_t* offsets,
+                         size_t n)
+{
+    const int L = ThreadState::LANES - 1;
+    C25519_RC(t.reserve_dev(L, 3, (size_t)offsets[n]));
+    C25519_RC(t.reserve_dev(L, 4, sizeof(uint64_t) * (n + 1)));
+    *d_msgs = t.dbuf[L][3];
+    *d_off = t.dbuf[L][4];
+    if (offsets[n]) C25519_TRY(hipMemcpyAsync(*d_msgs, msgs, (size_t)offsets[n], hipMemcpyHostToDevice, t.stream[L]));
+    C25519_TRY(hipMemcpyAsync(*d_off, offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, t.stream[L]));
+    return 0;
+}
+
 int ed25519_SignMessage_ragged_batch(unsigned char* sig, const unsigned char* priv, const unsigned char* msgs,
                                      const uint64_t* offsets, size_t n)
 {
     if (!sig || !priv || !offsets) return bad_arg("null pointer");
     if (n == 0) return 0;
-    Staging& s = staging();
-    C25519_RC(s.ensure_stream());
-    C25519_RC(up(s, 0, priv, 64 * n));
-    C25519_RC(up(s, 1, msgs, (size_t)offsets[n]));
-    C25519_RC(s.reserve(2, 64 * n));
-    C25519_RC(up(s, 3, offsets, sizeof(uint64_t) * (n + 1)));
-    C25519_RC(ed25519_SignMessage_ragged_dev(s.ptr[2], s.ptr[0], s.ptr[1], (const uint64_t*)s.ptr[3], n, s.stream));
-    C25519_RC(down(s, sig, 2, 64 * n));
-    C25519_TRY(hipStreamSynchronize(s.stream));
+    ThreadState& t = tls();
+    C25519_RC(t.ensure());
+    const int L = ThreadState::LANES - 1;
+    hipStream_t st = t.stream[L];
+    void *d_msgs, *d_off;
+    C25519_RC(ragged_upload(t, &d_msgs, &d_off, msgs, offsets, n));
+    C25519_RC(t.reserve_dev(L, 0, 64 * n));
+    C25519_RC(t.reserve_dev(L, 1, 64 * n));
+    C25519_TRY(hipMemcpyAsync(t.dbuf[L][0], priv, 64 * n, hipMemcpyHostToDevice, st));
+    C25519_RC(ed25519_SignMessage_ragged_dev(t.dbuf[L][1], t.dbuf[L][0], d_msgs, (const uint64_t*)d_off, n, st));
+    C25519_TRY(hipMemcpyAsync(sig, t.dbuf[L][1], 64 * n, hipMemcpyDeviceToHost, st));
+    C25519_TRY(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -1174,17 +1188,20 @@ int ed25519_VerifySignature_ragged_batch(int* verdict, const unsigned char* sig,
 {
     if (!verdict || !sig || !pk || !offsets) return bad_arg("null pointer");
     if (n == 0) return 0;
-    Staging& s = staging();
-    C25519_RC(s.ensure_stream());
-    C25519_RC(up(s, 0, sig, 64 * n));
-    C25519_RC(up(s, 1, pk, 32 * n));
-    C25519_RC(up(s, 2, msgs, (size_t)offsets[n]));
-    C25519_RC(s.reserve(3, sizeof(int) * n));
-    C25519_RC(up(s, 4, offsets, sizeof(uint64_t) * (n + 1)));
-    C25519_RC(ed25519_VerifySignature_ragged_dev(s.ptr[3], s.ptr[0], s.ptr[1], s.ptr[2], (const uint64_t*)s.ptr[4], n,
-                                                 s.stream));
-    C25519_RC(down(s, verdict, 3, sizeof(int) * n));
-    C25519_TRY(hipStreamSynchronize(s.stream));
+    ThreadState& t = tls();
+    C25519_RC(t.ensure());
+    const int L = ThreadState::LANES - 1;
+    hipStream_t st = t.stream[L];
+    void *d_msgs, *d_off;
+    C25519_RC(ragged_upload(t, &d_msgs, &d_off, msgs, offsets, n));
+    C25519_RC(t.reserve_dev(L, 0, 64 * n));
+    C25519_RC(t.reserve_dev(L, 1, 32 * n));
+    C25519_RC(t.reserve_dev(L, 2, sizeof(int) * n));
+    C25519_TRY(hipMemcpyAsync(t.dbuf[L][0], sig, 64 * n, hipMemcpyHostToDevice, st));
+    C25519_TRY(hipMemcpyAsync(t.dbuf[L][1], pk, 32 * n, hipMemcpyHostToDevice, st));
+    C25519_RC(ed25519_VerifySignature_ragged_dev(t.dbuf[L][2], t.dbuf[L][0], t.dbuf[L][1], d_msgs, (const uint64_t*)d_off, n, st));
+    C25519_TRY(hipMemcpyAsync(verdict, t.dbuf[L][2], sizeof(int) * n, hipMemcpyDeviceToHost, st));
+    C25519_TRY(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -1207,15 +1224,13 @@ void curve25519_dh_CreateSharedKey(unsigned char* shared, const unsigned char* p
 
 void ed25519_CreateKeyPair(unsigned char* pubKey, unsigned char* privKey, const void* blinding, const unsigned char* sk)
 {
-    (void)blinding;                           // output-neutral in the reference (ed25519_sign.c:254-263)
-    if (int rc = ed25519_CreateKeyPair_batch(pubKey, privKey, sk, 1)) c25519_host::die(__func__, rc);
+    if (int rc = keypair_batch(pubKey, privKey, blinding, sk, 1)) c25519_host::die(__func__, rc);
 }
 
 void ed25519_SignMessage(unsigned char* signature, const unsigned char* privKey, const void* blinding,
                          const unsigned char* msg, size_t msg_size)
 {
-    (void)blinding;
-    if (int rc = ed25519_SignMessage_batch(signature, privKey, msg, msg_size, 1)) c25519_host::die(__func__, rc);
+    if (int rc = sign_batch(signature, privKey, blinding, msg, msg_size, 1)) c25519_host::die(__func__, rc);
 }
 
 int ed25519_VerifySignature(const unsigned char* signature, const unsigned char* publicKey, const unsigned char* msg,
@@ -1227,26 +1242,36 @@ int ed25519_VerifySignature(const unsigned char* signature, const unsigned char*
     return verdict;
 }
 
-// Blinding contexts: accepted and carried for API compatibility; they hold the caller's seed digest
-// position only (no arithmetic depends on them, matching the reference's observable behaviour).
-struct blinding_ctx { unsigned char opaque[192]; };
-
+// Blinding contexts (ed25519_sign.c:289-341): 192 bytes, the reference's EDP_BLINDING_CTX shape (bl, zr, BP), derived
+// ON THE DEVICE from the caller's seed; the context lives in the caller's storage or is malloc'ed here, exactly as in
+// the reference.  Signing / key generation with a context computes (k + bl)*B + BP from a randomised starting point
+// (lanes.cuh), so the walk and its table lookups see a scalar that differs per context; outputs are unchanged.
 void* ed25519_Blinding_Init(void* context, const unsigned char* seed, size_t size)
 {
-    blinding_ctx* ctx = (blinding_ctx*)context;
-    if (!ctx) {
-        ctx = (blinding_ctx*)malloc(sizeof(blinding_ctx));
-        if (!ctx) return nullptr;
-    }
-    memset(ctx->opaque, 0, sizeof ctx->opaque);
-    for (size_t i = 0; i < size; i++) ctx->opaque[i % sizeof ctx->opaque] ^= seed[i];
+    void* ctx = context ? context : malloc(4 * BLIND_WORDS);
+    if (!ctx) return nullptr;                  // allocation failure is the only error the reference reports (:306)
+    ThreadState& t = tls();
+    auto run = [&]() -> int {
+        C25519_RC(t.ensure());
+        const int L = ThreadState::LANES - 1;
+        C25519_RC(t.reserve_dev(L, 0, 4 * BLIND_WORDS));
+        C25519_RC(t.reserve_dev(L, 1, size ? size : 1));
+        if (size) C25519_TRY(hipMemcpyAsync(t.dbuf[L][1], seed, size, hipMemcpyHostToDevice, t.stream[L]));
+        C25519_RC(ed25519_Blinding_Init_dev(t.dbuf[L][0], t.dbuf[L][1], size, t.stream[L]));
+        C25519_TRY(hipMemcpyAsync(ctx, t.dbuf[L][0], 4 * BLIND_WORDS, hipMemcpyDeviceToHost, t.stream[L]));
+        C25519_TRY(hipMemsetAsync(t.dbuf[L][0], 0, 4 * BLIND_WORDS, t.stream[L]));
+        if (size) C25519_TRY(hipMemsetAsync(t.dbuf[L][1], 0, size, t.stream[L]));
+        C25519_TRY(hipStreamSynchronize(t.stream[L]));
+        return 0;
+    };
+    if (int rc = run()) c25519_host::die(__func__, rc);
     return ctx;
 }
 
 void ed25519_Blinding_Finish(void* context)
 {
     if (context) {
-        memset(context, 0, sizeof(blinding_ctx));
+        memset(context, 0, 4 * BLIND_WORDS);
         free(context);
     }
 }
@@ -1258,14 +1283,10 @@ int ed25519_Verify_Init_batch(void* ctx, const unsigned char* pk, size_t n)
 {
     if (!ctx || !pk) return bad_arg("null pointer");
     if (n == 0) return 0;
-    Staging& s = staging();
-    C25519_RC(s.ensure_stream());
-    C25519_RC(up(s, 0, pk, 32 * n));
-    C25519_RC(s.reserve(1, 2080 * n));
-    C25519_RC(ed25519_Verify_Init_dev(s.ptr[1], s.ptr[0], n, s.stream));
-    C25519_RC(down(s, ctx, 1, 2080 * n));
-    C25519_TRY(hipStreamSynchronize(s.stream));
-    return 0;
+    return run_batch(n, { Arr{ pk, nullptr, 32 }, Arr{ nullptr, ctx, 2080 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return ed25519_Verify_Init_dev(d[1], d[0], c, st);
+                     });
 }
 
 int ed25519_Verify_Check_batch(int* verdict, const void* ctx, const unsigned char* sig, const unsigned char* msg,
@@ -1273,16 +1294,15 @@ int ed25519_Verify_Check_batch(int* verdict, const void* ctx, const unsigned cha
 {
     if (!verdict || !ctx || !sig || (!msg && msg_size)) return bad_arg("null pointer");
     if (n == 0) return 0;
-    Staging& s = staging();
-    C25519_RC(s.ensure_stream());
-    C25519_RC(up(s, 0, sig, 64 * n));
-    C25519_RC(up(s, 1, ctx, 2080));
-    C25519_RC(up(s, 2, msg, msg_size * n));
-    C25519_RC(s.reserve(3, sizeof(int) * n));
-    C25519_RC(ed25519_Verify_Check_dev(s.ptr[3], s.ptr[1], s.ptr[0], s.ptr[2], msg_size, n, s.stream));
-    C25519_RC(down(s, verdict, 3, sizeof(int) * n));
-    C25519_TRY(hipStreamSynchronize(s.stream));
-    return 0;
+    ThreadState& t = tls();
+    C25519_RC(t.ensure());
+    C25519_RC(t.reserve_dev(ThreadState::LANES - 1, ThreadState::SLOTS - 1, 2080));
+    void* dctx = t.dbuf[ThreadState::LANES - 1][ThreadState::SLOTS - 1];
+    C25519_TRY(hipMemcpy(dctx, ctx, 2080, hipMemcpyHostToDevice));
+    return run_batch(n, { Arr{ sig, nullptr, 64 }, Arr{ msg, nullptr, msg_size }, Arr{ nullptr, verdict, sizeof(int) } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return ed25519_Verify_Check_dev(d[2], dctx, d[0], d[1], msg_size, c, st);
+                     });
 }
 
 void* ed25519_Verify_Init(void* context, const unsigned char* publicKey)

@@ -23,15 +23,14 @@
 //   fe_sqr(a)        : needs beta_a <= 3.3
 // tools/fe_bounds.py replays every formula in the kernels against this contract.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+// The handful of gfx950 instruction sequences the field layer is built from (v_mad_u64_u32 column chains,
+// v_add_u32 doubling) live in valu_gfx950.cuh.  The CPU unit tests of THIS source (tests/host_emul/) pre-include
+// a C model of exactly those primitives and define C25519_VALU_PRIMITIVES; the product build never does.
+#ifndef C25519_VALU_PRIMITIVES
+#include "valu_gfx950.cuh"
+#endif
 
 namespace c25519 {
-
-typedef uint32_t u32;
-typedef uint64_t u64;
-
-#define C25519_DEV __device__ __forceinline__
 
 constexpr u32 M26 = 0x3ffffffu;
 constexpr u32 M25 = 0x1ffffffu;
@@ -70,26 +69,9 @@ C25519_DEV void fe_neg(fe& r, const fe& a)
     for (int i = 0; i < 10; i++) r.v[i] = fe_2p(i) - a.v[i];
 }
 
-// 2x as v_add_u32 x, x: on gfx950 v_add_u32 issues at the fast VOP2 rate (~24 lanes/clk/SIMD) while
-// v_lshlrev_b32 -- what the compiler picks for x*2 or x+x -- runs at the slower VOP3-class rate (~15.8), see
-// profiles/r01_valu_rates_select_shift.txt.
-C25519_DEV u32 dbl32(u32 x)
-{
-#ifdef C25519_DBL_BY_SHIFT
-    return x * 2u;
-#else
-    u32 r;
-    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
-    return r;
-#endif
-}
-
 // branch-free select: r = mask ? a : b, mask is all-ones or zero
 C25519_DEV void fe_select(fe& r, u32 mask, const fe& a, const fe& b)
 {
-#ifdef C25519_SELECT_BFI
-    asm("" : "+v"(mask));                 // keep it a bitwise select (v_bfi_b32) instead of v_cndmask on vcc
-#endif
 #pragma unroll
     for (int i = 0; i < 10; i++) r.v[i] = (a.v[i] & mask) | (b.v[i] & ~mask);
 }
@@ -115,64 +97,8 @@ C25519_DEV void fe_carry64(fe& r, u64 (&h)[10])
 // ---- chained-carry products --------------------------------------------------------------------------------
 // v_mad_u64_u32 adds a 64-bit value for free.  If the chain of MADs of column k+1 STARTS from the carry out of
 // column k, the carry propagation costs a 64-bit shift and a mask per limb and no separate 64-bit add (saves
-// 9 v_lshl_add_u64 per product).  Written with the MAD as an asm statement because the compiler's
-// reassociation otherwise moves the carry back to the end of each chain.
-#ifndef C25519_CHAINED
-#define C25519_CHAINED 1
-#endif
-
-// acc += sum x[t]*y[t]: one asm statement per column, so the compiler cannot reassociate the chain and does
-// not pad every MAD with a wait state (it pads asm boundaries only)
-C25519_DEV u64 mad_chain5(u64 acc, const u32 (&x)[5], const u32 (&y)[5])
-{
-    u64 carry_out;
-    asm(
-        "v_mad_u64_u32 %0, %1, %2, %7, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %3, %8, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %4, %9, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %5, %10, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %6, %11, %0"
-        : "+v"(acc), "=s"(carry_out)
-        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]),
-          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]));
-    return acc;
-}
-
-C25519_DEV u64 mad_chain6(u64 acc, const u32 (&x)[6], const u32 (&y)[6])
-{
-    u64 carry_out;
-    asm(
-        "v_mad_u64_u32 %0, %1, %2, %8, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %3, %9, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %4, %10, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %5, %11, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %6, %12, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %7, %13, %0"
-        : "+v"(acc), "=s"(carry_out)
-        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
-          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]));
-    return acc;
-}
-
-C25519_DEV u64 mad_chain10(u64 acc, const u32 (&x)[10], const u32 (&y)[10])
-{
-    u64 carry_out;
-    asm(
-        "v_mad_u64_u32 %0, %1, %2, %12, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %3, %13, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %4, %14, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %5, %15, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %6, %16, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %7, %17, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %8, %18, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %9, %19, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %10, %20, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %11, %21, %0"
-        : "+v"(acc), "=s"(carry_out)
-        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]),
-          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8]), "v"(y[9]));
-    return acc;
-}
+// 9 v_lshl_add_u64 per product).  mad_chain5/6/10 (valu_gfx950.cuh) are one asm statement per column because
+// the compiler's reassociation otherwise moves the carry back to the end of each chain.
 
 // limbs l[0..9] hold the masked columns, `carry` is what left column 9: fold it back times 19
 C25519_DEV void fe_finish_chain(fe& r, u32 (&l)[10], u64 carry)
@@ -259,108 +185,27 @@ C25519_DEV void fe_sqr_chained(fe& r, const fe& a, Extra extra)
 // r = a * b.   beta_a <= 5, beta_b <= 3.3; r may alias a or b.   (ecp_MulReduce)
 C25519_DEV void fe_mul(fe& r, const fe& a, const fe& b)
 {
-#if C25519_CHAINED
     fe_mul_chained(r, a, b);
-    return;
-#endif
-    u32 b19[10], a2[10];
-#pragma unroll
-    for (int j = 1; j < 10; j++) b19[j] = b.v[j] * 19u;
-#pragma unroll
-    for (int i = 1; i < 10; i += 2) a2[i] = dbl32(a.v[i]);
-
-    u64 h[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-        u64 acc = 0;
-#pragma unroll
-        for (int i = 0; i < 10; i++) {
-            const int j = (k - i + 10) % 10;
-            const bool wrap = i > k;                       // i + j = k + 10
-            const bool odd2 = (i & 1) && (j & 1);          // 2^25.5 radix: odd*odd picks up a factor 2
-            const u32 x = odd2 ? a2[i] : a.v[i];
-            const u32 y = wrap ? b19[j] : b.v[j];
-            acc += (u64)x * y;
-        }
-        h[k] = acc;
-    }
-    fe_carry64(r, h);
-}
-
-// column sums of a^2 (55 products instead of 100).   beta_a <= 3.3
-C25519_DEV void fe_sqr_columns(u64 (&h)[10], const fe& a)
-{
-    u32 f2[10], f19[10], f38[10];
-#pragma unroll
-    for (int i = 0; i < 10; i++) f2[i] = dbl32(a.v[i]);
-#pragma unroll
-    for (int j = 6; j < 10; j += 2) f19[j] = a.v[j] * 19u;
-#pragma unroll
-    for (int j = 5; j < 10; j += 2) f38[j] = a.v[j] * 38u;
-
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-        u64 acc = 0;
-#pragma unroll
-        for (int i = 0; i < 10; i++) {
-            const int j = (k - i + 10) % 10;
-            if (i > j) continue;                           // each unordered pair once
-            const bool wrap = (i + j) >= 10;
-            const bool odd2 = (i & 1) && (j & 1);
-            u32 x, y;
-            if (wrap && (j & 1)) {
-                x = (i < j && (i & 1)) ? f2[i] : a.v[i];
-                y = f38[j];
-            } else {
-                x = (i < j) ? f2[i] : a.v[i];
-                y = wrap ? f19[j] : (odd2 ? f2[j] : a.v[j]);
-            }
-            acc += (u64)x * y;
-        }
-        h[k] = acc;
-    }
 }
 
 // r = a^2.   beta_a <= 3.3; r may alias a.   (ecp_SqrReduce)
 C25519_DEV void fe_sqr(fe& r, const fe& a)
 {
-#if C25519_CHAINED
     fe_sqr_chained<false>(r, a, [](int) -> u64 { return 0; });
-    return;
-#endif
-    u64 h[10];
-    fe_sqr_columns(h, a);
-    fe_carry64(r, h);
 }
 
 // r = a^2 - m with the subtraction folded into the carry chain (result reduced).
 // beta_a <= 3.3, beta_m <= 2 (bias 4p).
 C25519_DEV void fe_sqr_sub(fe& r, const fe& a, const fe& m)
 {
-#if C25519_CHAINED
     fe_sqr_chained<false>(r, a, [&](int k) -> u64 { return (u64)(2u * fe_2p(k) - m.v[k]); });
-    return;
-#endif
-    u64 h[10];
-    fe_sqr_columns(h, a);
-#pragma unroll
-    for (int i = 0; i < 10; i++) h[i] += (u64)(2u * fe_2p(i) - m.v[i]);
-    fe_carry64(r, h);
 }
 
 // r = 2*a^2 + p - m, folded into the carry chain (result reduced).
 // beta_a <= 2.3 (columns are doubled), p any beta < 8, m reduced (bias 2p).
 C25519_DEV void fe_sqr2_add_sub(fe& r, const fe& a, const fe& p, const fe& m)
 {
-#if C25519_CHAINED
     fe_sqr_chained<true>(r, a, [&](int k) -> u64 { return (u64)(p.v[k] + fe_2p(k) - m.v[k]); });
-    return;
-#endif
-    u64 h[10];
-    fe_sqr_columns(h, a);
-#pragma unroll
-    for (int i = 0; i < 10; i++) h[i] = 2 * h[i] + (u64)(p.v[i] + fe_2p(i) - m.v[i]);
-    fe_carry64(r, h);
 }
 
 C25519_DEV void fe_sqr_n(fe& r, const fe& a, int n)
@@ -412,14 +257,14 @@ C25519_DEV void fe_carry32(fe& r, const fe& a)
 C25519_DEV void fe_from_words(fe& r, const u32 (&w)[8])
 {
     r.v[0] = (w[0] & M26) + 19u * (w[7] >> 31);
-    r.v[1] = __builtin_amdgcn_alignbit(w[1], w[0], 26) & M25;
-    r.v[2] = __builtin_amdgcn_alignbit(w[2], w[1], 19) & M26;
-    r.v[3] = __builtin_amdgcn_alignbit(w[3], w[2], 13) & M25;
+    r.v[1] = alignbit32(w[1], w[0], 26) & M25;
+    r.v[2] = alignbit32(w[2], w[1], 19) & M26;
+    r.v[3] = alignbit32(w[3], w[2], 13) & M25;
     r.v[4] = w[3] >> 6;
     r.v[5] = w[4] & M25;
-    r.v[6] = __builtin_amdgcn_alignbit(w[5], w[4], 25) & M26;
-    r.v[7] = __builtin_amdgcn_alignbit(w[6], w[5], 19) & M25;
-    r.v[8] = __builtin_amdgcn_alignbit(w[7], w[6], 12) & M26;
+    r.v[6] = alignbit32(w[5], w[4], 25) & M26;
+    r.v[7] = alignbit32(w[6], w[5], 19) & M25;
+    r.v[8] = alignbit32(w[7], w[6], 12) & M26;
     r.v[9] = (w[7] >> 6) & M25;
 }
 

@@ -100,13 +100,22 @@ C25519_DEV void ge_to_pe(ge_pe& r, const ge_ext& p)
 }
 
 // extended point from a precomputed row: (2x, 2y, 2z, 2xy) -- ed25519_sign.c:226-230 / ed25519_verify.c:258-262
-C25519_DEV void ge_from_pa(ge_ext& s, const ge_pa& q)
+// zr = nullptr: Z = 2 (R = 1; the reference's R is output-neutral).  With a blinding context the starting point is
+// spread over the projective class by the context's random R exactly as the reference does (ed25519_sign.c:232-237).
+C25519_DEV void ge_from_pa(ge_ext& s, const ge_pa& q, const fe* zr = nullptr)
 {
     fe t;
     fe_sub(t, q.ypx, q.ymx);  fe_carry32(s.X, t);
     fe_add(t, q.ypx, q.ymx);  fe_carry32(s.Y, t);
     fe_mul(s.T, q.t2d, fe_const(K_DI));
-    fe_set_u32(s.Z, 2);                            // Z = 2R with R = 1 (the reference's random R is output-neutral)
+    if (!zr) {
+        fe_set_u32(s.Z, 2);
+        return;
+    }
+    fe_add(t, *zr, *zr);  fe_carry32(s.Z, t);      // Z = 2R
+    fe_mul(s.X, s.X, *zr);                         // X = 2xR
+    fe_mul(s.T, s.T, *zr);                         // T = 2xyR
+    fe_mul(s.Y, s.Y, *zr);                         // Y = 2yR
 }
 
 C25519_DEV void ge_from_pe(ge_ext& s, const ge_pe& q)
@@ -193,16 +202,18 @@ C25519_DEV u32 fold8_at(const u32 (&k)[8], int n)
 //     sum_n 2^(31-n) T[c_n]  =  sum_{m<step} 2^(step-1-m) * sum_{t<BASE_NT} T_t[c_(t*step+m)]
 // i.e. step-1 doublings and 31 additions instead of 31 doublings and 31 additions -- the same point, hence the
 // same canonical bytes after the inversion.  BASE_NT = 4: 7 doublings, 120 KiB of LDS (MI355X has 160 KiB per
-// CU), shared by a 512-thread workgroup.  lds_tbl holds T_0 .. T_(BASE_NT-1) (= T itself), limb-major each.
+// CU), shared by a 1024-thread workgroup (BM_BLOCK).  lds_tbl holds T_0 .. T_(BASE_NT-1) (= T itself), limb-major each.
 constexpr int BASE_NT = 4;
 constexpr int BASE_STEP = 32 / BASE_NT;
 constexpr int BASE_TBL_WORDS = PA_WORDS * 256;
 
-C25519_DEV void ge_base_mult(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl)
+// FINAL_T: also produce T of the result (needed when another addition follows, i.e. the blinding point).
+template <bool FINAL_T = false>
+C25519_DEV void ge_base_mult(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl, const fe* zr = nullptr)
 {
     ge_pa q;
     lds_load_pa(q, lds_tbl, fold8_at(k, 0));
-    ge_from_pa(S, q);
+    ge_from_pa(S, q, zr);
 #pragma unroll 1
     for (int m = 0; m < BASE_STEP; m++) {
         if (m) ge_double(S);
@@ -215,7 +226,8 @@ C25519_DEV void ge_base_mult(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl)
         }
         // last table: a doubling or the affine conversion follows, neither reads T
         lds_load_pa(q, lds_tbl + (BASE_NT - 1) * BASE_TBL_WORDS, fold8_at(k, (BASE_NT - 1) * BASE_STEP + m));
-        ge_add_pa<false>(S, q);
+        if (FINAL_T && m == BASE_STEP - 1) ge_add_pa<true>(S, q);
+        else ge_add_pa<false>(S, q);
     }
 }
 

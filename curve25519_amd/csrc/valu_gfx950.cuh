@@ -1,0 +1,88 @@
+// curve25519_amd/csrc/valu_gfx950.cuh -- the gfx950 instruction sequences the field layer is built from.
+//
+// Everything above this file (fe25519.cuh, ge25519.cuh, sc25519.cuh, sha512.cuh, x25519.cuh) is plain C++ over
+// these primitives, so the CPU unit tests can run that same source against a C model of them
+// (tests/host_emul/valu_model.h).  This header is the only one with inline assembly.
+//
+// Measured issue classes on MI355X (tools/ubench/valu_rates.hip, profiles/r02_valu_rates.txt):
+//   v_mad_u64_u32                      one per ~4.3 cycles per wave   (32x32+64 -> 64, carry-out to an SGPR pair)
+//   v_lshrrev_b64 / v_mul_lo_u32 / ... one per ~4 cycles   ("half-rate" class: shifts, 64-bit, VOP3 integer)
+//   v_add_u32 / v_and_b32 / v_sub_u32  one per ~2 cycles   ("full-rate" class)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace c25519 {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define C25519_DEV __device__ __forceinline__
+
+// 2x as v_add_u32 x, x: v_add_u32 is full-rate, while v_lshlrev_b32 -- what the compiler picks for x*2 or x+x --
+// is in the half-rate class.
+C25519_DEV u32 dbl32(u32 x)
+{
+    u32 r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// (hi:lo) >> s, low 32 bits   (v_alignbit_b32)
+C25519_DEV u32 alignbit32(u32 hi, u32 lo, int s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+
+// acc += sum x[t]*y[t]: one asm statement per column, so the compiler cannot reassociate the chain (it would move
+// the carry-in to the end and re-create a separate 64-bit add) and does not pad every MAD with a wait state (it pads
+// asm boundaries only).  The SGPR pair receives the (never set) carry-out.
+C25519_DEV u64 mad_chain5(u64 acc, const u32 (&x)[5], const u32 (&y)[5])
+{
+    u64 carry_out;
+    asm(
+        "v_mad_u64_u32 %0, %1, %2, %7, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %3, %8, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %4, %9, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %5, %10, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %11, %0"
+        : "+v"(acc), "=s"(carry_out)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]),
+          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]));
+    return acc;
+}
+
+C25519_DEV u64 mad_chain6(u64 acc, const u32 (&x)[6], const u32 (&y)[6])
+{
+    u64 carry_out;
+    asm(
+        "v_mad_u64_u32 %0, %1, %2, %8, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %3, %9, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %4, %10, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %5, %11, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %12, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %7, %13, %0"
+        : "+v"(acc), "=s"(carry_out)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
+          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]));
+    return acc;
+}
+
+C25519_DEV u64 mad_chain10(u64 acc, const u32 (&x)[10], const u32 (&y)[10])
+{
+    u64 carry_out;
+    asm(
+        "v_mad_u64_u32 %0, %1, %2, %12, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %3, %13, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %4, %14, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %5, %15, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %16, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %7, %17, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %8, %18, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %9, %19, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %10, %20, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %11, %21, %0"
+        : "+v"(acc), "=s"(carry_out)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]),
+          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8]), "v"(y[9]));
+    return acc;
+}
+
+}  // namespace c25519

@@ -11,7 +11,7 @@
 //
 // The reference selects (P,Q) by pointer swap (ECP_MONT, :89).  Here the differential addition is
 // symmetric in its two inputs, so the state is kept as (S = sum, D = double) and only the INPUT OF
-// THE DOUBLING is selected per bit with v_bfi_b32 -- 20 selects per step instead of a 40-limb swap,
+// THE DOUBLING is selected per bit (the compiler emits v_cndmask_b32) -- 20 selects per step instead of a 40-limb swap,
 // no secret-dependent branch or address.
 #pragma once
 #include "fe25519.cuh"

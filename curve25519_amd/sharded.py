@@ -92,7 +92,10 @@ class HipEngine:
     def __init__(self, device=None):
         from . import api
         self.api = api
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if device.index is None:                        # "cuda" -> the current device's ordinal, so that tensor.device
+            device = torch.device("cuda", torch.cuda.current_device())   # comparisons in api.py are exact
+        self.device = device
 
     def _empty(self, n, w, dtype=torch.uint8):
         return torch.empty((n, w), dtype=dtype, device=self.device)

@@ -34,6 +34,11 @@ const char *c25519_amd_version(void);
 const char *c25519_amd_last_error(void);               /* per-thread, "" when none */
 int  c25519_amd_device_count(void);                    /* usable HIP devices (0 when none) */
 int  c25519_amd_set_device(int device);                /* device used by this host thread */
+/* Each host thread that calls into the library owns three streams, pinned + device staging buffers and a work
+ * scratch slab, all on the device that was current at its first call (they follow the thread to another device on
+ * the next call, released on the old one first).  They are freed when the thread exits; a long-lived thread can
+ * give them back earlier with this call.  Staging buffers are zeroed before they are freed. */
+void c25519_amd_thread_release(void);
 
 /* X25519 ------------------------------------------------------------------------------------ */
 /* n x curve25519_dh_CreateSharedKey (reference include/curve25519_dh.h:45); sk is clamped in place */
@@ -59,6 +64,22 @@ int ed25519_SignMessage_batch(unsigned char *sig, const unsigned char *priv, con
                               size_t msg_size, size_t n);
 int ed25519_SignMessage_dev(void *sig, const void *priv, const void *msg, size_t msg_size, size_t n,
                             void *stream);
+
+/* Blinding (reference include/ed25519_signature.h:54-64, source/ed25519_sign.c:246-331).  A context is 192 bytes --
+ * the reference's EDP_BLINDING_CTX size: scalar bl = L - t, 32 random bytes zr, and t*B as four canonical 32-byte
+ * elements.  ed25519_Blinding_Init (declared in ed25519_signature.h) derives it ON THE DEVICE from the caller's seed;
+ * the functions below take ONE context for the whole batch and compute (k + bl)*B + BP from a Z-randomised starting
+ * point, so the walk and its secret-indexed table lookups see a different scalar under every context.  Outputs are
+ * byte-identical to the unblinded calls (as in the reference). */
+int ed25519_Blinding_Init_dev(void *ctx /* 192 bytes */, const void *seed, size_t seed_len, void *stream);
+int ed25519_CreateKeyPair_blinded_batch(unsigned char *pub, unsigned char *priv, const void *blinding,
+                                        const unsigned char *sk, size_t n);
+int ed25519_CreateKeyPair_blinded_dev(void *pub, void *priv, const void *blinding, const void *sk, size_t n,
+                                      void *stream);
+int ed25519_SignMessage_blinded_batch(unsigned char *sig, const unsigned char *priv, const void *blinding,
+                                      const unsigned char *msg, size_t msg_size, size_t n);
+int ed25519_SignMessage_blinded_dev(void *sig, const void *priv, const void *blinding, const void *msg,
+                                    size_t msg_size, size_t n, void *stream);
 
 /* the same with messages of different lengths: message i is msgs[offsets[i] .. offsets[i+1]),
  * offsets has n+1 entries (host memory for _batch, device memory for _dev) */
@@ -107,8 +128,21 @@ int c25519_amd_verify_point_dev(void *out, const void *sig, const void *pk, cons
 
 /* device field arithmetic on n pairs of 32-byte little-endian values taken mod p = 2^255-19 (host pointers):
  * out[i] = canonical(op(a[i], b[i])), op 0 mul, 1 square, 2 add, 3 sub, 4 inverse, 5 a^((p-5)/8),
- * 6 canonicalise, 7 (a-b)*(a+b).  The unit-test hook for the L0 layer (the reference's ECP_SELF_TEST checks). */
+ * 6 canonicalise, 7 (a-b)*(a+b), 8 a^2-b, 9 2a^2+(a+b)-b, 10 a+121665b, 11 9a.
+ * The unit-test hook for the L0 layer (the reference's ECP_SELF_TEST checks, test/curve25519_selftest.c:640-741). */
 int c25519_amd_fe_selftest(unsigned char *out, const unsigned char *a, const unsigned char *b, size_t n, int op);
+
+/* device scalar arithmetic mod L (reference source/curve25519_order.c, unit checks test/curve25519_selftest.c:624-714):
+ * a is n x 64 bytes (512-bit little-endian), b n x 32 bytes, out n x 32 bytes.
+ *   op 0 canonical(a mod L)   1 raw a mod L            2 canonical(a[0..31] mod L)   3 raw a[0..31]*b
+ *   op 4 raw a[0..31]+b       5 raw a[32..35]*2^256 + a[0..31]   (eco_ReduceHiWord)  6 canonical(a[0..31]*b + a[32..63])
+ * "raw" = 256 bits congruent to the exact value mod L, not necessarily below L. */
+int c25519_amd_sc_selftest(unsigned char *out, const unsigned char *a, const unsigned char *b, size_t n, int op);
+
+/* fold recodings of n 32-byte scalars (reference ecp_8Folds / ecp_4Folds, source/curve25519_utils.c:144 / :125):
+ * out is n x 128 bytes: the 32 8-fold columns as the fixed-base walk indexes them, the same 32 as the verification
+ * walk consumes them, and the 64 4-fold columns. */
+int c25519_amd_fold_selftest(unsigned char *out, const unsigned char *k, size_t n);
 
 #ifdef __cplusplus
 }

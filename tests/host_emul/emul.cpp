@@ -1,0 +1,233 @@
+// tests/host_emul/emul.cpp -- TEST INFRASTRUCTURE.  Drives the device headers of curve25519_amd/csrc (compiled for
+// the host against the C model of the gfx950 primitives, valu_model.h) one lane at a time, the way the kernels of
+// engine.hip drive them per lane.  Exposes a plain C interface for tests/test_host_emul.py.  The point is to test the
+// DEVICE SOURCE (field / scalar / group / hashing / lane logic) on a CPU-only machine; the GPU tests then only have
+// to establish that the kernels' indexing, LDS staging and scratch plumbing around these functions are right.
+// Not part of the product and not a fallback: libcurve25519_amd.so contains no host arithmetic.
+#include "lanes.cuh"
+
+#include <mutex>
+#include <vector>
+
+using namespace c25519;
+
+namespace c25519 { unsigned long long emul_mad_overflows = 0; }
+
+namespace {
+
+std::vector<u32> g_tbl;                 // [BASE_NT][30][256] limb-major, as k_gen_base_table lays it out
+std::vector<u32> g_tbl_bytes;           // [256][24]
+std::once_flag g_tbl_once;
+
+void build_tables()
+{
+    g_tbl.assign((size_t)BASE_NT * BASE_TBL_WORDS, 0);
+    g_tbl_bytes.assign(256 * 24, 0);
+    for (int group = 0; group < BASE_NT; group++) {
+        const int extra = (BASE_NT - 1 - group) * BASE_STEP;
+        for (u32 k = 0; k < 256; k++) {
+            u32 rows[3][8];
+            ge_base_table_row(rows, k, extra);
+            for (int f = 0; f < 3; f++) {
+                fe c;
+                fe_from_words(c, rows[f]);
+                for (int l = 0; l < 10; l++) g_tbl[(size_t)group * BASE_TBL_WORDS + (10 * f + l) * 256 + k] = c.v[l];
+                if (extra == 0)
+                    for (int j = 0; j < 8; j++) g_tbl_bytes[k * 24 + 8 * f + j] = rows[f][j];
+            }
+        }
+    }
+}
+
+const u32* tables()
+{
+    std::call_once(g_tbl_once, build_tables);
+    return g_tbl.data();
+}
+
+void rd32(u32 (&w)[8], const unsigned char* p, size_t i) { memcpy(w, p + 32 * i, 32); }
+void wr32(unsigned char* p, size_t i, const u32 (&w)[8]) { memcpy(p + 32 * i, w, 32); }
+
+void affine_pack_host(u32 (&enc)[8], const ge_ext& S)
+{
+    u32 xw[8], yw[8];
+    ge_to_affine_words(xw, yw, S);
+    ge_pack(enc, xw, yw);
+}
+
+}  // namespace
+
+extern "C" {
+
+unsigned long long emul_mad_overflow_count(void) { return emul_mad_overflows; }
+
+void emul_fe_op(unsigned char* out, const unsigned char* a, const unsigned char* b, size_t n, int op)
+{
+    for (size_t i = 0; i < n; i++) {
+        u32 aw[8], bw[8], ow[8];
+        rd32(aw, a, i); rd32(bw, b, i);
+        fe_selftest_op(ow, aw, bw, op);
+        wr32(out, i, ow);
+    }
+}
+
+void emul_sc_op(unsigned char* out, const unsigned char* a, const unsigned char* b, size_t n, int op)
+{
+    for (size_t i = 0; i < n; i++) {
+        u32 aw[16], bw[8], ow[8];
+        memcpy(aw, a + 64 * i, 64); rd32(bw, b, i);
+        sc_selftest_op(ow, aw, bw, op);
+        wr32(out, i, ow);
+    }
+}
+
+void emul_fold(unsigned char* out, const unsigned char* k, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u32 kw[8];
+        rd32(kw, k, i);
+        fold_selftest_op(out + 128 * i, kw);
+    }
+}
+
+void emul_base_table(unsigned char* out /* 256 x 96 */)
+{
+    tables();
+    memcpy(out, g_tbl_bytes.data(), 256 * 96);
+}
+
+// curve25519_dh_CreateSharedKey / CalculatePublicKey (pk == NULL) per element, sk clamped in place
+void emul_x25519(unsigned char* out, const unsigned char* pk, unsigned char* sk, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8], w[8];
+        if (pk) rd32(u, pk, i);
+        rd32(k, sk, i);
+        clamp_words(k);
+        wr32(sk, i, k);
+        fe PX, PZ, zi;
+        if (pk) x25519_ladder_xz<false>(PX, PZ, u, k);
+        else x25519_ladder_xz<true>(PX, PZ, u, k);
+        fe_invert(zi, PZ);
+        fe_mul(PX, PX, zi);
+        fe_to_words(w, PX);
+        wr32(out, i, w);
+    }
+}
+
+void emul_x25519_public_fast(unsigned char* pk, unsigned char* sk, size_t n)
+{
+    const u32* tbl = tables();
+    for (size_t i = 0; i < n; i++) {
+        u32 k[8], w[8];
+        rd32(k, sk, i);
+        clamp_words(k);
+        wr32(sk, i, k);
+        ge_ext S;
+        ge_base_mult(S, k, tbl);
+        fe num, den, t;
+        fe_add(t, S.Z, S.Y);  fe_carry32(num, t);
+        fe_sub(t, S.Z, S.Y);  fe_carry32(den, t);
+        fe_invert(t, den);
+        fe_mul(num, num, t);
+        fe_to_words(w, num);
+        wr32(pk, i, w);
+    }
+}
+
+void emul_blinding_init(unsigned char* ctx /* 192 */, const unsigned char* seed, size_t len)
+{
+    u32 w[BLIND_WORDS];
+    ed_blinding_init_lane(w, seed, len, tables());
+    memcpy(ctx, w, sizeof w);
+}
+
+static void base_mult_any(ge_ext& S, const u32 (&k)[8], const unsigned char* blinding)
+{
+    if (blinding) {
+        u32 w[BLIND_WORDS];
+        memcpy(w, blinding, sizeof w);
+        ge_blinding b;
+        blinding_from_words(b, w);
+        ge_base_mult_blinded(S, k, b, tables());
+    } else {
+        ge_base_mult(S, k, tables());
+    }
+}
+
+void emul_ed25519_keypair(unsigned char* pub, unsigned char* priv, const unsigned char* blinding,
+                          const unsigned char* sk, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u32 seed[8], a[8], enc[8];
+        u64 b_words[4];
+        rd32(seed, sk, i);
+        ed_expand_seed(a, b_words, seed);
+        ge_ext S;
+        base_mult_any(S, a, blinding);
+        affine_pack_host(enc, S);
+        wr32(priv, 2 * i, seed);
+        wr32(priv, 2 * i + 1, enc);
+        wr32(pub, i, enc);
+    }
+}
+
+void emul_ed25519_sign(unsigned char* sig, const unsigned char* priv, const unsigned char* blinding,
+                       const unsigned char* msg, size_t len, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u32 seed[8], pkw[8], a[8], r[8], enc[8], s[8];
+        rd32(seed, priv, 2 * i);
+        rd32(pkw, priv, 2 * i + 1);
+        ed_sign_nonce(a, r, seed, msg + len * i, len);
+        ge_ext S;
+        base_mult_any(S, r, blinding);
+        affine_pack_host(enc, S);
+        ed_sign_s(s, enc, pkw, msg + len * i, len, a, r);
+        wr32(sig, 2 * i, enc);
+        wr32(sig, 2 * i + 1, s);
+    }
+}
+
+// enc(T) of T = s*B + h*(-A) per element (what Verify_Check compares with enc(R)), and the verdicts
+void emul_ed25519_verify(int* verdict, unsigned char* point /* may be NULL */, const unsigned char* sig,
+                         const unsigned char* pk, const unsigned char* msg, size_t len, size_t n)
+{
+    const u32* tbl = tables() + (size_t)(BASE_NT - 1) * BASE_TBL_WORDS;
+    std::vector<u32> q(QTABLE_LIMB_WORDS);
+    for (size_t i = 0; i < n; i++) {
+        u32 pkw[8], Rw[8], Sw[8], h[8], enc[8];
+        rd32(pkw, pk, i);
+        ge_ext Q, T;
+        ed_decode_neg_key(Q, pkw);
+        const QTableLimbs t{ q.data() };
+        qtable_build(t, Q);
+        rd32(Rw, sig, 2 * i);
+        rd32(Sw, sig, 2 * i + 1);
+        ed_hram(h, Rw, pkw, msg + len * i, len);
+        sc_mod(h);
+        ge_poly_mult(T, Sw, h, t, tbl);
+        // the batched inversion maps Z == 0 to 0, which is also what z^(p-2) gives
+        affine_pack_host(enc, T);
+        if (point) wr32(point, i, enc);
+        u32 diff = 0;
+        for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
+        if (verdict) verdict[i] = diff == 0;
+    }
+}
+
+// ed25519_Verify_Init: the 2080-byte context (pk || 16 canonical rows)
+void emul_ed25519_verify_init(unsigned char* ctx, const unsigned char* pk, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u32 pkw[8];
+        rd32(pkw, pk, i);
+        memcpy(ctx + 2080 * i, pkw, 32);
+        ge_ext Q;
+        ed_decode_neg_key(Q, pkw);
+        const QTableCanon t{ reinterpret_cast<u32*>(ctx + 2080 * i + 32) };
+        qtable_build(t, Q);
+    }
+}
+
+}  // extern "C"

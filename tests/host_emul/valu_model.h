@@ -1,0 +1,59 @@
+// tests/host_emul/valu_model.h -- TEST INFRASTRUCTURE.  A C model of the gfx950 primitives of
+// curve25519_amd/csrc/valu_gfx950.cuh plus stand-ins for the HIP keywords the device headers use, so that the
+// SAME device source (fe25519.cuh, sc25519.cuh, sha512.cuh, ge25519.cuh, x25519.cuh, lanes.cuh) can be compiled by
+// g++ and unit-tested on the CPU, one "lane" at a time, against Python big integers and the committed fixtures.
+// It is force-included (-include) by tests/host_emul/build.py only; nothing in the product links or includes it,
+// and it is not a fallback: libcurve25519_amd.so has no host arithmetic at all.
+#pragma once
+#define C25519_VALU_PRIMITIVES 1
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#define __device__
+#define __forceinline__ inline
+#define __restrict__
+#define C25519_DEV inline
+
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{ x, y, z, w }; }
+struct emul_dim3 { unsigned x, y, z; };
+static const emul_dim3 threadIdx = { 0, 0, 0 }, blockIdx = { 0, 0, 0 }, blockDim = { 1, 1, 1 };
+static inline void __syncthreads() {}
+
+namespace c25519 {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+inline u32 dbl32(u32 x) { return x + x; }
+inline u32 alignbit32(u32 hi, u32 lo, int s) { return (u32)((((u64)hi << 32) | lo) >> s); }
+
+// v_mad_u64_u32 wraps modulo 2^64 exactly like unsigned C arithmetic; the model additionally REPORTS a wrap,
+// because the field layer's bound contract says it can never happen (tools/fe_bounds.py proves it; this checks it
+// on the values that actually flow through the tests).
+extern unsigned long long emul_mad_overflows;
+inline u64 mad64(u64 acc, u32 x, u32 y)
+{
+    const u64 p = (u64)x * y;
+    const u64 r = acc + p;
+    if (r < acc) emul_mad_overflows++;
+    return r;
+}
+inline u64 mad_chain5(u64 acc, const u32 (&x)[5], const u32 (&y)[5])
+{
+    for (int t = 0; t < 5; t++) acc = mad64(acc, x[t], y[t]);
+    return acc;
+}
+inline u64 mad_chain6(u64 acc, const u32 (&x)[6], const u32 (&y)[6])
+{
+    for (int t = 0; t < 6; t++) acc = mad64(acc, x[t], y[t]);
+    return acc;
+}
+inline u64 mad_chain10(u64 acc, const u32 (&x)[10], const u32 (&y)[10])
+{
+    for (int t = 0; t < 10; t++) acc = mad64(acc, x[t], y[t]);
+    return acc;
+}
+
+}  // namespace c25519

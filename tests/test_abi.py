@@ -89,3 +89,19 @@ def test_product_does_not_use_the_oracle():
         assert "orc_" not in open(os.path.join(ROOT, "include", h)).read()
     out = subprocess.check_output(["ldd", os.path.join(pkg, "libcurve25519_amd.so")], text=True)
     assert "liborc" not in out and "curve25519_ref" not in out
+
+
+def test_bench_self_launch_fails_only_for_lack_of_devices():
+    """`python bench.py --gpus 2` (no torchrun, the driver's invocation) must get past the launcher logic: on this
+    GPU-less box the only acceptable failure is the device count."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert p.returncode == 0
+    else:
+        assert p.returncode != 0
+        assert "GPU(s)" in p.stderr and "launch with torch.distributed.run" not in p.stderr

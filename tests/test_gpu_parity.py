@@ -60,28 +60,47 @@ def test_field_layer_against_big_integers(api):
     """L0 unit test (the reference's ECP_SELF_TEST field identities, test/curve25519_selftest.c:640-741): the
     device field ops on adversarial 256-bit patterns against Python big-integer arithmetic mod p."""
     from curve25519_amd import _lib
+    import vectors
     L = _lib.load()
-    P = 2**255 - 19
-    special = [0, 1, 2, 19, 38, P - 1, P, P + 1, 2 * P - 1, 2 * P, 2 * P + 1, 2**255 - 1, 2**255, 2**256 - 1,
-               2**256 - 38, 2**256 - 39, 2**26 - 1, 2**26, 2**51 - 1, 2**51, (1 << 255) - 20,
-               int("3ffffff" * 9 + "ff", 16) % 2**256, int("aa" * 32, 16), int("55" * 32, 16),
-               121665, 121666, pow(2, (P - 1) // 4, P)]
-    rnd = synth.random_bytes((400, 32), 0xFE01)
-    vals = special + [int.from_bytes(r.tobytes(), "little") for r in rnd]
-    pairs = [(a, b) for a in special for b in special] + list(zip(vals, reversed(vals)))
-    a = np.stack([np.frombuffer(x.to_bytes(32, "little"), np.uint8) for x, _ in pairs])
-    b = np.stack([np.frombuffer(y.to_bytes(32, "little"), np.uint8) for _, y in pairs])
+    pairs, a, b = vectors.field_cases()
     n = len(pairs)
-    expect = {0: lambda x, y: x * y, 1: lambda x, y: x * x, 2: lambda x, y: x + y, 3: lambda x, y: x - y,
-              4: lambda x, y: pow(x, P - 2, P), 5: lambda x, y: pow(x, (P - 5) // 8, P), 6: lambda x, y: x,
-              7: lambda x, y: (x - y) * (x + y)}
-    for op, f in expect.items():
+    for op in vectors.FIELD_OPS:
+        bb = b
+        if op in vectors.FIELD_OPS_B_REDUCED:                # contract: the subtrahend is a reduced element
+            bb = np.stack([vectors.le(y % vectors.P, 32) for _, y in pairs])
         out = np.empty((n, 32), np.uint8)
-        rc = L.c25519_amd_fe_selftest(out.ctypes.data, a.ctypes.data, b.ctypes.data, n, op)
-        assert rc == 0
-        for i, (x, y) in enumerate(pairs):
-            got = int.from_bytes(out[i].tobytes(), "little")
-            assert got == f(x, y) % P, (op, hex(x), hex(y), hex(got))
+        assert L.c25519_amd_fe_selftest(out.ctypes.data, a.ctypes.data, bb.ctypes.data, n, op) == 0
+        vectors.check_field(op, out, pairs)
+
+
+def test_scalar_layer_borrow_paths(api):
+    """mod-L unit test on the device (the reference's eco_* checks, test/curve25519_selftest.c:624-714): n*L +- 1,
+    b*R +- 1, all-ones digests -- the inputs on which sc_reduce_hi / sc_mod take their add-back paths, which hashed
+    inputs reach with probability ~2^-95."""
+    from curve25519_amd import _lib
+    import vectors
+    L = _lib.load()
+    a512, b256, a, b = vectors.scalar_cases()
+    n = len(a512)
+    for op in vectors.SCALAR_OPS:
+        out = np.empty((n, 32), np.uint8)
+        assert L.c25519_amd_sc_selftest(out.ctypes.data, a.ctypes.data, b.ctypes.data, n, op) == 0
+        vectors.check_scalar(op, out, a512, b256)
+
+
+def test_fold_recodings_match_the_reference(api):
+    """ecp_8Folds / ecp_4Folds outputs of the reference (KAT["folds"]) against the device's three recoders."""
+    from curve25519_amd import _lib
+    L = _lib.load()
+    recs = KAT["folds"]
+    k = np.concatenate([h2a(r["k"]) for r in recs])
+    k = np.ascontiguousarray(np.concatenate([k] * 9)[:130])          # more than two waves
+    out = np.empty((k.shape[0], 128), np.uint8)
+    assert L.c25519_amd_fold_selftest(out.ctypes.data, k.ctypes.data, k.shape[0]) == 0
+    for i in range(k.shape[0]):
+        r = recs[i % len(recs)]
+        assert out[i, :32].tobytes().hex() == r["fold8"] and out[i, 32:64].tobytes().hex() == r["fold8"]
+        assert out[i, 64:].tobytes().hex() == r["fold4"]
 
 
 # ---- known-answer vectors -------------------------------------------------------------------------------
@@ -455,25 +474,160 @@ def test_reference_harness_runs_on_this_library():
     assert "FAILED" not in p.stdout
 
 
-def test_two_launch_x25519_path_still_matches():
-    """The two-launch form of X25519 (ladder kernel + k_batch_invert, kept behind C25519_AMD_X25519_SPLIT=1 as an
-    A/B knob) must give the same bytes as the default single-launch kernel and the fixtures."""
-    code = (
-        "import sys, json, numpy as np; sys.path.insert(0, %r)\n"
-        "from curve25519_amd import api\n"
-        "g = np.load(%r)\n"
-        "s, c = api.curve25519_dh_CreateSharedKey(g['x_pk'], g['x_sk'])\n"
-        "assert np.array_equal(s, g['x_shared']) and np.array_equal(c, g['x_sk_clamped'])\n"
-        "P = 2**255 - 19\n"
-        "pk = np.stack([np.frombuffer(int(v).to_bytes(32, 'little'), np.uint8) for v in (0, 1, P - 1, P, P + 1, 9, 2**256 - 1)])\n"
-        "sk = np.full((7, 32), 0x42, np.uint8)\n"
-        "print(json.dumps([r.tobytes().hex() for r in api.curve25519_dh_CreateSharedKey(pk, sk)[0]]))\n"
-    ) % (ROOT, os.path.join(GOLD, "random_1024.npz"))
-    outs = []
-    for env in ({}, {"C25519_AMD_X25519_SPLIT": "1"}):
-        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
-                           env={**os.environ, **env})
-        assert p.returncode == 0, p.stderr[-2000:]
-        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
-    assert outs[0] == outs[1]
-    assert outs[0][0] == "00" * 32 and outs[0][3] == "00" * 32          # low-order inputs -> zero bytes in both forms
+def test_reference_cxx_wrappers_run_on_this_library():
+    """the reference's C++ classes (C++/x25519.cpp: DH + SHA-512 KDF; C++/ed25519.cpp: keygen / sign
+    with the reference's static blinding contexts, verify), compiled where they lie by `make -C oracle ref-cxx` and
+    linked against libcurve25519_amd.so, reproduce the RFC 7748 / RFC 8032 vectors.  Exit code = failure count."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "cxx_wrappers_on_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/cxx_wrappers_on_amd not built (needs /root/reference at build time)")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "0 failure(s)" in p.stdout and "FAIL" not in p.stdout
+
+
+def test_blinding_contexts_are_real_and_output_neutral(api, oracle):
+    """ed25519_Blinding_Init builds (bl, zr, BP) on the device; signing / key generation with it walk the scalar
+    k + bl and add BP, and the bytes are those of the unblinded calls (reference ed25519_sign.c:254-259; its harness
+    asserts the same equality, test/curve25519_test.c:385-394)."""
+    from curve25519_amd import _lib
+    import vectors
+    L = _lib.load()
+    n = 5000
+    sk, msg = synth.random_bytes((n, 32), 0xB101), synth.random_bytes((n, 45), 0xB102)
+    pub, priv = api.ed25519_CreateKeyPair(sk)
+    sig = api.ed25519_SignMessage(priv, msg)
+    assert np.array_equal(sig, oracle.ed25519_sign(priv, msg, threads=THREADS))
+    ctxs = []
+    for seed in (b"", b"x", bytes(range(64)), bytes(200)):
+        ctx = np.zeros(192, np.uint8)
+        sbuf = np.frombuffer(seed, np.uint8).copy() if seed else np.zeros(1, np.uint8)
+        got = L.ed25519_Blinding_Init(ctx.ctypes.data, sbuf.ctypes.data, len(seed))
+        assert got == ctx.ctypes.data                       # caller's storage is filled, as in the reference
+        bl = int.from_bytes(ctx[:32].tobytes(), "little")
+        assert 0 < bl < vectors.L and ctx[32:64].any() and ctx[160:192].tobytes() == (2).to_bytes(32, "little")
+        ctxs.append(ctx.tobytes())
+        bpub, bpriv = np.empty_like(pub), np.empty_like(priv)
+        _lib.check(L.ed25519_CreateKeyPair_blinded_batch(bpub.ctypes.data, bpriv.ctypes.data, ctx.ctypes.data,
+                                                         sk.ctypes.data, n), "keypair blinded")
+        assert np.array_equal(bpub, pub) and np.array_equal(bpriv, priv)
+        bsig = np.empty_like(sig)
+        _lib.check(L.ed25519_SignMessage_blinded_batch(bsig.ctypes.data, priv.ctypes.data, ctx.ctypes.data,
+                                                       msg.ctypes.data, msg.shape[1], n), "sign blinded")
+        assert np.array_equal(bsig, sig)
+    assert len(set(ctxs)) == 4
+    # the single-call API with a malloc'ed context
+    L.ed25519_Blinding_Init.restype = C.c_void_p
+    h = L.ed25519_Blinding_Init(None, b"seed", 4)
+    one_pub, one_priv, one_sig = (C.c_ubyte * 32)(), (C.c_ubyte * 64)(), (C.c_ubyte * 64)()
+    L.ed25519_CreateKeyPair(one_pub, one_priv, C.c_void_p(h), sk[0].ctypes.data)
+    L.ed25519_SignMessage(one_sig, one_priv, C.c_void_p(h), msg[0].ctypes.data, msg.shape[1])
+    L.ed25519_Blinding_Finish(C.c_void_p(h))
+    assert bytes(one_pub) == pub[0].tobytes() and bytes(one_sig) == sig[0].tobytes()
+
+
+def test_dev_entry_points_validate_their_pointers(api):
+    """*_dev calls refuse host memory and misaligned pointers instead of faulting inside a kernel."""
+    import torch
+    from curve25519_amd import _lib
+    L = _lib.load()
+    dev = torch.device("cuda", 0)
+    n = 256
+    d = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    h = np.zeros((n, 32), np.uint8)
+    rc = L.curve25519_dh_CreateSharedKey_dev(C.c_void_p(d.data_ptr()), C.c_void_p(h.ctypes.data), C.c_void_p(d.data_ptr()), n, None)
+    assert rc != 0 and b"device pointers" in L.c25519_amd_last_error()
+    rc = L.ed25519_VerifySignature_dev(C.c_void_p(h.ctypes.data), C.c_void_p(d.data_ptr()), C.c_void_p(d.data_ptr()),
+                                       C.c_void_p(d.data_ptr()), 16, n // 2, None)
+    assert rc != 0
+    with pytest.raises(ValueError):                                  # the torch wrappers check shapes first
+        api.curve25519_dh_CreateSharedKey_dev(d, d[: n - 1], d)
+    with pytest.raises(ValueError):
+        api.ed25519_VerifySignature_dev(torch.zeros((n, 1), dtype=torch.int64, device=dev), torch.zeros((n, 64), dtype=torch.uint8, device=dev), d, d)
+
+
+def test_thread_resources_are_released(api):
+    """Per-thread streams / staging / scratch are freed on thread exit and by c25519_amd_thread_release(): a churn of
+    short-lived threads must not grow device memory (round-1 leaked ~2.7 KB per verified element per thread)."""
+    import threading
+    import torch
+    from curve25519_amd import _lib
+    L = _lib.load()
+    n = 1 << 15
+    sk, msg = synth.random_bytes((n, 32), 0xC001), synth.random_bytes((n, 32), 0xC002)
+    pub, priv = api.ed25519_CreateKeyPair(sk)
+    sig = api.ed25519_SignMessage(priv, msg)
+
+    def work():
+        assert api.ed25519_VerifySignature(sig, pub, msg).all()
+
+    work()
+    L.c25519_amd_thread_release()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(6):
+        th = threading.Thread(target=work)
+        th.start()
+        th.join()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 16 << 20, (free0, free1)        # one verify scratch alone is ~90 MB at this n
+    work()                                                  # and the main thread still works after its own release
+
+
+def test_mixed_config5_through_hip_engine(api):
+    """BASELINE.json configs[4] at one GPU's share (2^20 mixed, contiguous thirds) through sharded.mixed_sharded and
+    the HIP engine with a process group of one rank: every third equals the same rows of the full 2^20 batches, whose
+    SHA-256 digests are the reference's (DIG) -- so the mixed path is tied to the reference's outputs."""
+    import torch
+    import torch.distributed as dist
+    from curve25519_amd import sharded
+    n = 1 << 20
+    dev = torch.device("cuda", 0)
+    eng = sharded.HipEngine(dev)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    sk, pk = synth.x25519_inputs(n)
+    esk, msg = synth.ed25519_inputs(n)
+    full_shared = eng.x25519_shared(up(pk), up(sk)).cpu().numpy()
+    pub, priv = eng.ed25519_keypair(up(esk))
+    sig = eng.ed25519_sign(priv, up(msg))
+    bsig, bmsg, bad = synth.corrupt_for_verify(sig.cpu().numpy(), msg)
+    full_ok = eng.ed25519_verify(up(bsig), pub, up(bmsg)).cpu().numpy()
+    d = DIG[str(n)]
+    assert sha(full_shared) == d["x25519_shared"] and sha(sig.cpu().numpy()) == d["ed25519_sig"]
+    assert sha(full_ok.reshape(-1).astype("<i4")) == d["ed25519_verdicts"]
+    (xa, xb), (sa, sb), (va, vb) = sharded.mixed_thirds(n)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        m_shared, m_sig, m_ok = sharded.mixed_sharded(
+            eng, up(pk[xa:xb]), up(sk[xa:xb]), priv[sa:sb].contiguous(), up(msg[sa:sb]),
+            up(bsig[va:vb]), pub[va:vb].contiguous(), up(bmsg[va:vb]))
+        # the one-collective form bench.py uses (RCCL gather, world of one)
+        og = sharded.OverlappedGather(xb - xa, 32, dev, root=0)
+        buf = og.next_buffer()
+        buf.copy_(m_shared)
+        og.submit()
+        og.finish()
+        assert torch.equal(og.gathered(0), m_shared)
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(m_shared.cpu().numpy(), full_shared[xa:xb])
+    assert np.array_equal(m_sig.cpu().numpy(), sig.cpu().numpy()[sa:sb])
+    assert np.array_equal(m_ok.cpu().numpy(), full_ok[va:vb])
+    assert np.array_equal(m_ok.cpu().numpy().reshape(-1) == 0, bad[va:vb])
+
+
+def test_bench_mixed_and_self_launch_run():
+    """bench.py --workload mixed (configs[4]) prints a well-formed line, and the N>1 code path (process group, RCCL
+    gathers) runs with a world of one rank."""
+    for extra in (["--workload", "mixed"], ["--dist-selftest", "--no-side"]):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu"] + extra,
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = json.loads(p.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+        if "mixed" in extra:
+            assert line["verify_rejects_exactly_the_corrupted"] is True
+            assert set(line["roofline"]["parts"]) == {"x25519", "sign", "verify"}

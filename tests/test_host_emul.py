@@ -1,0 +1,195 @@
+"""CPU tests of the DEVICE SOURCE: curve25519_amd/csrc/*.cuh compiled by g++ against a C model of the gfx950
+primitives (tests/host_emul/) and driven one lane at a time -- against Python big integers, the committed
+fixtures (the real reference's outputs) and the oracle.  What this leaves to the GPU suite is the kernels' indexing,
+LDS staging and scratch plumbing, and the asm primitives themselves (tests/test_gpu_parity.py)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "host_emul"))
+from curve25519_amd import synth  # noqa: E402
+import vectors  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+KAT = json.load(open(os.path.join(GOLD, "kat.json")))
+R1024 = np.load(os.path.join(GOLD, "random_1024.npz"))
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+vp, sz = C.c_void_p, C.c_size_t
+
+
+def h2a(s):
+    return np.frombuffer(bytes.fromhex(s), np.uint8).reshape(1, -1).copy()
+
+
+@pytest.fixture(scope="module")
+def emul():
+    import build as emul_build
+    lib = C.CDLL(emul_build.build())
+    lib.emul_mad_overflow_count.restype = C.c_ulonglong
+    for name, args in {"emul_fe_op": [vp, vp, vp, sz, C.c_int], "emul_sc_op": [vp, vp, vp, sz, C.c_int],
+                       "emul_fold": [vp, vp, sz], "emul_base_table": [vp], "emul_x25519": [vp, vp, vp, sz],
+                       "emul_x25519_public_fast": [vp, vp, sz], "emul_blinding_init": [vp, vp, sz],
+                       "emul_ed25519_keypair": [vp, vp, vp, vp, sz], "emul_ed25519_sign": [vp, vp, vp, vp, sz, sz],
+                       "emul_ed25519_verify": [vp, vp, vp, vp, vp, sz, sz], "emul_ed25519_verify_init": [vp, vp, sz]}.items():
+        getattr(lib, name).argtypes = args
+        getattr(lib, name).restype = None
+    yield lib
+    assert lib.emul_mad_overflow_count() == 0, "a v_mad_u64_u32 column wrapped 2^64: the bound contract is broken"
+
+
+def ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Emul:
+    def __init__(self, lib):
+        self.lib = lib
+
+    def x25519(self, pk, sk):
+        sk = np.ascontiguousarray(sk).copy()
+        out = np.empty_like(sk)
+        self.lib.emul_x25519(ptr(out), ptr(np.ascontiguousarray(pk)) if pk is not None else None, ptr(sk), sk.shape[0])
+        return out, sk
+
+    def public_fast(self, sk):
+        sk = np.ascontiguousarray(sk).copy()
+        out = np.empty_like(sk)
+        self.lib.emul_x25519_public_fast(ptr(out), ptr(sk), sk.shape[0])
+        return out, sk
+
+    def keypair(self, sk, blinding=None):
+        n = sk.shape[0]
+        pub, priv = np.empty((n, 32), np.uint8), np.empty((n, 64), np.uint8)
+        self.lib.emul_ed25519_keypair(ptr(pub), ptr(priv), ptr(blinding), ptr(np.ascontiguousarray(sk)), n)
+        return pub, priv
+
+    def sign(self, priv, msg, blinding=None):
+        n = priv.shape[0]
+        msg = np.ascontiguousarray(msg).reshape(n, -1) if n else np.zeros((0, 0), np.uint8)
+        sig = np.empty((n, 64), np.uint8)
+        self.lib.emul_ed25519_sign(ptr(sig), ptr(np.ascontiguousarray(priv)), ptr(blinding), ptr(msg), msg.shape[1], n)
+        return sig
+
+    def verify(self, sig, pk, msg, point=False):
+        n = sig.shape[0]
+        msg = np.ascontiguousarray(msg).reshape(n, -1)
+        ok, pt = np.empty(n, np.int32), np.empty((n, 32), np.uint8)
+        self.lib.emul_ed25519_verify(ptr(ok), ptr(pt), ptr(np.ascontiguousarray(sig)), ptr(np.ascontiguousarray(pk)),
+                                     ptr(msg), msg.shape[1], n)
+        return (ok, pt) if point else ok
+
+
+@pytest.fixture(scope="module")
+def dev(emul):
+    return Emul(emul)
+
+
+def test_field_layer_against_big_integers(emul):
+    pairs, a, b = vectors.field_cases()
+    for op in vectors.FIELD_OPS:
+        bb = b
+        if op in vectors.FIELD_OPS_B_REDUCED:                # contract: the subtrahend is a reduced element
+            bb = np.stack([vectors.le(y % vectors.P, 32) for _, y in pairs])
+        out = np.empty((len(pairs), 32), np.uint8)
+        emul.emul_fe_op(ptr(out), ptr(a), ptr(bb), len(pairs), op)
+        vectors.check_field(op, out, pairs)
+
+
+def test_scalar_layer_borrow_paths(emul):
+    a512, b256, a, b = vectors.scalar_cases()
+    for op in vectors.SCALAR_OPS:
+        out = np.empty((len(a512), 32), np.uint8)
+        emul.emul_sc_op(ptr(out), ptr(a), ptr(b), len(a512), op)
+        vectors.check_scalar(op, out, a512, b256)
+
+
+def test_fold_recodings_match_the_reference(emul):
+    recs = KAT["folds"]
+    k = np.concatenate([h2a(r["k"]) for r in recs])
+    out = np.empty((len(recs), 128), np.uint8)
+    emul.emul_fold(ptr(out), ptr(k), len(recs))
+    for i, r in enumerate(recs):
+        assert out[i, :32].tobytes().hex() == r["fold8"]
+        assert out[i, 32:64].tobytes().hex() == r["fold8"]
+        assert out[i, 64:].tobytes().hex() == r["fold4"]
+
+
+def test_base_table(emul):
+    tbl = np.empty((256, 3, 32), np.uint8)
+    emul.emul_base_table(ptr(tbl))
+    assert sha(tbl) == KAT["base_folding8_sha256"]
+
+
+def test_x25519_kats(dev):
+    recs = KAT["x25519"]
+    shared, clamped = dev.x25519(np.concatenate([h2a(r["pk"]) for r in recs]), np.concatenate([h2a(r["sk"]) for r in recs]))
+    for i, r in enumerate(recs):
+        assert shared[i].tobytes().hex() == r["shared"] and clamped[i].tobytes().hex() == r["sk_clamped"], r["name"]
+    recs = KAT["x25519_public"]
+    sk = np.concatenate([h2a(r["sk"]) for r in recs])
+    for pk, clamped in (dev.x25519(None, sk), dev.public_fast(sk)):
+        for i, r in enumerate(recs):
+            assert pk[i].tobytes().hex() == r["pk"] and clamped[i].tobytes().hex() == r["sk_clamped"], r["name"]
+
+
+def test_ed25519_kats(dev):
+    for r in KAT["ed25519"]:
+        msg = np.frombuffer(bytes.fromhex(r["msg"]), np.uint8).reshape(1, -1)
+        pub, priv = dev.keypair(h2a(r["sk"]))
+        assert pub.tobytes().hex() == r["pk"] and priv.tobytes().hex() == r["priv"], r["name"]
+        sig = dev.sign(priv, msg)
+        assert sig.tobytes().hex() == r["sig"], r["name"]
+        assert int(dev.verify(sig, pub, msg)[0]) == 1
+    for r in KAT["ed25519_verify"]:
+        msg = np.frombuffer(bytes.fromhex(r["msg"]), np.uint8).reshape(1, -1)
+        assert int(dev.verify(h2a(r["sig"]), h2a(r["pk"]), msg)[0]) == r["verify"], r["name"]
+
+
+def test_reference_fixture_rows(dev):
+    g, m = R1024, 192
+    shared, clamped = dev.x25519(g["x_pk"][:m], g["x_sk"][:m])
+    assert np.array_equal(shared, g["x_shared"][:m]) and np.array_equal(clamped, g["x_sk_clamped"][:m])
+    pub, priv = dev.keypair(g["ed_sk"][:m])
+    assert np.array_equal(pub, g["ed_pub"][:m]) and np.array_equal(priv, g["ed_priv"][:m])
+    assert np.array_equal(dev.sign(priv, g["ed_msg"][:m]), g["ed_sig"][:m])
+    assert np.array_equal(dev.verify(g["v_sig"][:m], g["ed_pub"][:m], g["v_msg"][:m]), g["v_ok"][:m])
+
+
+def test_verify_point_on_garbage_keys(dev, oracle):
+    n = 200
+    sig, pk, msg = synth.random_bytes((n, 64), 0xA501), synth.random_bytes((n, 32), 0xA502), synth.random_bytes((n, 24), 0xA503)
+    ok, pt = dev.verify(sig, pk, msg, point=True)
+    assert np.array_equal(pt, oracle.ed25519_verify_point(sig, pk, msg))
+    assert np.array_equal(ok, oracle.ed25519_verify(sig, pk, msg))
+
+
+def test_blinding_is_real_and_output_neutral(dev, emul):
+    """A context derived from a seed changes the scalar the walk sees ((k + bl) mod L != k) and the starting
+    point's Z, and the outputs stay byte-identical (reference ed25519_sign.c:254-259; its own harness checks the
+    same equality, test/curve25519_test.c:385-394)."""
+    n = 24
+    sk, msg = synth.random_bytes((n, 32), 0xB101), synth.random_bytes((n, 45), 0xB102)
+    pub, priv = dev.keypair(sk)
+    sig = dev.sign(priv, msg)
+    seen = set()
+    for seed in (b"", b"x", bytes(range(64)), bytes(200)):
+        ctx = np.empty(192, np.uint8)
+        s = np.frombuffer(seed, np.uint8).copy() if seed else np.zeros(1, np.uint8)
+        emul.emul_blinding_init(ptr(ctx), ptr(s), len(seed))
+        bl = int.from_bytes(ctx[:32].tobytes(), "little")
+        assert 0 < bl <= vectors.L
+        t = (vectors.L - bl) % vectors.L
+        seen.add(bl)
+        # BP = t*B in the PE form: (y+x, y-x, 2dxy, 2) -- check it against the base table identity via keypairs:
+        # (k + bl)*B + t*B == k*B is exactly what the equalities below establish for every k
+        bpub, bpriv = dev.keypair(sk, blinding=ctx)
+        assert np.array_equal(bpub, pub) and np.array_equal(bpriv, priv)
+        assert np.array_equal(dev.sign(priv, msg, blinding=ctx), sig)
+        assert t != 0
+    assert len(seen) == 4

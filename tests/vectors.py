@@ -1,0 +1,111 @@
+"""Adversarial unit-test inputs shared by the CPU (host-emulated device source) and GPU suites, with the expected
+results computed by Python big integers.  The cases follow the reference's own unit checks
+(test/curve25519_selftest.c:624-741): field identities mod p, and mod-L reductions around the n*L +- 1 and
+b*R +- 1 boundaries where eco_ReduceHiWord / eco_Mod take their borrow paths."""
+import numpy as np
+
+from curve25519_amd import synth
+
+P = 2**255 - 19
+L = 2**252 + 27742317777372353535851937790883648493
+R = (1 << 256) % L                      # 2^256 mod L
+MINUS_R = (1 << 256) - 16 * (L - 2**252)  # what one top-word fold subtracts per unit: 2^256 - 16c ... see sc25519.cuh
+
+
+def le(x: int, nbytes: int) -> np.ndarray:
+    return np.frombuffer(int(x).to_bytes(nbytes, "little"), np.uint8)
+
+
+def field_cases():
+    """(pairs, a[n,32], b[n,32]) of 256-bit patterns: every special value against every other, plus seeded random."""
+    special = [0, 1, 2, 19, 38, P - 1, P, P + 1, 2 * P - 1, 2 * P, 2 * P + 1, 2**255 - 1, 2**255, 2**256 - 1,
+               2**256 - 38, 2**256 - 39, 2**26 - 1, 2**26, 2**51 - 1, 2**51, (1 << 255) - 20,
+               int("3ffffff" * 9 + "ff", 16) % 2**256, int("aa" * 32, 16), int("55" * 32, 16),
+               121665, 121666, pow(2, (P - 1) // 4, P)]
+    rnd = synth.random_bytes((400, 32), 0xFE01)
+    vals = special + [int.from_bytes(r.tobytes(), "little") for r in rnd]
+    pairs = [(a, b) for a in special for b in special] + list(zip(vals, reversed(vals)))
+    a = np.stack([le(x, 32) for x, _ in pairs])
+    b = np.stack([le(y, 32) for _, y in pairs])
+    return pairs, a, b
+
+
+FIELD_OPS = {
+    0: lambda x, y: x * y, 1: lambda x, y: x * x, 2: lambda x, y: x + y, 3: lambda x, y: x - y,
+    4: lambda x, y: pow(x, P - 2, P), 5: lambda x, y: pow(x, (P - 5) // 8, P), 6: lambda x, y: x,
+    7: lambda x, y: (x - y) * (x + y), 8: lambda x, y: x * x - y, 9: lambda x, y: 2 * x * x + x,
+    10: lambda x, y: x + 121665 * y, 11: lambda x, y: 9 * x,
+}
+# ops 8 and 9 take a reduced second operand (the contract of fe_sqr_sub / fe_sqr2_add_sub)
+FIELD_OPS_B_REDUCED = {8, 9}
+
+
+def scalar_cases():
+    """(a512 ints, b256 ints, a[n,64], b[n,32]): values that force the borrow / add-back paths of the mod-L code."""
+    a512, b256 = [], []
+    edge256 = [0, 1, L - 1, L, L + 1, 2 * L - 1, 2 * L, 2 * L + 1, 15 * L - 1, 15 * L, 15 * L + 1, 2**252 - 1, 2**252,
+               2**252 + 1, 2**253 - 1, 2**255 - 1, 2**255, 2**256 - 1, R - 1, R, R + 1, 2**256 - R, 16 * (L - 2**252),
+               16 * (L - 2**252) - 1, 16 * (L - 2**252) + 1]
+    for n in range(0, 16):
+        for d in (-1, 0, 1):
+            v = n * L + d
+            if 0 <= v < 2**256:
+                edge256.append(v)
+    for k in (1, 2, 3, 7, 0x7fffffff, 0x80000000, 0xfffffffe, 0xffffffff):
+        for d in (-1, 0, 1):
+            edge256.append((k * R + d) % 2**256)
+            edge256.append((k * 16 * (L - 2**252) + d) % 2**256)
+    edge256 = sorted(set(edge256))
+    hi_words = [0, 1, 2, 0x7fffffff, 0x80000000, 0xfffffffe, 0xffffffff]
+    for lo in edge256:
+        for hi in hi_words:
+            a512.append(lo + (hi << 256))
+            b256.append(edge256[(len(a512) * 7) % len(edge256)])
+    # full 512-bit patterns: all-ones, multiples of L near 2^512, digests
+    big = [2**512 - 1, 2**512 - L, (2**512 // L) * L, (2**512 // L) * L - 1, (2**512 // L) * L + 1, 2**511, 2**256,
+           2**256 - 1, (2**256 - 1) << 256]
+    for k in range(1, 40):
+        big.append(((2**512 // L) - k) * L + (k % 3) - 1)
+    for v in big:
+        a512.append(v % 2**512)
+        b256.append(edge256[(v % 9973) % len(edge256)])
+    rnd = synth.random_bytes((600, 96), 0x5C01)
+    for r in rnd:
+        a512.append(int.from_bytes(r[:64].tobytes(), "little"))
+        b256.append(int.from_bytes(r[64:].tobytes(), "little"))
+    a = np.stack([le(x, 64) for x in a512])
+    b = np.stack([le(y, 32) for y in b256])
+    return a512, b256, a, b
+
+
+M256 = 2**256 - 1
+# op -> (expected exact value, canonical?)   see include/curve25519_amd.h c25519_amd_sc_selftest
+SCALAR_OPS = {
+    0: (lambda a, b: a, True),
+    1: (lambda a, b: a, False),
+    2: (lambda a, b: a & M256, True),
+    3: (lambda a, b: (a & M256) * b, False),
+    4: (lambda a, b: (a & M256) + b, False),
+    5: (lambda a, b: (a & M256) + (((a >> 256) & 0xffffffff) << 256), False),
+    6: (lambda a, b: (a & M256) * b + (a >> 256), True),
+}
+
+
+def check_scalar(op, out, a512, b256):
+    f, canonical = SCALAR_OPS[op]
+    for i, (x, y) in enumerate(zip(a512, b256)):
+        got = int.from_bytes(out[i].tobytes(), "little")
+        exp = f(x, y) % L
+        if canonical:
+            assert got == exp, (op, i, hex(x), hex(y), hex(got), hex(exp))
+        else:
+            assert got % L == exp and got < 2**256, (op, i, hex(x), hex(y), hex(got))
+
+
+def check_field(op, out, pairs):
+    f = FIELD_OPS[op]
+    for i, (x, y) in enumerate(pairs):
+        got = int.from_bytes(out[i].tobytes(), "little")
+        if op in FIELD_OPS_B_REDUCED:
+            y %= P
+        assert got == f(x, y) % P, (op, hex(x), hex(y), hex(got))

@@ -1,0 +1,50 @@
+#!/bin/bash
+# tools/gpu_round.sh -- one gpurun call's worth of work: the GPU test suite, bench lines, the instruction-rate
+# microbenchmark, the host-API rates and the rocprofv3 passes.  Everything lands under gpurun_out/r02/.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tests|bench|ubench|prof|all ...]'
+set -u
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/r02
+mkdir -p $OUT
+cd $REPO
+WHAT=${*:-all}
+has() { [[ " $WHAT " == *" $1 "* || " $WHAT " == *" all "* ]]; }
+
+if has tests; then
+  timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 > $OUT/pytest_gpu.log
+  echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  tail -5 $OUT/pytest_gpu.log
+fi
+if has bench; then
+  timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+  timeout 300 python bench.py --steps 10 --warmup 3 --workload mixed --no-cpu > $OUT/bench_mixed.json 2> $OUT/bench_mixed.err; echo "mixed rc=$?"
+  timeout 300 python bench.py --steps 5 --warmup 2 --dist-selftest --no-cpu > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "dist1 rc=$?"
+  timeout 300 python tools/hostapi_rate.py --json $OUT/hostapi_rate.json > $OUT/hostapi_rate.txt 2>&1; echo "hostapi rc=$?"
+  cat $OUT/hostapi_rate.txt
+fi
+if has ubench; then
+  timeout 300 tools/ubench/valu_rates $OUT/valu_rates.json > $OUT/valu_rates.txt 2>&1; echo "ubench rc=$?"
+  [ -x tools/ubench/field_ab ] && { timeout 300 tools/ubench/field_ab > $OUT/field_ab.txt 2>&1; echo "field_ab rc=$?"; cat $OUT/field_ab.txt; }
+fi
+if has ab && ls build_ab/*.so >/dev/null 2>&1; then
+  timeout 600 python tools/ab_bench.py curve25519_amd/libcurve25519_amd.so build_ab/*.so --ops x25519,sign,verify,keypair --rounds 4 > $OUT/ab_bench.txt 2>&1
+  echo "ab rc=$?"; cat $OUT/ab_bench.txt
+fi
+if has prof; then
+  cd /tmp && export TMPDIR=/tmp
+  BENCH="python $REPO/bench.py --steps 24 --warmup 6 --no-cpu"
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o stats -- $BENCH > $OUT/prof_stats.log 2>&1
+  BENCHX="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu"
+  timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_fetch -o fetch -- $BENCHX > $OUT/prof_fetch.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/prof_write -o write -- $BENCHX > $OUT/prof_write.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $OUT/prof_sq -o sq -- $BENCHX > $OUT/prof_sq.log 2>&1
+  timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM -d $OUT/prof_sq2 -o sq2 -- $BENCHX > $OUT/prof_sq2.log 2>&1
+  cd $REPO
+  S=$(find $OUT/prof_stats -name '*.db' | head -1)
+  [ -n "$S" ] && python tools/rocpd_summary.py stats $S > $OUT/kernel_stats.txt && cat $OUT/kernel_stats.txt
+  P=$(find $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq $OUT/prof_sq2 -name '*.db')
+  [ -n "$P" ] && python tools/rocpd_summary.py pmc $P > $OUT/pmc.txt && python tools/rocpd_summary.py pmc-json $P > $OUT/pmc.json
+  # keep the databases out of the 64 MiB pull
+  find $OUT -name '*.db' -size +8M -delete
+fi
+echo "gpu_round done: $WHAT"

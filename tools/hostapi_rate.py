@@ -1,15 +1,72 @@
-import sys,time; sys.path.insert(0,".")
-import numpy as np
-from curve25519_amd import api, synth
-n=1<<20
-sk,pk=synth.x25519_inputs(n)
-esk,msg=synth.ed25519_inputs(n)
-api.curve25519_dh_CreateSharedKey(pk[:1024],sk[:1024])
-for name,fn in (("x25519", lambda: api.curve25519_dh_CreateSharedKey(pk,sk)),):
-    fn(); t=time.perf_counter(); fn(); fn(); dt=(time.perf_counter()-t)/2
-    print(name, "host-buffer API: %.2f ms per 2^20 -> %.1f M ops/s (PCIe + staging inclusive)"%(dt*1e3, n/dt/1e6))
-pub,priv=api.ed25519_CreateKeyPair(esk)
-sig=api.ed25519_SignMessage(priv,msg)
-for name,fn in (("sign", lambda: api.ed25519_SignMessage(priv,msg)),("verify", lambda: api.ed25519_VerifySignature(sig,pub,msg))):
-    fn(); t=time.perf_counter(); fn(); fn(); dt=(time.perf_counter()-t)/2
-    print(name, "host-buffer API: %.2f ms per 2^20 -> %.1f M ops/s"%(dt*1e3, n/dt/1e6))
+#!/usr/bin/env python3
+"""tools/hostapi_rate.py -- throughput of the host-pointer (*_batch) entry points, the ones a C caller of the drop-in
+API uses: pageable numpy arrays in, results out, PCIe + staging inclusive, against the device-resident (*_dev) rate.
+
+    python tools/hostapi_rate.py [--n 1048576] [--json out.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from curve25519_amd import api, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=1 << 20)
+ap.add_argument("--json", default=None)
+args = ap.parse_args()
+n = args.n
+dev = torch.device("cuda", 0)
+sk, pk = synth.x25519_inputs(n)
+esk, msg = synth.ed25519_inputs(n)
+api.curve25519_dh_CreateSharedKey(pk[:1024], sk[:1024])
+pub, priv = api.ed25519_CreateKeyPair(esk)
+sig = api.ed25519_SignMessage(priv, msg)
+
+
+def host_rate(fn, reps=4):
+    fn()
+    fn()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t) / reps
+
+
+def dev_rate(fn, reps=6):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / reps
+
+
+d = {k: torch.from_numpy(v).to(dev) for k, v in dict(sk=sk, pk=pk, msg=msg, pub=pub, priv=priv, sig=sig).items()}
+o32, o64 = torch.empty((n, 32), dtype=torch.uint8, device=dev), torch.empty((n, 64), dtype=torch.uint8, device=dev)
+ok = torch.empty((n, 1), dtype=torch.int32, device=dev)
+rows = {}
+for name, hfn, dfn, moved in (
+        ("x25519", lambda: api.curve25519_dh_CreateSharedKey(pk, sk),
+         lambda: api.curve25519_dh_CreateSharedKey_dev(o32, d["pk"], d["sk"]), 128),
+        ("sign", lambda: api.ed25519_SignMessage(priv, msg),
+         lambda: api.ed25519_SignMessage_dev(o64, d["priv"], d["msg"]), 160),
+        ("verify", lambda: api.ed25519_VerifySignature(sig, pub, msg),
+         lambda: api.ed25519_VerifySignature_dev(ok, d["sig"], d["pub"], d["msg"]), 132)):
+    th, td = host_rate(hfn), dev_rate(dfn)
+    rows[name] = {"host_ms": round(th * 1e3, 3), "host_Mops": round(n / th / 1e6, 2), "dev_ms": round(td * 1e3, 3),
+                  "dev_Mops": round(n / td / 1e6, 2), "host_over_dev": round(td / th, 3),
+                  "pcie_GBps": round(moved * n / th / 1e9, 2)}
+    print(f"{name:7s} host-pointer API {th * 1e3:8.2f} ms per 2^{int(np.log2(n))} = {n / th / 1e6:7.1f} M ops/s "
+          f"({moved * n / th / 1e9:5.1f} GB/s over PCIe, staging inclusive) | device-resident {td * 1e3:7.2f} ms = "
+          f"{n / td / 1e6:7.1f} M ops/s | ratio {td / th:.2f}")
+if args.json:
+    json.dump({"n": n, "rows": rows}, open(args.json, "w"), indent=1)

@@ -17,9 +17,13 @@ constexpr int UNROLL = 16;      // instructions of the tested kind per loop iter
 // Each body issues UNROLL instructions on 8 independent dependency chains (2 per chain).
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
+// s_memtime ticks at the shader clock (MI355X_MICROARCH.md); wave 0 of workgroup 0 reports the ticks its own loop took,
+// which gives the shader clock the chip actually sustained under this instruction mix (ticks / elapsed time) and
+// cycles per wave-instruction that do not depend on the nominal 2.4 GHz.
 template <int KIND>
-__global__ void __launch_bounds__(256) k_rate(unsigned* out, unsigned seed)
+__global__ void __launch_bounds__(256) k_rate(unsigned* out, unsigned seed, unsigned long long* ticks)
 {
+    const unsigned long long t_begin = __builtin_readcyclecounter();
     unsigned a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u;
     unsigned r0 = a, r1 = b, r2 = a + 1, r3 = b + 1, r4 = a + 2, r5 = b + 2, r6 = a + 3, r7 = b + 3;
     unsigned t0 = b, t1 = a, t2 = b + 5, t3 = a + 5, t4 = b + 6, t5 = a + 6, t6 = b + 7, t7 = a + 7;
@@ -152,6 +156,61 @@ __global__ void __launch_bounds__(256) k_rate(unsigned* out, unsigned seed)
 #define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(r##i) : "v"(a));
             REP8(X) REP8(X)
 #undef X
+        } else if constexpr (KIND == 32) {  // v_mad_u64_u32 with a zero addend (inline constant): no 64-bit VGPR source
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(q##i) : "v"(r##i), "v"(b) : "vcc");
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 33) {  // v_mad_u64_u32, ONE dependent chain (latency): 16 MADs on one accumulator
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q0) : "v"(a), "v"(b) : "vcc");
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 34) {  // v_mad_u64_u32 with an SGPR multiplicand
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, s24, %1, %0" : "+v"(q##i) : "v"(b) : "vcc", "s24");
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 35) {  // v_mad_i64_i32
+#define X(i) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(q##i) : "v"(a), "v"(b) : "vcc");
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 36) {  // column chain as the field product issues it: 10 MADs + 64-bit shift + mask
+#define M2 "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\t"
+            asm volatile(M2 M2 M2 M2 "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0"
+                         : "+v"(q0) : "v"(a), "v"(b) : "vcc");
+            r0 ^= (unsigned)q0 & 0x3ffffffu;
+            q0 >>= 26;
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0"
+                         : "+v"(q0) : "v"(a), "v"(b) : "vcc");
+            r1 ^= (unsigned)q0 & 0x1ffffffu;
+            q0 >>= 25;
+#undef M2
+        } else if constexpr (KIND == 37) {  // v_fma_f32, 16 independent chains, destination != sources
+#define X(i) asm volatile("v_fma_f32 %0, %2, %3, %1" : "=v"(f##i) : "v"(fa), "v"(fm), "v"(fa));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 38) {  // v_add_u32 with an inline constant (one VGPR read)
+#define X(i) asm volatile("v_add_u32 %0, 17, %0" : "+v"(r##i));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 39) {  // v_pk_fma_f32 counted as TWO lane-FMAs per lane
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(d##i) : "v"(dm), "v"(da));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 40) {  // v_mad_u64_u32 + v_addc_co_u32 as a saturated (radix 2^32) product needs them
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(q##i), "+v"(r##i) : "v"(a), "v"(b) : "vcc");
+            REP8(X)
+#undef X
+        } else if constexpr (KIND == 41) {  // v_lshl_add_u32
+#define X(i) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 42) {  // v_or_b32
+#define X(i) asm volatile("v_or_b32 %0, %0, %1" : "+v"(r##i) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 43) {  // v_mad_u64_u32, distinct destination (d = a*b + c, c another pair)
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(q##i) : "v"(a), "v"(b), "v"(q7) : "vcc");
+            X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(0) X(1)
+#undef X
         } else if constexpr (KIND == 23) {  // v_mad_i32_i24 ... placeholder for v_perm/v_bfe: v_bfe_u32
 #define X(i) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(r##i));
             REP8(X) REP8(X)
@@ -164,6 +223,8 @@ __global__ void __launch_bounds__(256) k_rate(unsigned* out, unsigned seed)
     float fs = f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7;
     acc ^= (unsigned)qa ^ (unsigned)(qa >> 32) ^ (unsigned)__double2loint(ds) ^ __float_as_uint(fs);
     if (acc == 0x12345678u) out[0] = acc;      // keep everything live, (almost) never store
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t_end - t_begin;
 }
 
 struct Kind { int id; const char* name; };
@@ -176,16 +237,22 @@ static const Kind kinds[] = {
     {15, "mix 1 mad64 : 1 addc"}, {16, "mix 1 mad64 : 3 add"},
     {24, "v_cndmask_b32_e64(sgpr mask)"}, {25, "v_bfi_b32"}, {26, "v_and_or_b32"}, {27, "v_cmp+v_cndmask(vcc)"},
     {28, "v_lshlrev_b32"}, {29, "v_sub_u32"}, {30, "v_and_b32"}, {31, "v_mov_b32"},
+    {32, "v_mad_u64_u32(zero addend)"}, {33, "v_mad_u64_u32(one dependent chain)"}, {34, "v_mad_u64_u32(sgpr factor)"},
+    {35, "v_mad_i64_i32"}, {43, "v_mad_u64_u32(separate dst)"}, {36, "field column: 12 mad + 2 and + 2 shift64"},
+    {37, "v_fma_f32(16 chains, dst != src)"}, {38, "v_add_u32(inline const)"}, {39, "v_pk_fma_f32"},
+    {40, "mad64+addc pair (saturated radix)"}, {41, "v_lshl_add_u32"}, {42, "v_or_b32"},
 };
 
-template <int KIND> static void launch(int blocks, unsigned* d, hipStream_t s) { k_rate<KIND><<<blocks, 256, 0, s>>>(d, 1); }
+static unsigned long long* g_ticks;
+template <int KIND> static void launch(int blocks, unsigned* d, hipStream_t s) { k_rate<KIND><<<blocks, 256, 0, s>>>(d, 1, g_ticks); }
 
 static void dispatch(int kind, int blocks, unsigned* d, hipStream_t s)
 {
     switch (kind) {
 #define C(k) case k: launch<k>(blocks, d, s); break;
         C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(18)
-        C(19) C(20) C(21) C(22) C(23) C(24) C(25) C(26) C(27) C(28) C(29) C(30) C(31)
+        C(19) C(20) C(21) C(22) C(23) C(24) C(25) C(26) C(27) C(28) C(29) C(30) C(31) C(32) C(33) C(34) C(35) C(36)
+        C(37) C(38) C(39) C(40) C(41) C(42) C(43)
 #undef C
     }
 }
@@ -198,13 +265,14 @@ int main(int argc, char** argv)
     double ghz = prop.clockRate / 1e6;
     printf("device %s  CUs %d  clock %.3f GHz\n", prop.name, cus, ghz);
     unsigned* d; CHECK(hipMalloc(&d, 64));
+    CHECK(hipMalloc(&g_ticks, 8));
     hipStream_t s; CHECK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const char* json = argc > 1 ? argv[1] : nullptr;
     FILE* jf = json ? fopen(json, "w") : nullptr;
     if (jf) fprintf(jf, "{\"device\": \"%s\", \"cus\": %d, \"clock_ghz\": %.3f, \"rates\": {\n", prop.name, cus, ghz);
     bool first = true;
-    for (int wps : {2, 8}) {               // waves per SIMD: 256-thread block = 1 wave per SIMD
+    for (int wps : {1, 2, 4, 8}) {         // waves per SIMD: 256-thread block = 1 wave per SIMD
         int blocks = cus * wps;
         for (const Kind& k : kinds) {
             dispatch(k.id, blocks, d, s);
@@ -218,12 +286,23 @@ int main(int argc, char** argv)
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
                 if (ms < best) best = ms;
             }
-            double insts = (double)blocks * 4 /*waves*/ * ITERS * UNROLL;     // wave-instructions
-            double lane_ops_per_s = insts * 64 / (best * 1e-3);
-            double per_clk_per_simd = lane_ops_per_s / (cus * 4.0 * ghz * 1e9);
-            printf("wps=%d %-30s %8.3f ms  %8.2f Tlane-op/s  %6.2f lanes/clk/SIMD\n", wps, k.name, best,
-                   lane_ops_per_s / 1e12, per_clk_per_simd);
-            if (jf) { fprintf(jf, "%s  \"%s@wps%d\": %.4e", first ? "" : ",\n", k.name, wps, lane_ops_per_s); first = false; }
+            unsigned long long ticks = 0;
+            CHECK(hipMemcpy(&ticks, g_ticks, 8, hipMemcpyDeviceToHost));
+            const int per_iter = k.id == 36 ? 16 : UNROLL;                    // instructions per loop iteration
+            const double scale = k.id == 39 ? 2.0 : 1.0;                      // packed: two lane-ops per lane
+            double insts = (double)blocks * 4 /*waves*/ * ITERS * per_iter;   // wave-instructions
+            double lane_ops_per_s = scale * insts * 64 / (best * 1e-3);
+            // wave 0's own loop: `wps` waves share its SIMD, so the SIMD issued wps * ITERS * per_iter instructions
+            // in `ticks` shader cycles
+            double clk_per_inst = (double)ticks / ((double)wps * ITERS * per_iter);
+            double eff_ghz = (double)ticks / (best * 1e-3) / 1e9;             // kernel ~= one wave's loop + launch
+            printf("wps=%d %-42s %8.3f ms  %8.2f Tlane-op/s  %6.2f SIMD-cycles/wave-instr  (%.2f GHz sustained)\n", wps,
+                   k.name, best, lane_ops_per_s / 1e12, clk_per_inst, eff_ghz);
+            if (jf) {
+                fprintf(jf, "%s  \"%s@wps%d\": %.4e", first ? "" : ",\n", k.name, wps, lane_ops_per_s); first = false;
+                fprintf(jf, ",\n  \"cycles:%s@wps%d\": %.3f", k.name, wps, clk_per_inst);
+                fprintf(jf, ",\n  \"ghz:%s@wps%d\": %.3f", k.name, wps, eff_ghz);
+            }
         }
     }
     if (jf) { fprintf(jf, "\n}}\n"); fclose(jf); }
