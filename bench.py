@@ -224,6 +224,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)                              # does not return
 
+    # stdout carries exactly ONE line, the result: whatever libraries print at C level (RCCL's version banner, ...)
+    # is routed to stderr for the rest of the run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from curve25519_amd import synth
@@ -440,7 +446,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         result["cpu_baseline"] = None if args.no_cpu else cpu_baseline(quick=world > 1)
-        print(json.dumps(result), flush=True)
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -176,7 +176,16 @@ __global__ void __launch_bounds__(256 * BASE_NT) k_gen_base_table(u32* tbl_limbs
 // ------------------------------------------------------------------------------------------------
 // Ed25519
 // ------------------------------------------------------------------------------------------------
-constexpr int ED_BLOCK = 256;
+#ifndef C25519_ED_BLOCK
+#define C25519_ED_BLOCK 256
+#endif
+#ifndef C25519_VI_WAVES
+#define C25519_VI_WAVES 2            // waves per SIMD the register allocator aims at: Verify_Init ...
+#endif
+#ifndef C25519_VC_WAVES
+#define C25519_VC_WAVES 2            // ... and Verify_Check (A/B: profiles/r02_ab_occupancy.txt)
+#endif
+constexpr int ED_BLOCK = C25519_ED_BLOCK;
 constexpr int BM_BLOCK = 1024;            // fixed-base kernels: one 120 KiB table set per 16 waves (4 per SIMD)
 
 C25519_DEV void store_proj(const ProjScratch& scr, size_t n, size_t i, const ge_ext& S)
@@ -299,7 +308,7 @@ __global__ void __launch_bounds__(256) k_ed25519_blinding_init(u32* ctx, const u
 // ed25519_Verify_Init (ed25519_verify.c:179-232): decompress -A (inverted parity :192-195, no validation) and
 // fill the key's 16-row 4-fold table.  `tables` holds n tables of Tbl's format, `stride_words` apart.
 template <typename Tbl>
-__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_init(const void* pk, size_t n, u32* tables,
+__global__ void __launch_bounds__(ED_BLOCK, C25519_VI_WAVES) k_ed25519_verify_init(const void* pk, size_t n, u32* tables,
                                                                       size_t stride_words)
 {
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
@@ -330,7 +339,7 @@ C25519_DEV void verify_check_lane(const ProjScratch& scr, size_t n, size_t i, co
 }
 
 template <typename Tbl>
-__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check(ProjScratch scr, const void* sig, const void* pk,
+__global__ void __launch_bounds__(ED_BLOCK, C25519_VC_WAVES) k_ed25519_verify_check(ProjScratch scr, const void* sig, const void* pk,
                                                                        Msgs msgs, size_t n,
                                                                        const u32* __restrict__ g_tbl, u32* tables,
                                                                        size_t stride_words)

@@ -310,7 +310,7 @@ def test_device_pointer_entry_points(api, oracle):
     assert np.array_equal(pk.cpu().numpy(), e_out)
     from curve25519_amd import _lib
     with pytest.raises(_lib.EngineError):                           # misaligned device pointer is refused
-        api.curve25519_dh_CreateSharedKey_dev(out, out.view(-1)[1:32 * (n - 1) + 1].view(n - 1, 32), sk[: n - 1])
+        api.curve25519_dh_CreateSharedKey_dev(out[: n - 1], out.view(-1)[1:32 * (n - 1) + 1].view(n - 1, 32), sk[: n - 1])
 
 
 def test_two_phase_verification(api, oracle):
@@ -561,17 +561,19 @@ def test_thread_resources_are_released(api):
     def work():
         assert api.ed25519_VerifySignature(sig, pub, msg).all()
 
+    def churn(k):
+        for _ in range(k):
+            th = threading.Thread(target=work)
+            th.start()
+            th.join()
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
     work()
     L.c25519_amd_thread_release()
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
-    for _ in range(6):
-        th = threading.Thread(target=work)
-        th.start()
-        th.join()
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 < 16 << 20, (free0, free1)        # one verify scratch alone is ~90 MB at this n
+    free_a = churn(2)                                      # the HIP runtime may keep one freed block cached: settle first
+    free_b = churn(8)
+    assert free_a - free_b < 16 << 20, (free_a, free_b)    # one verify scratch alone is ~90 MB at this n
     work()                                                  # and the main thread still works after its own release
 
 
@@ -626,7 +628,8 @@ def test_bench_mixed_and_self_launch_run():
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu"] + extra,
                            capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-3000:]
-        line = json.loads(p.stdout.strip().splitlines()[-1])
+        assert len(p.stdout.strip().splitlines()) == 1, p.stdout          # exactly one line on stdout
+        line = json.loads(p.stdout)
         assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
         if "mixed" in extra:
             assert line["verify_rejects_exactly_the_corrupted"] is True

@@ -211,6 +211,42 @@ __global__ void __launch_bounds__(256) k_rate(unsigned* out, unsigned seed, unsi
 #define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(q##i) : "v"(a), "v"(b), "v"(q7) : "vcc");
             X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(0) X(1)
 #undef X
+        } else if constexpr (KIND == 44) {  // dependent MAD chain, ping-pong between two accumulators (dst != src2)
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %1\n\tv_mad_u64_u32 %1, vcc, %3, %2, %0" : "+v"(q0), "+v"(q1) : "v"(a), "v"(b) : "vcc");
+            REP8(X)
+#undef X
+        } else if constexpr (KIND == 45) {  // MAD, explicit registers, all four source dwords in different VGPR banks (v%4)
+            asm volatile(
+                "v_mov_b32 v40, %0\n\tv_mov_b32 v41, %1\n\t"
+                "v_mad_u64_u32 v[42:43], vcc, v40, v41, v[42:43]\n\tv_mad_u64_u32 v[46:47], vcc, v40, v41, v[46:47]\n\t"
+                "v_mad_u64_u32 v[50:51], vcc, v40, v41, v[50:51]\n\tv_mad_u64_u32 v[54:55], vcc, v40, v41, v[54:55]\n\t"
+                "v_mad_u64_u32 v[42:43], vcc, v40, v41, v[42:43]\n\tv_mad_u64_u32 v[46:47], vcc, v40, v41, v[46:47]\n\t"
+                "v_mad_u64_u32 v[50:51], vcc, v40, v41, v[50:51]\n\tv_mad_u64_u32 v[54:55], vcc, v40, v41, v[54:55]\n\t"
+                "v_mad_u64_u32 v[42:43], vcc, v40, v41, v[42:43]\n\tv_mad_u64_u32 v[46:47], vcc, v40, v41, v[46:47]\n\t"
+                "v_mad_u64_u32 v[50:51], vcc, v40, v41, v[50:51]\n\tv_mad_u64_u32 v[54:55], vcc, v40, v41, v[54:55]\n\t"
+                "v_mad_u64_u32 v[42:43], vcc, v40, v41, v[42:43]\n\tv_mad_u64_u32 v[46:47], vcc, v40, v41, v[46:47]\n\t"
+                "v_mad_u64_u32 v[50:51], vcc, v40, v41, v[50:51]\n\tv_mad_u64_u32 v[54:55], vcc, v40, v41, v[54:55]\n\t"
+                "v_xor_b32 %2, v42, v46\n\tv_xor_b32 %2, %2, v50\n\tv_xor_b32 %2, %2, v54"
+                : : "v"(a), "v"(b), "v"(r0)
+                : "vcc", "v40", "v41", "v42", "v43", "v46", "v47", "v50", "v51", "v54", "v55");
+        } else if constexpr (KIND == 46) {  // MAD, explicit registers, both factors and the addend's low dword in ONE bank
+            asm volatile(
+                "v_mov_b32 v40, %0\n\tv_mov_b32 v44, %1\n\t"
+                "v_mad_u64_u32 v[48:49], vcc, v40, v44, v[48:49]\n\tv_mad_u64_u32 v[52:53], vcc, v40, v44, v[52:53]\n\t"
+                "v_mad_u64_u32 v[56:57], vcc, v40, v44, v[56:57]\n\tv_mad_u64_u32 v[60:61], vcc, v40, v44, v[60:61]\n\t"
+                "v_mad_u64_u32 v[48:49], vcc, v40, v44, v[48:49]\n\tv_mad_u64_u32 v[52:53], vcc, v40, v44, v[52:53]\n\t"
+                "v_mad_u64_u32 v[56:57], vcc, v40, v44, v[56:57]\n\tv_mad_u64_u32 v[60:61], vcc, v40, v44, v[60:61]\n\t"
+                "v_mad_u64_u32 v[48:49], vcc, v40, v44, v[48:49]\n\tv_mad_u64_u32 v[52:53], vcc, v40, v44, v[52:53]\n\t"
+                "v_mad_u64_u32 v[56:57], vcc, v40, v44, v[56:57]\n\tv_mad_u64_u32 v[60:61], vcc, v40, v44, v[60:61]\n\t"
+                "v_mad_u64_u32 v[48:49], vcc, v40, v44, v[48:49]\n\tv_mad_u64_u32 v[52:53], vcc, v40, v44, v[52:53]\n\t"
+                "v_mad_u64_u32 v[56:57], vcc, v40, v44, v[56:57]\n\tv_mad_u64_u32 v[60:61], vcc, v40, v44, v[60:61]\n\t"
+                "v_xor_b32 %2, v48, v52\n\tv_xor_b32 %2, %2, v56\n\tv_xor_b32 %2, %2, v60"
+                : : "v"(a), "v"(b), "v"(r0)
+                : "vcc", "v40", "v44", "v48", "v49", "v52", "v53", "v56", "v57", "v60", "v61");
+        } else if constexpr (KIND == 47) {  // v_mad_u64_u32 with src0 == src1 (squaring term: 3 source dwords)
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(q##i) : "v"(a) : "vcc");
+            REP8(X) REP8(X)
+#undef X
         } else if constexpr (KIND == 23) {  // v_mad_i32_i24 ... placeholder for v_perm/v_bfe: v_bfe_u32
 #define X(i) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(r##i));
             REP8(X) REP8(X)
@@ -241,6 +277,8 @@ static const Kind kinds[] = {
     {35, "v_mad_i64_i32"}, {43, "v_mad_u64_u32(separate dst)"}, {36, "field column: 12 mad + 2 and + 2 shift64"},
     {37, "v_fma_f32(16 chains, dst != src)"}, {38, "v_add_u32(inline const)"}, {39, "v_pk_fma_f32"},
     {40, "mad64+addc pair (saturated radix)"}, {41, "v_lshl_add_u32"}, {42, "v_or_b32"},
+    {44, "v_mad_u64_u32(dependent, ping-pong dst)"}, {45, "v_mad_u64_u32(operands in 4 banks)"},
+    {46, "v_mad_u64_u32(operands in 1 bank)"}, {47, "v_mad_u64_u32(src0 == src1)"},
 };
 
 static unsigned long long* g_ticks;
@@ -252,7 +290,7 @@ static void dispatch(int kind, int blocks, unsigned* d, hipStream_t s)
 #define C(k) case k: launch<k>(blocks, d, s); break;
         C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(18)
         C(19) C(20) C(21) C(22) C(23) C(24) C(25) C(26) C(27) C(28) C(29) C(30) C(31) C(32) C(33) C(34) C(35) C(36)
-        C(37) C(38) C(39) C(40) C(41) C(42) C(43)
+        C(37) C(38) C(39) C(40) C(41) C(42) C(43) C(44) C(45) C(46) C(47)
 #undef C
     }
 }
@@ -292,11 +330,11 @@ int main(int argc, char** argv)
             const double scale = k.id == 39 ? 2.0 : 1.0;                      // packed: two lane-ops per lane
             double insts = (double)blocks * 4 /*waves*/ * ITERS * per_iter;   // wave-instructions
             double lane_ops_per_s = scale * insts * 64 / (best * 1e-3);
-            // wave 0's own loop: `wps` waves share its SIMD, so the SIMD issued wps * ITERS * per_iter instructions
-            // in `ticks` shader cycles
-            double clk_per_inst = (double)ticks / ((double)wps * ITERS * per_iter);
-            double eff_ghz = (double)ticks / (best * 1e-3) / 1e9;             // kernel ~= one wave's loop + launch
-            printf("wps=%d %-42s %8.3f ms  %8.2f Tlane-op/s  %6.2f SIMD-cycles/wave-instr  (%.2f GHz sustained)\n", wps,
+            // wave 0 is the oldest wave of its SIMD and keeps issue priority: `ticks` is how long ITS loop took,
+            // i.e. the single-wave issue interval (meaningful at wps = 1, where ticks / time is also the clock)
+            double clk_per_inst = (double)ticks / ((double)ITERS * per_iter);
+            double eff_ghz = (double)ticks / (best * 1e-3) / 1e9;
+            printf("wps=%d %-42s %8.3f ms  %8.2f Tlane-op/s  %6.2f cycles/instr for the oldest wave  (ticks/time %.2f GHz)\n", wps,
                    k.name, best, lane_ops_per_s / 1e12, clk_per_inst, eff_ghz);
             if (jf) {
                 fprintf(jf, "%s  \"%s@wps%d\": %.4e", first ? "" : ",\n", k.name, wps, lane_ops_per_s); first = false;
