@@ -36,6 +36,12 @@ SIGNATURES = {
     "ed25519_CreateKeyPair_blinded_dev": [_vp, _vp, _vp, _vp, _sz, _vp],
     "ed25519_SignMessage_blinded_batch": [_vp, _vp, _vp, _vp, _sz, _sz],
     "ed25519_SignMessage_blinded_dev": [_vp, _vp, _vp, _vp, _sz, _sz, _vp],
+    "c25519_amd_multi_create": [_vp, _vp, C.c_int],
+    "c25519_amd_multi_destroy": [_vp],
+    "c25519_amd_multi_device_count": [_vp],
+    "curve25519_dh_CreateSharedKey_multi": [_vp, _vp, _vp, _vp, _sz],
+    "ed25519_SignMessage_multi": [_vp, _vp, _vp, _vp, _sz, _sz],
+    "ed25519_VerifySignature_multi": [_vp, _vp, _vp, _vp, _vp, _sz, _sz],
     "c25519_amd_base_table": [_vp],
     "c25519_amd_sc_selftest": [_vp, _vp, _vp, _sz, C.c_int],
     "c25519_amd_fold_selftest": [_vp, _vp, _sz],
@@ -73,6 +79,7 @@ _RESTYPE = {
     "ed25519_Blinding_Finish": None,
     "ed25519_Verify_Finish": None,
     "c25519_amd_thread_release": None,
+    "c25519_amd_multi_destroy": None,
 }
 
 _lib = None

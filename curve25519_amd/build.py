@@ -37,7 +37,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: the gfx950 library cannot be built on this machine")
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           os.path.join(CSRC, "engine.hip"), "-o", LIB + ".tmp"]
+           os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "multi_device.hip"), "-ldl", "-o", LIB + ".tmp"]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), file=sys.stderr)

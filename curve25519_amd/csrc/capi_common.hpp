@@ -65,9 +65,10 @@ inline void arm_exit_guard()
     if (!armed.exchange(true)) atexit([] { runtime_alive().store(false); });
 }
 
-// Per-host-thread device resources.  Everything belongs to ONE device (`device`); when the thread calls in with
-// another current device, the old device's resources are released first (on that device).  Released by
-// c25519_amd_thread_release(), or when the thread exits while the runtime is still alive.
+// Per-host-thread device resources.  The staging side (streams, pinned + device buffers of the *_batch pipeline)
+// belongs to ONE device (`device`): when the thread calls a *_batch function with another current device, the old
+// device's staging is released first, on that device.  Work scratch of the *_dev functions is kept per device.
+// Everything is released by c25519_amd_thread_release(), or when the thread exits while the runtime is still alive.
 struct ThreadState {
     static constexpr int LANES = 3;        // pipeline depth of the host-pointer (*_batch) entry points
     static constexpr int SLOTS = 5;        // arrays per lane (inputs, outputs, in/out)
@@ -78,13 +79,18 @@ struct ThreadState {
     size_t dcap[LANES][SLOTS] = {};
     void* hbuf[LANES][SLOTS] = {};         // pinned host staging (hipHostMalloc)
     size_t hcap[LANES][SLOTS] = {};
-    // work scratch of the *_dev entry points: one grow-only slab; consecutive calls reuse it in stream order, a call
-    // on another stream first waits for the previous use
-    void* work = nullptr;
-    size_t work_cap = 0;
-    hipEvent_t work_done = nullptr;
-    hipStream_t work_last = nullptr;
-    bool work_used = false;
+    // work scratch of the *_dev entry points: one grow-only slab PER DEVICE (a thread may drive several GPUs, see
+    // multi_device.hip); consecutive calls reuse it in stream order, a call on another stream first waits for the
+    // previous use
+    static constexpr int MAX_DEV = 64;
+    struct WorkSlab {
+        void* ptr = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+        hipStream_t last = nullptr;
+        bool used = false;
+    };
+    WorkSlab work[MAX_DEV];
 
     // bind to the current device (creating streams/events on first use)
     int ensure()
@@ -93,7 +99,7 @@ struct ThreadState {
         C25519_TRY(hipGetDevice(&dev));
         arm_exit_guard();
         if (device >= 0 && dev != device) {
-            release();
+            release_staging();
             C25519_TRY(hipSetDevice(dev));
         }
         if (device < 0) {
@@ -101,7 +107,6 @@ struct ThreadState {
                 C25519_TRY(hipStreamCreateWithFlags(&stream[l], hipStreamNonBlocking));
                 C25519_TRY(hipEventCreateWithFlags(&done[l], hipEventDisableTiming));
             }
-            C25519_TRY(hipEventCreateWithFlags(&work_done, hipEventDisableTiming));
             device = dev;
         }
         return 0;
@@ -126,29 +131,37 @@ struct ThreadState {
     }
     int acquire_work(void** out, size_t bytes, hipStream_t s)
     {
-        C25519_RC(ensure());
-        if (work && bytes > work_cap) {
+        int dev = 0;
+        C25519_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= MAX_DEV) return bad_arg("device ordinal out of range");
+        arm_exit_guard();
+        WorkSlab& w = work[dev];
+        if (w.ptr && bytes > w.cap) {
             C25519_TRY(hipDeviceSynchronize());
-            C25519_TRY(hipFree(work));
-            work = nullptr; work_cap = 0; work_used = false;
+            C25519_TRY(hipFree(w.ptr));
+            w.ptr = nullptr; w.cap = 0; w.used = false;
         }
-        if (!work) {
+        if (!w.ptr) {
             const size_t want = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes;
-            C25519_TRY(hipMalloc(&work, want));
-            work_cap = want;
+            C25519_TRY(hipMalloc(&w.ptr, want));
+            w.cap = want;
         }
-        if (work_used && s != work_last) C25519_TRY(hipStreamWaitEvent(s, work_done, 0));
-        *out = work;
+        if (!w.done) C25519_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+        if (w.used && s != w.last) C25519_TRY(hipStreamWaitEvent(s, w.done, 0));
+        *out = w.ptr;
         return 0;
     }
     int release_work(hipStream_t s)
     {
-        C25519_TRY(hipEventRecord(work_done, s));
-        work_last = s; work_used = true;
+        int dev = 0;
+        C25519_TRY(hipGetDevice(&dev));
+        WorkSlab& w = work[dev];
+        C25519_TRY(hipEventRecord(w.done, s));
+        w.last = s; w.used = true;
         return 0;
     }
-    // free everything on the owning device (the buffers held staged secrets: they are zeroed first)
-    void release()
+    // free the staging side on its device (the buffers held staged secrets: they are zeroed first)
+    void release_staging()
     {
         if (device < 0) return;
         int cur = -1;
@@ -165,12 +178,27 @@ struct ThreadState {
             if (done[l]) (void)hipEventDestroy(done[l]);
             stream[l] = nullptr; done[l] = nullptr;
         }
-        if (work) { (void)hipMemset(work, 0, work_cap); (void)hipFree(work); }
-        if (work_done) (void)hipEventDestroy(work_done);
-        work = nullptr; work_cap = 0; work_done = nullptr; work_last = nullptr; work_used = false;
         (void)hipGetLastError();
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
         device = -1;
+    }
+    // ... and everything: staging plus every device's work scratch
+    void release()
+    {
+        release_staging();
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        for (int d = 0; d < MAX_DEV; d++) {
+            WorkSlab& w = work[d];
+            if (!w.ptr && !w.done) continue;
+            (void)hipSetDevice(d);
+            (void)hipDeviceSynchronize();
+            if (w.ptr) { (void)hipMemset(w.ptr, 0, w.cap); (void)hipFree(w.ptr); }
+            if (w.done) (void)hipEventDestroy(w.done);
+            w = WorkSlab();
+        }
+        (void)hipGetLastError();
+        if (cur >= 0) (void)hipSetDevice(cur);
     }
     ~ThreadState()
     {

@@ -116,6 +116,25 @@ int ed25519_Verify_Check_batch(int *verdict, const void *ctx, const unsigned cha
 int ed25519_Verify_Check_dev(void *verdict, const void *ctx, const void *sig, const void *msg,
                              size_t msg_size, size_t n, void *stream);
 
+/* Multi-GPU (BASELINE.json north_star: "batches shard embarrassingly across the 8 GPUs of one node
+ * with a single RCCL gather over xGMI") ------------------------------------------------------------------------------
+ * One host thread drives n_dev devices.  A call cuts the batch into contiguous shards (device d owns elements
+ * [n*d/n_dev, n*(d+1)/n_dev)), every device uploads its shard and runs the same kernels as the single-GPU entry points
+ * on its own stream, and each result array is gathered to devices[0] with ONE grouped ncclGather (RCCL,
+ * /opt/rocm/include/rccl/rccl.h:745; loaded with dlopen on first use) before the host reads it from the root device.
+ * Host pointers, synchronous, same byte layouts and results as the *_batch functions.  The handle owns one stream, one
+ * RCCL communicator and grow-only staging buffers per device; it is not thread-safe (one handle per calling thread). */
+typedef struct c25519_amd_multi c25519_amd_multi;
+int  c25519_amd_multi_create(c25519_amd_multi **m, const int *devices, int n_dev);
+void c25519_amd_multi_destroy(c25519_amd_multi *m);
+int  c25519_amd_multi_device_count(const c25519_amd_multi *m);
+int curve25519_dh_CreateSharedKey_multi(c25519_amd_multi *m, unsigned char *shared, const unsigned char *pk,
+                                        unsigned char *sk, size_t n);
+int ed25519_SignMessage_multi(c25519_amd_multi *m, unsigned char *sig, const unsigned char *priv,
+                              const unsigned char *msg, size_t msg_size, size_t n);
+int ed25519_VerifySignature_multi(c25519_amd_multi *m, int *verdict, const unsigned char *sig, const unsigned char *pk,
+                                  const unsigned char *msg, size_t msg_size, size_t n);
+
 /* introspection used by tests and bench ------------------------------------------------------ */
 /* copies the device-generated 256 x 96-byte 8-fold base table (canonical Y+X, Y-X, 2dT rows --
  * the content of reference source/base_folding8.h) to `out` */

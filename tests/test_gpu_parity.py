@@ -634,3 +634,36 @@ def test_bench_mixed_and_self_launch_run():
         if "mixed" in extra:
             assert line["verify_rejects_exactly_the_corrupted"] is True
             assert set(line["roofline"]["parts"]) == {"x25519", "sign", "verify"}
+
+
+def test_c_abi_multi_device_entry_points(api):
+    """The C-level multi-GPU entry points (shards per device, one grouped ncclGather per output to devices[0]) with the
+    devices this box has -- one here, so RCCL runs a communicator of one rank; the shard / gather / read-back
+    bookkeeping is the same code for any count.  Results are the fixture's (the reference's) bytes."""
+    from curve25519_amd import _lib
+    L = _lib.load()
+    ndev = min(api.device_count(), 8)
+    devs = (C.c_int * ndev)(*range(ndev))
+    h = C.c_void_p()
+    _lib.check(L.c25519_amd_multi_create(C.byref(h), devs, ndev), "c25519_amd_multi_create")
+    try:
+        assert L.c25519_amd_multi_device_count(h) == ndev
+        g = {k: np.ascontiguousarray(R1024[k]) for k in R1024.files}     # materialise once: ctypes gets raw pointers
+        for n in (1024, 1000, 1):
+            sk, pk = g["x_sk"][:n].copy(), g["x_pk"][:n].copy()
+            shared = np.empty((n, 32), np.uint8)
+            _lib.check(L.curve25519_dh_CreateSharedKey_multi(h, shared.ctypes.data, pk.ctypes.data, sk.ctypes.data, n), "x25519 multi")
+            assert np.array_equal(shared, g["x_shared"][:n]) and np.array_equal(sk, g["x_sk_clamped"][:n])
+            sig = np.empty((n, 64), np.uint8)
+            priv, msg = np.ascontiguousarray(g["ed_priv"][:n]), np.ascontiguousarray(g["ed_msg"][:n])
+            _lib.check(L.ed25519_SignMessage_multi(h, sig.ctypes.data, priv.ctypes.data, msg.ctypes.data, 32, n), "sign multi")
+            assert np.array_equal(sig, g["ed_sig"][:n])
+            ok = np.empty(n, np.int32)
+            vs, vm, pub = np.ascontiguousarray(g["v_sig"][:n]), np.ascontiguousarray(g["v_msg"][:n]), np.ascontiguousarray(g["ed_pub"][:n])
+            _lib.check(L.ed25519_VerifySignature_multi(h, ok.ctypes.data, vs.ctypes.data, pub.ctypes.data, vm.ctypes.data, 32, n), "verify multi")
+            assert np.array_equal(ok, g["v_ok"][:n])
+        assert L.curve25519_dh_CreateSharedKey_multi(h, shared.ctypes.data, g["x_pk"].ctypes.data, sk.ctypes.data, 0) == 0
+    finally:
+        L.c25519_amd_multi_destroy(h)
+    bad = (C.c_int * 1)(63)
+    assert L.c25519_amd_multi_create(C.byref(h), bad, 1) != 0
