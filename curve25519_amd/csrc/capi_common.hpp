@@ -70,7 +70,7 @@ inline void arm_exit_guard()
 // device's staging is released first, on that device.  Work scratch of the *_dev functions is kept per device.
 // Everything is released by c25519_amd_thread_release(), or when the thread exits while the runtime is still alive.
 struct ThreadState {
-    static constexpr int LANES = 3;        // pipeline depth of the host-pointer (*_batch) entry points
+    static constexpr int LANES = 4;        // pipeline depth of the host-pointer (*_batch) entry points
     static constexpr int SLOTS = 5;        // arrays per lane (inputs, outputs, in/out)
     int device = -1;
     hipStream_t stream[LANES] = {};

@@ -23,6 +23,7 @@
 #include <initializer_list>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 using namespace c25519;
 
@@ -647,12 +648,15 @@ int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t 
 }
 
 // ---- host-pointer pipeline used by the *_batch entry points -------------------------------------------------------
-// A call is cut into chunks that rotate over LANES (stream, pinned host buffers, device buffers) sets:
-//     stage-in  : CPU copies the caller's (pageable) arrays into the lane's pinned buffers
-//     enqueue   : H2D copies, the *_dev kernels, D2H copies into pinned buffers, all asynchronous on the lane's stream
-//     stage-out : once the lane's event has fired, CPU copies the results into the caller's arrays
-// Stage-out runs on a helper thread, stage-in on the calling thread, so that both CPU copies and both PCIe directions
-// ride under the kernels of the neighbouring chunks (pinned memory: hipMemcpyAsync is a real DMA, not a staged copy).
+// A call is cut into pieces that rotate over LANES (stream, pinned host buffers, device buffers) sets; three roles
+// work on different pieces at the same time:
+//     stage-in  : two helper threads copy the caller's (pageable) arrays into a lane's pinned buffers
+//     submit    : the calling thread enqueues H2D copies, the *_dev kernels and D2H copies into pinned buffers, all
+//                 asynchronous on the lane's stream (pinned memory: hipMemcpyAsync is a real DMA, not a staged copy)
+//     stage-out : a helper thread waits for the lane's event and copies the results into the caller's arrays
+// so both CPU copies and both PCIe directions ride under the kernels of the neighbouring pieces.  Pieces are n/8 for
+// big batches: the chip needs ~2^19 lanes in flight to run at full rate, and a piece cannot finish faster than one
+// ladder's latency (~1.2 ms), so fewer, larger pieces in flight beat many small ones (measured, profiles/r02_hostapi.txt).
 struct Arr {
     const void* in;      // caller's source (nullptr: output only)
     void* out;           // caller's destination (nullptr: input only); in and out may both be set (IN/OUT array)
@@ -669,11 +673,10 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     if (na > ThreadState::SLOTS) return bad_arg("internal: too many arrays");
     size_t row = 0;
     for (int a = 0; a < na; a++) row += arr[a].elem;
-    // chunking: big batches in >= 8 pieces so that three can be in flight; small ones in one piece
-    size_t chunk = n;
-    if (n >= ((size_t)1 << 17)) chunk = round_up((n + 7) / 8, 256);
-    const size_t max_chunk_bytes = (size_t)256 << 20;
-    while (chunk > 256 && chunk * row > max_chunk_bytes) chunk = round_up(chunk / 2, 256);
+    static const size_t pieces = [] { const char* e = getenv("C25519_AMD_BATCH_PIECES"); int v = e ? atoi(e) : 0; return (size_t)(v >= 2 && v <= 64 ? v : 8); }();
+    size_t chunk = n >= ((size_t)1 << 17) ? round_up((n + pieces - 1) / pieces, 256) : n;
+    const size_t cap = round_up(((size_t)256 << 20) / (row ? row : 1) + 1, 256);       // <= 256 MiB of staging per lane
+    if (chunk > cap) chunk = cap;
     const size_t nchunks = (n + chunk - 1) / chunk;
     const int lanes = nchunks < (size_t)ThreadState::LANES ? (int)nchunks : ThreadState::LANES;
     for (int l = 0; l < lanes; l++)
@@ -681,87 +684,101 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
             C25519_RC(t.reserve_dev(l, a, arr[a].elem * chunk));
             C25519_RC(t.reserve_host(l, a, arr[a].elem * chunk));
         }
-
-    // stage-out worker: consumes chunk indices in order
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t submitted = 0, drained = 0;
-    int worker_rc = 0;
-    bool abort_all = false;
-    auto drain_one = [&](size_t c) -> int {
+    auto span = [&](size_t c, size_t& lo, size_t& cnt) { lo = c * chunk; cnt = (n - lo < chunk) ? n - lo : chunk; };
+    auto stage_in = [&](size_t c) {
+        size_t lo, cnt;
+        span(c, lo, cnt);
         const int l = (int)(c % lanes);
-        const size_t lo = c * chunk, cnt = (n - lo < chunk) ? n - lo : chunk;
-        C25519_TRY(hipEventSynchronize(t.done[l]));
         for (int a = 0; a < na; a++)
-            if (arr[a].out) memcpy((char*)arr[a].out + lo * arr[a].elem, t.hbuf[l][a], cnt * arr[a].elem);
-        return 0;
+            if (arr[a].in && cnt * arr[a].elem) memcpy(t.hbuf[l][a], (const char*)arr[a].in + lo * arr[a].elem, cnt * arr[a].elem);
     };
-    const bool threaded = nchunks > 1;
-    std::thread worker;
-    if (threaded)
-        worker = std::thread([&] {
-            for (size_t c = 0; c < nchunks; c++) {
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return submitted > c || abort_all; });
-                    if (abort_all) return;
-                }
-                const int rc = drain_one(c);
-                std::lock_guard<std::mutex> lk(mu);
-                if (rc && !worker_rc) worker_rc = rc;
-                drained = c + 1;
-                cv.notify_all();
-            }
-        });
-    auto stop_worker = [&](int rc) {
-        if (threaded) {
-            { std::lock_guard<std::mutex> lk(mu); abort_all = true; }
-            cv.notify_all();
-            worker.join();
-        }
-        return rc;
-    };
-
-    int rc = 0;
-    for (size_t c = 0; c < nchunks && !rc; c++) {
+    auto submit = [&](size_t c) -> int {
+        size_t lo, cnt;
+        span(c, lo, cnt);
         const int l = (int)(c % lanes);
-        const size_t lo = c * chunk, cnt = (n - lo < chunk) ? n - lo : chunk;
-        if (threaded && c >= (size_t)lanes) {           // the lane's previous chunk must have left its pinned buffers
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return drained > c - lanes || worker_rc; });
-            if (worker_rc) { rc = worker_rc; break; }
-        }
         hipStream_t st = t.stream[l];
         void* dptr[ThreadState::SLOTS] = {};
         for (int a = 0; a < na; a++) {
             dptr[a] = t.dbuf[l][a];
-            if (arr[a].in && cnt * arr[a].elem) {
-                memcpy(t.hbuf[l][a], (const char*)arr[a].in + lo * arr[a].elem, cnt * arr[a].elem);
-                if (hipMemcpyAsync(dptr[a], t.hbuf[l][a], cnt * arr[a].elem, hipMemcpyHostToDevice, st) != hipSuccess)
-                    rc = c25519_host::fail(hipGetLastError(), "hipMemcpyAsync(H2D)", __FILE__, __LINE__);
+            if (arr[a].in && cnt * arr[a].elem)
+                C25519_TRY(hipMemcpyAsync(dptr[a], t.hbuf[l][a], cnt * arr[a].elem, hipMemcpyHostToDevice, st));
+        }
+        C25519_RC(launch(dptr, cnt, lo, st));
+        for (int a = 0; a < na; a++)
+            if (arr[a].out && cnt * arr[a].elem)
+                C25519_TRY(hipMemcpyAsync(t.hbuf[l][a], dptr[a], cnt * arr[a].elem, hipMemcpyDeviceToHost, st));
+        C25519_TRY(hipEventRecord(t.done[l], st));
+        return 0;
+    };
+    auto drain = [&](size_t c) -> int {
+        size_t lo, cnt;
+        span(c, lo, cnt);
+        const int l = (int)(c % lanes);
+        C25519_TRY(hipEventSynchronize(t.done[l]));
+        for (int a = 0; a < na; a++)
+            if (arr[a].out && cnt * arr[a].elem) memcpy((char*)arr[a].out + lo * arr[a].elem, t.hbuf[l][a], cnt * arr[a].elem);
+        return 0;
+    };
+
+    if (nchunks == 1) {                                   // small batch: no helper threads
+        stage_in(0);
+        C25519_RC(submit(0));
+        return drain(0);
+    }
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> staged(nchunks, 0);
+    size_t submitted = 0, drained = 0;
+    int failed = 0;                                       // first error of any role; everybody stops
+    constexpr int STAGERS = 2;
+    std::thread helpers[STAGERS + 1];
+    for (int sidx = 0; sidx < STAGERS; sidx++)
+        helpers[sidx] = std::thread([&, sidx] {
+            for (size_t c = sidx; c < nchunks; c += STAGERS) {
+                {   // the lane's previous piece must have left its pinned buffers
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return failed || c < (size_t)lanes || drained > c - lanes; });
+                    if (failed) return;
+                }
+                stage_in(c);
+                { std::lock_guard<std::mutex> lk(mu); staged[c] = 1; }
+                cv.notify_all();
             }
-        }
-        if (!rc) rc = launch(dptr, cnt, lo, st);
-        for (int a = 0; a < na && !rc; a++)
-            if (arr[a].out && cnt * arr[a].elem &&
-                hipMemcpyAsync(t.hbuf[l][a], dptr[a], cnt * arr[a].elem, hipMemcpyDeviceToHost, st) != hipSuccess)
-                rc = c25519_host::fail(hipGetLastError(), "hipMemcpyAsync(D2H)", __FILE__, __LINE__);
-        if (!rc && hipEventRecord(t.done[l], st) != hipSuccess)
-            rc = c25519_host::fail(hipGetLastError(), "hipEventRecord", __FILE__, __LINE__);
-        if (rc) break;
-        if (threaded) {
-            { std::lock_guard<std::mutex> lk(mu); submitted = c + 1; }
+        });
+    helpers[STAGERS] = std::thread([&] {
+        for (size_t c = 0; c < nchunks; c++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return failed || submitted > c; });
+                if (failed) return;
+            }
+            const int rc = drain(c);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc && !failed) failed = rc;
+                drained = c + 1;
+            }
             cv.notify_all();
-        } else {
-            rc = drain_one(c);
         }
+    });
+    for (size_t c = 0; c < nchunks; c++) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return failed || staged[c]; });
+            if (failed) break;
+        }
+        const int rc = submit(c);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc && !failed) failed = rc;
+            submitted = c + 1;
+        }
+        cv.notify_all();
+        if (rc) break;
     }
-    if (rc) return stop_worker(rc);
-    if (threaded) {
-        worker.join();
-        if (worker_rc) return worker_rc;
-    }
-    return 0;
+    for (auto& h : helpers) h.join();
+    return failed;
 }
 
 inline size_t verify_scratch_bytes(size_t n)

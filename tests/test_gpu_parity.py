@@ -667,3 +667,40 @@ def test_c_abi_multi_device_entry_points(api):
         L.c25519_amd_multi_destroy(h)
     bad = (C.c_int * 1)(63)
     assert L.c25519_amd_multi_create(C.byref(h), bad, 1) != 0
+
+
+def test_host_pointer_api_keeps_up_with_the_device_rate(api):
+    """The *_batch entry point a C caller of the drop-in API uses (pageable host arrays in and out) must stay close to
+    the device-resident rate at the benchmark size: pinned staging, two stage-in threads and one stage-out thread keep
+    both PCIe directions under the kernels.  Measured 0.83 on MI355X (profiles/r02_hostapi.txt); round 1 was 0.48."""
+    import time
+    import torch
+    from curve25519_amd import _lib
+    L = _lib.load()
+    n = 1 << 20
+    sk, pk = synth.x25519_inputs(n)
+    out = np.zeros((n, 32), np.uint8)
+    dev = torch.device("cuda", 0)
+    dsk, dpk, dout = torch.from_numpy(sk).to(dev), torch.from_numpy(pk).to(dev), torch.empty((n, 32), dtype=torch.uint8, device=dev)
+
+    def host():
+        assert L.curve25519_dh_CreateSharedKey_batch(out.ctypes.data, pk.ctypes.data, sk.ctypes.data, n) == 0
+
+    def device():
+        api.curve25519_dh_CreateSharedKey_dev(dout, dpk, dsk)
+        torch.cuda.synchronize()
+
+    best = {}
+    for name, fn in (("host", host), ("dev", device)):
+        fn()
+        fn()
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        best[name] = min(ts)
+    assert np.array_equal(out, dout.cpu().numpy())
+    ratio = best["dev"] / best["host"]
+    print(f"host-pointer X25519: {n / best['host'] / 1e6:.1f} M ops/s, device-resident {n / best['dev'] / 1e6:.1f} M ops/s, ratio {ratio:.2f}")
+    assert ratio >= 0.7, best
