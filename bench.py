@@ -69,12 +69,14 @@ def latest_profile(pattern):
 
 
 def measured_mad_peak():
-    """lane-MAC/s of v_mad_u64_u32 measured by tools/ubench/valu_rates on MI355X (committed summary)."""
+    """lane-MAC/s of v_mad_u64_u32 in its ACCUMULATING form (d = a*b + d, what a multi-precision column is made of),
+    measured by tools/ubench/valu_rates on MI355X at 8 waves per SIMD (committed summary).  The same file also has the
+    non-accumulating forms (zero addend, SGPR factor: ~9 % faster issue), which no column chain can use."""
     try:
         path = latest_profile("r[0-9][0-9]_valu_rates.json")
         with open(path) as f:
             rates = json.load(f)["rates"]
-        return max(v for k, v in rates.items() if k.startswith("v_mad_u64_u32")), os.path.basename(path)
+        return max(v for k, v in rates.items() if k.startswith("v_mad_u64_u32@")), os.path.basename(path)
     except Exception:
         return None, None
 

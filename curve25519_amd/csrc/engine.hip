@@ -43,6 +43,9 @@ struct ProjScratch {            // projective result + prefix products of the ba
 #ifndef C25519_XF_BLOCK
 #define C25519_XF_BLOCK 512
 #endif
+#ifndef C25519_XF_WAVES
+#define C25519_XF_WAVES 4             // waves per SIMD the register allocator aims at (A/B: profiles/r02_ab_occupancy.txt)
+#endif
 constexpr int XF_BLOCK = C25519_XF_BLOCK;     // waves per workgroup = elements per inverting lane
 constexpr int XF_K = XF_BLOCK / 64;
 
@@ -73,7 +76,7 @@ C25519_DEV u32 fe_zero_to_one(fe& z)
 }
 
 template <bool BASE9>
-__global__ void __launch_bounds__(XF_BLOCK, 4) k_x25519_fused(void* out, const void* pk, void* sk, size_t n)
+__global__ void __launch_bounds__(XF_BLOCK, C25519_XF_WAVES) k_x25519_fused(void* out, const void* pk, void* sk, size_t n)
 {
     __shared__ u32 zbuf[10 * XF_BLOCK];      // PZ, later 1/PZ
     __shared__ u32 xbuf[10 * XF_BLOCK];      // PX

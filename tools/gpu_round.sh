@@ -18,7 +18,7 @@ fi
 if has bench; then
   timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
   timeout 300 python bench.py --steps 10 --warmup 3 --workload mixed --no-cpu > $OUT/bench_mixed.json 2> $OUT/bench_mixed.err; echo "mixed rc=$?"
-  timeout 300 python bench.py --steps 5 --warmup 2 --dist-selftest --no-cpu > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "dist1 rc=$?"
+  timeout 300 python bench.py --steps 20 --warmup 5 --dist-selftest --no-side --no-cpu > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "dist1 rc=$?"
   timeout 300 python tools/hostapi_rate.py --json $OUT/hostapi_rate.json > $OUT/hostapi_rate.txt 2>&1; echo "hostapi rc=$?"
   cat $OUT/hostapi_rate.txt
 fi
@@ -32,7 +32,7 @@ if has ab && ls build_ab/*.so >/dev/null 2>&1; then
 fi
 if has prof; then
   cd /tmp && export TMPDIR=/tmp
-  BENCH="python $REPO/bench.py --steps 24 --warmup 6 --no-cpu"
+  BENCH="python $REPO/bench.py --steps 60 --warmup 6 --no-cpu"
   timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o stats -- $BENCH > $OUT/prof_stats.log 2>&1
   BENCHX="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu"
   timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_fetch -o fetch -- $BENCHX > $OUT/prof_fetch.log 2>&1
