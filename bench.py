@@ -197,7 +197,7 @@ def self_launch(args):
     """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py ...`."""
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < args.gpus:
+    if have < args.gpus and not (have and os.environ.get("C25519_BENCH_SHARE_GPU")):
         raise SystemExit(f"bench.py --gpus {args.gpus}: this machine exposes {have} GPU(s) to this process "
                          "(the launcher is fine; the devices are missing)")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -244,13 +244,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # C25519_BENCH_SHARE_GPU=1: launcher self-test on a box with fewer GPUs than ranks -- the ranks share the devices
+    # that exist and gather over gloo (RCCL refuses a duplicate device).  Exercises the self-launch, rank and gather
+    # bookkeeping of the N > 1 path; the number it prints is NOT a multi-GPU measurement and says so.
+    share_gpu = bool(os.environ.get("C25519_BENCH_SHARE_GPU")) and torch.cuda.device_count() < world
+    dev_index = local_rank % torch.cuda.device_count() if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or args.dist_selftest
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.batch
     eng = HipEngine(dev)
@@ -331,7 +339,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         kms = [sum(events[k][j][0].elapsed_time(events[k][j][1]) for k in range(args.steps)) / max(1, args.steps)
@@ -402,7 +410,8 @@ def main():
             "vs_baseline": None, "dtype": "u64", "dtype_note": "26/25-bit limbs in u32 registers, 32x32+64->64-bit "
             "integer MACs (v_mad_u64_u32), bit-exact results", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAME[wl], "batch_per_gpu": n, "global_batch": n * world,
-                       "parallelism": f"shard{world}" + ("+rccl_gather" if use_dist else "")},
+                       "parallelism": f"shard{world}" + (("+gloo_gather_SHARED_GPU_SELFTEST" if share_gpu else "+rccl_gather")
+                                                          if use_dist else "")},
             "roofline": roof,
         }
         result.update(side)

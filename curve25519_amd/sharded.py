@@ -56,7 +56,12 @@ class OverlappedGather:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.out = [torch.empty((rows, width), dtype=dtype, device=device) for _ in range(2)]
-        self.recv = [[torch.empty((rows, width), dtype=dtype, device=device) for _ in range(self.world)]
+        # a gloo group (the launcher self-test, where several ranks share one GPU and RCCL would refuse the duplicate
+        # device) cannot move device memory: the rows are staged through host copies; RCCL gathers device buffers
+        self.host_staged = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+        wire = "cpu" if self.host_staged else device
+        self.wire = [torch.empty((rows, width), dtype=dtype, device=wire) for _ in range(2)] if self.host_staged else self.out
+        self.recv = [[torch.empty((rows, width), dtype=dtype, device=wire) for _ in range(self.world)]
                      for _ in range(2)] if self.rank == root else [None, None]
         self.work = [None, None]
         self.step = 0
@@ -72,7 +77,9 @@ class OverlappedGather:
     def submit(self):
         """Start gathering the buffer handed out by the last next_buffer() call."""
         b = self.step & 1
-        self.work[b] = dist.gather(self.out[b], self.recv[b], dst=self.root, group=self.group, async_op=True)
+        if self.host_staged:
+            self.wire[b].copy_(self.out[b])
+        self.work[b] = dist.gather(self.wire[b], self.recv[b], dst=self.root, group=self.group, async_op=True)
         self.step += 1
 
     def finish(self):

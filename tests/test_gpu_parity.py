@@ -704,3 +704,21 @@ def test_host_pointer_api_keeps_up_with_the_device_rate(api):
     ratio = best["dev"] / best["host"]
     print(f"host-pointer X25519: {n / best['host'] / 1e6:.1f} M ops/s, device-resident {n / best['dev'] / 1e6:.1f} M ops/s, ratio {ratio:.2f}")
     assert ratio >= 0.7, best
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` exactly as the driver invokes it, on a box with ONE GPU: C25519_BENCH_SHARE_GPU lets the
+    two ranks share it (gloo gather, since RCCL refuses a duplicate device), so the self-launch under
+    torch.distributed.run, the rank / seed / gather bookkeeping and the single JSON line from rank 0 are exercised
+    for real.  (The RCCL gather itself runs in --dist-selftest with a world of one.)"""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    if torch.cuda.device_count() < 2:
+        env["C25519_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", str(1 << 16), "--no-cpu"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(p.stdout.strip().splitlines()) == 1, p.stdout
+    line = json.loads(p.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2 << 16 and line["value"] > 0
+    assert line["verify"]["n_gpus"] == 2 and line["verify"]["rejects_exactly_the_corrupted"] is True
