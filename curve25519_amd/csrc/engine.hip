@@ -14,6 +14,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared engine.hip -o libcurve25519_amd.so
 #include "capi_common.hpp"
 #include "lanes.cuh"
+#include "verify_fast.cuh"
 
 #include "../../include/curve25519_amd.h"
 #include "../../include/curve25519_dh.h"
@@ -356,6 +357,108 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VC_WAVES) k_ed25519_verify_ch
     load32(pkw, pk, i);
     const Tbl tbl{ tables + i * stride_words };
     verify_check_lane(scr, n, i, sig, pkw, msgs, tbl, lds_tbl);
+}
+
+// ---- the lattice fast path (verify_fast.cuh): three kernels over the same 256-element workgroups ------------------------
+// per-element hand-over between them, struct-of-arrays: sigma[8], rho[5], tau[5] (biased), flag word
+//   bit 0  R decodes canonically onto the curve      bit 1  the key is on the curve
+//   bit 2  the short vector fits the walk             bit 3  tau < 0
+struct FastScratch {
+    u32 *tables;            // per lane: window table of +-Q, then of -R (2 x WTABLE_WORDS, lane-contiguous)
+    u32 *sigma, *rho, *tau, *flags;
+    u32 *wg_slow;           // per workgroup: some element needs the reference-order path
+};
+constexpr size_t FAST_TABLE_WORDS = 2 * WTABLE_WORDS;
+constexpr int FS_BLOCK = 256;
+
+// step 1: hash, short lattice vector, sigma -- integer work only (few registers, eight waves per SIMD)
+__global__ void __launch_bounds__(FS_BLOCK) k_ed25519_verify_fast_scalars(FastScratch fs, const void* sig, const void* pk,
+                                                                          Msgs msgs, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u32 pkw[8], Rw[8], Sw[8], sigma[8], rho[5], tau[5], tau_neg;
+    load32(pkw, pk, i);
+    load32(Rw, sig, 2 * i);
+    load32(Sw, sig, 2 * i + 1);
+    const u32 lat_ok = ed_verify_fast_scalars(sigma, rho, tau, tau_neg, pkw, Rw, Sw, msgs.ptr(i), msgs.len(i));
+    soa_store8(fs.sigma, n, i, sigma);
+#pragma unroll
+    for (int w = 0; w < 5; w++) { fs.rho[(size_t)w * n + i] = rho[w]; fs.tau[(size_t)w * n + i] = tau[w]; }
+    fs.flags[i] = (lat_ok & 4u) | (tau_neg & 8u);
+}
+
+// step 2: decode both points, build the two window tables; decides which workgroups the fast path keeps
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_fast_points(FastScratch fs, const void* sig, const void* pk,
+                                                                             size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    u32 slow = 0;
+    if (i < n) {
+        u32 pkw[8], Rw[8];
+        load32(pkw, pk, i);
+        load32(Rw, sig, 2 * i);
+        const u32 f = fs.flags[i];
+        const QTableLimbs tq{ fs.tables + i * FAST_TABLE_WORDS }, tr{ fs.tables + i * FAST_TABLE_WORDS + WTABLE_WORDS };
+        const u32 pts = ed_verify_fast_points(tq, tr, pkw, Rw, (f & 8u) ? 0xffffffffu : 0u);
+        fs.flags[i] = f | pts;
+        slow = !((f & 4u) && (pts & 2u));
+    }
+    const int any_slow = __syncthreads_or(slow != 0);
+    if (threadIdx.x == 0) fs.wg_slow[blockIdx.x] = any_slow ? 1u : 0u;
+}
+
+// the reference-order path for one element, start to finish (own table, own inversion): what ed25519_VerifySignature does
+// (ed25519_verify.c:163-176 = Verify_Init + Verify_Check), used for the workgroups the fast path gives up
+C25519_DEV int verify_reference_order_lane(const u32 (&pkw)[8], const void* sig, size_t i, const uint8_t* msg, size_t len,
+                                           u32* lane_table, const u32* lds_tbl)
+{
+    u32 Sw[8], h[8], Rw[8], enc[8], xw[8], yw[8];
+    const QTableLimbs tbl{ lane_table };
+    {
+        ge_ext Q;
+        ed_decode_neg_key(Q, pkw);
+        qtable_build(tbl, Q);
+    }
+    load32(Rw, sig, 2 * i);
+    ed_hram(h, Rw, pkw, msg, len);
+    sc_mod(h);
+    load32(Sw, sig, 2 * i + 1);
+    ge_ext T;
+    ge_poly_mult(T, Sw, h, tbl, lds_tbl);
+    ge_to_affine_words(xw, yw, T);                            // z^(p-2): Z == 0 gives 0 like the reference
+    ge_pack(enc, xw, yw);
+    u32 diff = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
+    return diff == 0 ? 1 : 0;
+}
+
+// step 3: the 140-doubling walk and the neutral-element test -- or, for a workgroup with an off-curve key or an
+// over-long vector among its 256 elements (rare), the reference's own operation order for all of them, in the same
+// launch (separate launches for these few workgroups cost 0.4 ms each even when they have nothing to do).
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_fast_walk(FastScratch fs, int* verdict, const void* sig,
+                                                                           const void* pk, Msgs msgs, size_t n,
+                                                                           const u32* __restrict__ g_tbl)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
+    lds_stage_base_table(lds_tbl, g_tbl + (BASE_NT - 1) * BASE_TBL_WORDS);
+    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u32* lane_tables = fs.tables + i * FAST_TABLE_WORDS;
+    if (fs.wg_slow[blockIdx.x]) {                              // uniform over the workgroup
+        u32 pkw[8];
+        load32(pkw, pk, i);
+        verdict[i] = verify_reference_order_lane(pkw, sig, i, msgs.ptr(i), msgs.len(i), lane_tables, lds_tbl);
+        return;
+    }
+    u32 sigma[8], rho[5], tau[5];
+    soa_load8(sigma, fs.sigma, n, i);
+#pragma unroll
+    for (int w = 0; w < 5; w++) { rho[w] = fs.rho[(size_t)w * n + i]; tau[w] = fs.tau[(size_t)w * n + i]; }
+    const QTableLimbs tq{ lane_tables }, tr{ lane_tables + WTABLE_WORDS };
+    const u32 neutral = ge_walk_is_neutral(sigma, tau, rho, tq, tr, lds_tbl);
+    verdict[i] = (neutral & fs.flags[i] & 1u) ? 1 : 0;
 }
 
 // Same check with ONE key for the whole batch (the reference's two-phase use: Verify_Init once, many
@@ -784,14 +887,24 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     return failed;
 }
 
+// scratch of one verification pass: per-lane tables (the larger of the two paths' formats: they never live at the same
+// time for one workgroup), projective results of the reference-order path, the fast path's scalars and flags
+constexpr size_t VERIFY_TABLE_WORDS = FAST_TABLE_WORDS > QTABLE_LIMB_WORDS ? FAST_TABLE_WORDS : QTABLE_LIMB_WORDS;
+inline size_t verify_scalar_words(size_t n) { return round_up(8 * n, 4) + 2 * round_up(5 * n, 4) + round_up(n, 4) + round_up(grid_for(n, ED_BLOCK), 4); }
 inline size_t verify_scratch_bytes(size_t n)
 {
-    return (n * QTABLE_LIMB_WORDS + proj_words(n)) * sizeof(u32);
+    return (n * VERIFY_TABLE_WORDS + proj_words(n) + verify_scalar_words(n)) * sizeof(u32);
 }
 
-// Init + Check on per-lane tables; Fin decides what leaves: the verdict, or enc(T) for the test hook
+// fast = true: the lattice path (verify_fast.cuh) decides every workgroup whose keys are all on the curve and whose
+// short vectors fit; the others run the reference's order inside the same walk kernel.  fast = false: reference order
+// for everything in its own kernels, and Fin decides what leaves it: the verdict, or enc(T) for the test hook.
+// where the calling thread's last fast-path verification left its per-workgroup flags (c25519_amd_verify_last_slow_groups)
+struct LastVerify { const u32* wg_slow = nullptr; unsigned groups = 0; hipStream_t stream = nullptr; int device = -1; };
+thread_local LastVerify tl_last_verify;
+
 template <typename MakeFin>
-int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t stream, MakeFin make_fin)
+int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t stream, int* verdict, bool fast, MakeFin make_fin)
 {
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
@@ -799,10 +912,29 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
     C25519_RC(tls().acquire_work(&w, verify_scratch_bytes(n), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     u32* tables = (u32*)w + proj_words(n);
-    k_ed25519_verify_init<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(pk, n, tables, QTABLE_LIMB_WORDS);
+    const unsigned grid = grid_for(n, ED_BLOCK);
+    if (fast) {
+        FastScratch fs;
+        fs.tables = tables;
+        fs.sigma = tables + n * VERIFY_TABLE_WORDS;
+        fs.rho = fs.sigma + round_up(8 * n, 4);
+        fs.tau = fs.rho + round_up(5 * n, 4);
+        fs.flags = fs.tau + round_up(5 * n, 4);
+        fs.wg_slow = fs.flags + round_up(n, 4);
+        k_ed25519_verify_fast_scalars<<<grid_for(n, FS_BLOCK), FS_BLOCK, 0, stream>>>(fs, sig, pk, msgs, n);
+        C25519_TRY(hipGetLastError());
+        k_ed25519_verify_fast_points<<<grid, ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
+        C25519_TRY(hipGetLastError());
+        k_ed25519_verify_fast_walk<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, n, tbl);
+        C25519_TRY(hipGetLastError());
+        tl_last_verify.wg_slow = fs.wg_slow; tl_last_verify.groups = grid; tl_last_verify.stream = stream;
+        (void)hipGetDevice(&tl_last_verify.device);
+        return tls().release_work(stream);
+    }
+    tl_last_verify = LastVerify();
+    k_ed25519_verify_init<QTableLimbs><<<grid, ED_BLOCK, 0, stream>>>(pk, n, tables, VERIFY_TABLE_WORDS);
     C25519_TRY(hipGetLastError());
-    k_ed25519_verify_check<QTableLimbs><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
-        scr, sig, pk, msgs, n, tbl, tables, QTABLE_LIMB_WORDS);
+    k_ed25519_verify_check<QTableLimbs><<<grid, ED_BLOCK, 0, stream>>>(scr, sig, pk, msgs, n, tbl, tables, VERIFY_TABLE_WORDS);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, make_fin(scr), stream));
     return tls().release_work(stream);
@@ -967,9 +1099,11 @@ size_t ed25519_VerifySignature_scratch_bytes(size_t n) { return verify_scratch_b
 
 static int verify_dev(void* verdict, const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t stream)
 {
+    // C25519_AMD_VERIFY_REFERENCE_ORDER=1: every element through the reference-order kernels (A/B and test knob)
+    static const bool fast = getenv("C25519_AMD_VERIFY_REFERENCE_ORDER") == nullptr;
     if (int rc = check_dev_args(n, { verdict, sig, pk })) return rc;
     if (n == 0) return 0;
-    return verify_run(sig, pk, msgs, n, stream,
+    return verify_run(sig, pk, msgs, n, stream, (int*)verdict, fast,
                       [&](const ProjScratch& scr) { return FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }; });
 }
 
@@ -980,8 +1114,23 @@ int c25519_amd_verify_point_dev(void* out, const void* sig, const void* pk, cons
     if (!out || !sig || !pk || (!msg && msg_size)) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { out, sig, pk })) return rc;
     if (n == 0) return 0;
-    return verify_run(sig, pk, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, (hipStream_t)stream,
+    return verify_run(sig, pk, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, (hipStream_t)stream, nullptr, false,
                       [&](const ProjScratch& scr) { return FinishPack{ scr.a, scr.b, out, n, 1, 0, nullptr, 0, 0 }; });
+}
+
+// how many 256-element workgroups of the calling thread's last ed25519_VerifySignature_* call on this device went through
+// the reference-order kernels instead of the lattice path (-1: no fast-path verification to report).  Synchronises.
+long c25519_amd_verify_last_slow_groups(void)
+{
+    const LastVerify& lv = tl_last_verify;
+    int dev = -1;
+    if (!lv.wg_slow || hipGetDevice(&dev) != hipSuccess || dev != lv.device) return -1;
+    if (hipStreamSynchronize(lv.stream) != hipSuccess) return -1;
+    std::vector<u32> flags(lv.groups);
+    if (hipMemcpy(flags.data(), lv.wg_slow, sizeof(u32) * lv.groups, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    long c = 0;
+    for (u32 f : flags) c += f != 0;
+    return c;
 }
 
 int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, const void* msg, size_t msg_size,

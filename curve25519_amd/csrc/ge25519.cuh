@@ -129,7 +129,9 @@ C25519_DEV void ge_from_pe(ge_ext& s, const ge_pe& q)
 
 // x from y with the requested parity: sqrt((y^2-1)/(d y^2+1)); like the reference there is NO
 // on-curve rejection -- a non-square input just yields whatever the formula yields.   (ed25519_CalculateX)
-C25519_DEV void ge_calc_x(fe& X, const fe& Y, u32 parity)
+// Returns all-ones iff the result satisfies the curve equation (v x^2 == u): the reference never looks at this; the
+// fast verification path (verify_fast.cuh) does, and only to choose between itself and the reference-order path.
+C25519_DEV u32 ge_calc_x_checked(fe& X, const fe& Y, u32 parity)
 {
     fe u, v, a, b, t;
     fe one;
@@ -148,13 +150,15 @@ C25519_DEV void ge_calc_x(fe& X, const fe& Y, u32 parity)
     fe_mul(X, b, a);
 
     fe_sqr(b, X);                                    // is v x^2 == u ?
-    fe_mul(b, b, v);
+    fe_mul(b, b, v);                                 // c = v x^2, reduced
+    fe_add(a, b, u);                                 // c + u: zero iff x*sqrt(-1) is the root
     fe_sub(b, b, u);
-    u32 bw[8];
+    u32 bw[8], aw[8];
     fe_to_words(bw, b);
-    u32 nz = 0;
+    fe_to_words(aw, a);
+    u32 nz = 0, nz2 = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) nz |= bw[i];
+    for (int i = 0; i < 8; i++) { nz |= bw[i]; nz2 |= aw[i]; }
     fe_mul(t, X, fe_const(K_SQRTM1));
     fe_select(X, nz ? 0xffffffffu : 0u, t, X);       // :92-93
 
@@ -163,7 +167,10 @@ C25519_DEV void ge_calc_x(fe& X, const fe& Y, u32 parity)
     fe_neg(t, X);
     fe_select(t, ((xw[0] ^ parity) & 1u) ? 0xffffffffu : 0u, t, X);
     fe_carry32(X, t);
+    return (nz == 0 || nz2 == 0) ? 0xffffffffu : 0u;
 }
+
+C25519_DEV void ge_calc_x(fe& X, const fe& Y, u32 parity) { (void)ge_calc_x_checked(X, Y, parity); }
 
 // ---- 8-fold base table, staged in LDS ------------------------------------------------------------
 // LDS layout is limb-major: word w of row k sits at tbl[w * 256 + k], so the 64 secret row indices of

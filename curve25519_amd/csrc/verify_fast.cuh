@@ -1,0 +1,494 @@
+// curve25519_amd/csrc/verify_fast.cuh -- exact Ed25519 verification with half the doublings, for keys that are on
+// the curve.
+//
+// The reference (source/ed25519_verify.c:287-313) accepts iff enc(T) == R bytes with T = s*B + h*Q, Q = -A decompressed
+// WITHOUT validation; it pays 255 doublings for the 253-bit h (192 building the 4-fold table, 63 walking it), and for
+// a key used once no comb shape changes that count.  What does: a short vector of the lattice
+// {(rho, tau): tau = rho*h mod 8L}.  E(F_p) has order 8L, so [rho*h]Q = [tau]Q for ANY curve point Q, torsion included,
+// and if rho is odd (and 0 < rho < L) then gcd(rho, 8L) = 1 and multiplication by rho is a bijection of the group:
+//         T == R   <=>   [rho](s*B + h*Q - R) == O   <=>   [rho*s mod L]B + [tau]Q + [rho](-R) == O
+// with rho, tau of ~128 bits: 140 doublings instead of 255.  When Q is on the curve the reference's own formulas are
+// the complete group law (a = -1 is a square, d is not), so its T is the group's T, and enc() is injective on curve
+// points: "R bytes decode canonically to a curve point R and the right-hand side holds" IS the reference's verdict,
+// for every s (S >= L included: B has order L) and every torsion component of A or R.  Everything else -- a key that
+// does not decompress onto the curve, a lattice vector longer than the walk's capacity -- is left to the
+// reference-order path (k_ed25519_verify_init / _check), selected per workgroup.
+// Public data only: nothing here needs to be constant-time.
+#pragma once
+#include "ge25519.cuh"
+#include "sc25519.cuh"
+#include "sha512.cuh"
+
+namespace c25519 {
+
+// ---- lattice reduction -------------------------------------------------------------------------------------------------
+// Euclid on (8L, h) carrying the cofactor of h.  Every vector (r, T) kept has r >= 0 and r = T*h (mod 8L) with T a
+// signed integer; every step is a unimodular combination of the two current vectors, so they always form a basis of
+// the lattice and their T's are never both even.  Two phases, both on 32-bit words:
+//   * Lehmer steps: the leading 62 bits of both remainders go through a shift-subtract Euclid in two registers that
+//     accumulates a 2x2 matrix with entries below 2^31 (about 28 bits of progress), which is then applied exactly to
+//     the full vectors (a handful of v_mad_u64_u32 chains).  The leading-bits quotients need not be the true ones: any
+//     unimodular matrix keeps the invariants, only how fast the vectors shrink depends on them;
+//   * exact shift-subtract steps finish: until the smaller remainder is below 2^128, and then the other vector only
+//     until its remainder is below 2^129, which keeps its cofactor as short as the lattice allows.
+// Whatever comes out is checked (odd, short enough) before it is used.
+constexpr int LAT_CAP_BITS = 142;          // what the 36-digit signed walk can take (a random h exceeds it with p ~ 2^-22)
+constexpr int LAT_R = 8, LAT_T = 6;        // words of a remainder (unsigned) / of a cofactor (two's complement)
+
+template <int W>
+C25519_DEV int bitlen_words(const u32 (&a)[W])
+{
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) n = a[i] ? 32 * i + (32 - __builtin_clz(a[i])) : n;
+    return n;
+}
+C25519_DEV int bitlen64(u64 x) { return x ? 64 - __builtin_clzll(x) : 0; }
+template <int W>
+C25519_DEV bool geq_words(const u32 (&a)[W], const u32 (&b)[W])            // a >= b, unsigned
+{
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const u64 d = (u64)a[i] - b[i] - borrow;
+        borrow = (u32)(d >> 63);
+    }
+    return borrow == 0;
+}
+// r = a << k for 0 <= k < 32 * W (bits shifted out are lost).  any_word_shift: wave-uniform hint that some lane has k >= 32.
+template <int W>
+C25519_DEV void shl_var(u32 (&r)[W], const u32 (&a)[W], int k, bool any_word_shift)
+{
+    const int b = k & 31;
+    u32 t[W];
+#pragma unroll
+    for (int i = W - 1; i >= 0; i--) {
+        const u64 pair = ((u64)a[i] << 32) | (i ? a[i - 1] : 0u);
+        t[i] = (u32)(pair >> (32 - b));
+    }
+    if (any_word_shift) {
+        const int ws = k >> 5;
+#pragma unroll
+        for (int stage = 4; stage >= 1; stage >>= 1) {
+            if (stage >= W) continue;
+            const bool on = (ws & stage) != 0;
+#pragma unroll
+            for (int i = W - 1; i >= 0; i--) t[i] = on ? (i >= stage ? t[i - stage] : 0u) : t[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < W; i++) r[i] = t[i];
+}
+// the 62 bits of a below bit position `top` (top >= 62), or a itself when top < 62
+template <int W>
+C25519_DEV u64 leading62(const u32 (&a)[W], int top, bool any_word_shift)
+{
+    const int sh = top > 62 ? top - 62 : 0;
+    u32 t[W];
+    // right shift by sh: bits, then words
+    const int b = sh & 31;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const u64 pair = ((u64)(i + 1 < W ? a[i + 1] : 0u) << 32) | a[i];
+        t[i] = (u32)(pair >> b);
+    }
+    if (any_word_shift) {
+        const int ws = sh >> 5;
+#pragma unroll
+        for (int stage = 4; stage >= 1; stage >>= 1) {
+            if (stage >= W) continue;
+            const bool on = (ws & stage) != 0;
+#pragma unroll
+            for (int i = 0; i < W; i++) t[i] = on ? (i + stage < W ? t[i + stage] : 0u) : t[i];
+        }
+    }
+    return ((u64)t[1] << 32) | t[0];
+}
+// out = A*x - B*y modulo 2^(32 W)   (A, B < 2^32; two's complement when the operands are sign-extended)
+template <int W>
+C25519_DEV void lin_comb(u32 (&out)[W], const u32 (&x)[W], u32 A, const u32 (&y)[W], u32 B)
+{
+    u32 p[W], q[W];
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) { c += (u64)x[i] * A; p[i] = (u32)c; c >>= 32; }
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) { c += (u64)y[i] * B; q[i] = (u32)c; c >>= 32; }
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const u64 d = (u64)p[i] - q[i] - borrow;
+        out[i] = (u32)d;
+        borrow = (u32)(d >> 63);
+    }
+}
+template <int W>
+C25519_DEV void negate_words(u32 (&a)[W])
+{
+    u32 carry = 1;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const u64 s = (u64)(~a[i]) + carry;
+        a[i] = (u32)s;
+        carry = (u32)(s >> 32);
+    }
+}
+
+// 8L as eight 32-bit words
+C25519_DEV void lat_modulus(u32 (&n)[8])
+{
+    n[0] = K_L[0] << 3;
+#pragma unroll
+    for (int i = 1; i < 8; i++) n[i] = (K_L[i] << 3) | (K_L[i - 1] >> 29);
+}
+
+// one Lehmer step on the vectors (r0, t0), (r1, t1).  Returns false for a lane that made no progress.
+C25519_DEV bool lat_lehmer_step(u32 (&r0)[LAT_R], u32 (&t0)[LAT_T], u32 (&r1)[LAT_R], u32 (&t1)[LAT_T], bool active, bool& sane)
+{
+    const int l0 = bitlen_words<LAT_R>(r0), l1 = bitlen_words<LAT_R>(r1);
+    const int top = l0 > l1 ? l0 : l1;
+    const bool words = __any(active && top > 62 + 31);
+    u64 x0 = leading62<LAT_R>(r0, top, words), x1 = leading62<LAT_R>(r1, top, words);
+    // x0 = A*a - B*b, x1 = -C*a + D*b for the original leading parts (a, b); entries only ever grow
+    u32 A = 1, B = 0, C = 0, D = 1;
+#pragma unroll 1
+    for (int it = 0; it < 48; it++) {
+        const bool c = x0 >= x1;
+        const u64 big = c ? x0 : x1, small = c ? x1 : x0;
+        const u32 ms0 = c ? C : A, ms1 = c ? D : B, mb0 = c ? A : C, mb1 = c ? B : D;     // rows of small / big
+        int k = bitlen64(big) - bitlen64(small);
+        u64 sh = small << k;
+        if (sh > big) { k -= 1; sh >>= 1; }
+        const u64 n0 = (u64)mb0 + ((u64)ms0 << k), n1 = (u64)mb1 + ((u64)ms1 << k);
+        // keep the matrix below 2^31 and the smaller leading part above 2^33 (below that its low bits are noise)
+        const bool go = active && small >= ((u64)1 << 33) && k < 31 && n0 < ((u64)1 << 31) && n1 < ((u64)1 << 31);
+        if (!__any(go)) break;
+        if (go) {
+            const u64 nb = big - sh;
+            x0 = c ? nb : x0; x1 = c ? x1 : nb;
+            A = c ? (u32)n0 : A; B = c ? (u32)n1 : B;
+            C = c ? C : (u32)n0; D = c ? D : (u32)n1;
+        }
+    }
+    const bool progressed = active && !(A == 1 && B == 0 && C == 0 && D == 1);
+    // apply exactly: (r0, r1) <- (A r0 - B r1, -C r0 + D r1), same for the cofactors (two's complement, sign-extended)
+    u32 x[LAT_R + 1], y[LAT_R + 1], n0[LAT_R + 1], n1[LAT_R + 1];
+#pragma unroll
+    for (int i = 0; i < LAT_R; i++) { x[i] = r0[i]; y[i] = r1[i]; }
+    x[LAT_R] = y[LAT_R] = 0;
+    lin_comb<LAT_R + 1>(n0, x, A, y, B);
+    lin_comb<LAT_R + 1>(n1, y, D, x, C);
+    u32 tx[LAT_T + 1], ty[LAT_T + 1], m0[LAT_T + 1], m1[LAT_T + 1];
+#pragma unroll
+    for (int i = 0; i < LAT_T; i++) { tx[i] = t0[i]; ty[i] = t1[i]; }
+    tx[LAT_T] = 0u - (t0[LAT_T - 1] >> 31);
+    ty[LAT_T] = 0u - (t1[LAT_T - 1] >> 31);
+    lin_comb<LAT_T + 1>(m0, tx, A, ty, B);
+    lin_comb<LAT_T + 1>(m1, ty, D, tx, C);
+    // a remainder that came out negative (the leading-bits quotient overshot): flip the whole vector
+    if (n0[LAT_R] >> 31) { negate_words<LAT_R + 1>(n0); negate_words<LAT_T + 1>(m0); }
+    if (n1[LAT_R] >> 31) { negate_words<LAT_R + 1>(n1); negate_words<LAT_T + 1>(m1); }
+    if (progressed) {
+        sane = sane && n0[LAT_R] == 0 && n1[LAT_R] == 0;
+#pragma unroll
+        for (int i = 0; i < LAT_R; i++) { r0[i] = n0[i]; r1[i] = n1[i]; }
+#pragma unroll
+        for (int i = 0; i < LAT_T; i++) { t0[i] = m0[i]; t1[i] = m1[i]; }
+    }
+    return progressed;
+}
+
+// h (< 2^256, normally canonical mod L) -> rho (odd, > 0), |tau|, sign of tau, as 5-word little-endian magnitudes.
+// Returns all-ones if both fit the walk (bit length <= LAT_CAP_BITS), zero otherwise (the caller falls back).
+C25519_DEV u32 sc_lattice_short(u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative, const u32 (&h)[8])
+{
+    u32 r0[LAT_R], r1[LAT_R], t0[LAT_T] = { 0, 0, 0, 0, 0, 0 }, t1[LAT_T] = { 1, 0, 0, 0, 0, 0 };
+    lat_modulus(r0);
+#pragma unroll
+    for (int i = 0; i < LAT_R; i++) r1[i] = h[i];
+    bool sane = true;
+    // phase 1: Lehmer steps while both remainders are still well above the target
+    {
+        bool active = true;
+#pragma unroll 1
+        for (int guard = 0; guard < 16; guard++) {
+            const int l0 = bitlen_words<LAT_R>(r0), l1 = bitlen_words<LAT_R>(r1);
+            active = active && sane && (l0 < l1 ? l0 : l1) > 160;
+            if (!__any(active)) break;
+            active = lat_lehmer_step(r0, t0, r1, t1, active, sane) && active;
+        }
+    }
+    // phase 2: exact steps.  A step subtracts the (shifted) smaller vector from the larger one; it is wanted while the
+    // smaller remainder still has more than 128 bits, or it does not but the larger one has more than 129.
+    bool stopped = false;
+#pragma unroll 1
+    for (int guard = 0; guard < 400; guard++) {
+        const bool c = geq_words<LAT_R>(r0, r1);                       // r0 is the larger one
+        const int l0 = bitlen_words<LAT_R>(r0), l1 = bitlen_words<LAT_R>(r1);
+        const int lbig = c ? l0 : l1, lsmall = c ? l1 : l0;
+        // |T_small| << k has to stay inside the signed 192 bits; if it would not (h with a freak quotient, e.g. h = 1)
+        // this lane simply stops: the smaller vector may still be the answer, the larger one is then of no use
+        const int k0 = lbig - lsmall;
+        u32 mag[LAT_T];
+#pragma unroll
+        for (int i = 0; i < LAT_T; i++) mag[i] = (c ? t1[i] : t0[i]) ^ (0u - ((c ? t1[LAT_T - 1] : t0[LAT_T - 1]) >> 31));
+        const bool room = bitlen_words<LAT_T>(mag) + k0 <= 32 * LAT_T - 3;
+        const bool want = sane && !stopped && room && lsmall != 0 && (lsmall > 128 || lbig > 129);
+        stopped = stopped || (sane && !room);
+        if (!__any(want)) break;
+        u32 big[LAT_R], small[LAT_R], tb[LAT_T], ts[LAT_T], sh[LAT_R], tsh[LAT_T];
+#pragma unroll
+        for (int i = 0; i < LAT_R; i++) { big[i] = c ? r0[i] : r1[i]; small[i] = c ? r1[i] : r0[i]; }
+#pragma unroll
+        for (int i = 0; i < LAT_T; i++) { tb[i] = c ? t0[i] : t1[i]; ts[i] = c ? t1[i] : t0[i]; }
+        int k = want ? k0 : 0;
+        const bool words = __any(k >= 32);
+        shl_var<LAT_R>(sh, small, k, words);
+        if (!geq_words<LAT_R>(big, sh)) {                              // one bit too far (k >= 1 here)
+            k -= 1;
+#pragma unroll
+            for (int i = 0; i < LAT_R; i++) sh[i] = (sh[i] >> 1) | (i + 1 < LAT_R ? sh[i + 1] << 31 : 0u);
+        }
+        shl_var<LAT_T>(tsh, ts, k, words);
+        u32 borrow = 0, borrow_t = 0;
+#pragma unroll
+        for (int i = 0; i < LAT_R; i++) {
+            const u64 d = (u64)big[i] - sh[i] - borrow;
+            big[i] = (u32)d;
+            borrow = (u32)(d >> 63);
+        }
+#pragma unroll
+        for (int i = 0; i < LAT_T; i++) {                              // two's complement: T_big -= T_small << k
+            const u64 d = (u64)tb[i] - tsh[i] - borrow_t;
+            tb[i] = (u32)d;
+            borrow_t = (u32)(d >> 63);
+        }
+        if (want) {
+#pragma unroll
+            for (int i = 0; i < LAT_R; i++) { r0[i] = c ? big[i] : r0[i]; r1[i] = c ? r1[i] : big[i]; }
+#pragma unroll
+            for (int i = 0; i < LAT_T; i++) { t0[i] = c ? tb[i] : t0[i]; t1[i] = c ? t1[i] : tb[i]; }
+        }
+    }
+    // the smaller vector if its cofactor is odd, else the other (a basis never has two even cofactors)
+    const bool small_is_1 = geq_words<LAT_R>(r0, r1);
+    const bool small_odd = ((small_is_1 ? t1[0] : t0[0]) & 1u) != 0;
+    const bool use1 = small_is_1 == small_odd;                         // vector 1 is picked
+    u32 r[LAT_R], t[LAT_T];
+#pragma unroll
+    for (int i = 0; i < LAT_R; i++) r[i] = use1 ? r1[i] : r0[i];
+#pragma unroll
+    for (int i = 0; i < LAT_T; i++) t[i] = use1 ? t1[i] : t0[i];
+    const bool t_negative = (t[LAT_T - 1] >> 31) != 0;                 // r = T*h: with rho = |T|, tau = sign(T) * r
+    if (t_negative) negate_words<LAT_T>(t);
+    tau_negative = t_negative ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { rho[i] = t[i]; tau[i] = r[i]; }
+    const bool fits = sane && bitlen_words<LAT_R>(r) <= LAT_CAP_BITS && bitlen_words<LAT_T>(t) <= LAT_CAP_BITS && (t[0] & 1u);
+    return fits ? 0xffffffffu : 0u;
+}
+
+// sigma = rho * s mod L (canonical); s is the signature's raw 256-bit S
+C25519_DEV void sc_mul_short(u32 (&sigma)[8], const u32 (&rho)[5], const u32 (&s)[8])
+{
+    u32 r8[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) r8[i] = i < 5 ? rho[i] : 0u;
+    sc_mul(sigma, s, r8);
+    sc_mod(sigma);
+}
+
+// ---- signed radix-16 digits ----------------------------------------------------------------------------------------------
+constexpr int WALK_DIGITS = 36;             // 36 digits in [-8, 7] cover magnitudes below 2^142
+// k + 0x888...8 (36 nibbles): nibble i of the sum, minus 8, is the signed digit d_i in [-8, 7] with k = sum d_i 16^i,
+// so digits can be read most-significant first without a carry chain.  k < 2^142.
+C25519_DEV void bias_signed16(u32 (&kb)[5], const u32 (&k)[5])
+{
+    const u32 bias[5] = { 0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u, 0x00008888u };
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        c += (u64)k[i] + bias[i];
+        kb[i] = (u32)c;
+        c >>= 32;
+    }
+}
+// digit i of a biased scalar: |d_i| in 0..8 and all-ones if d_i < 0
+C25519_DEV u32 signed16_at(u32& negative, const u32 (&kb)[5], int i)
+{
+    u32 w = kb[0];
+#pragma unroll
+    for (int t = 1; t < 5; t++) w = ((i >> 3) == t) ? kb[t] : w;
+    const u32 nib = (w >> (4 * (i & 7))) & 15u;
+    negative = nib < 8u ? 0xffffffffu : 0u;
+    return nib < 8u ? 8u - nib : nib - 8u;
+}
+
+// ---- per-lane window tables: rows 0..8 = 0, P, 2P, ..., 8P in PE form ---------------------------------------------------------
+constexpr int WTABLE_ROWS = 9;
+constexpr size_t WTABLE_WORDS = WTABLE_ROWS * PE_WORDS;   // 360 words = 1440 bytes per table
+
+template <typename Tbl>
+C25519_DEV void wtable_build(const Tbl& tbl, const ge_ext& P)
+{
+    ge_pe pe, p1;
+    fe_set_u32(pe.ypx, 1); fe_set_u32(pe.ymx, 1); fe_set_u32(pe.t2d, 0); fe_set_u32(pe.z2, 2);
+    tbl.store(0, pe);
+    ge_to_pe(p1, P);
+    tbl.store(1, p1);
+    // order chosen to keep at most two extended points alive beside p1: 2P, (3P, 6P, 7P), then (4P, 5P, 8P)
+    ge_ext P2 = P, U, t;
+    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(2, pe);
+    ge_add_pe<true>(U, P2, p1);     ge_to_pe(pe, U);  tbl.store(3, pe);
+    ge_double<true>(U);             ge_to_pe(pe, U);  tbl.store(6, pe);
+    ge_add_pe<true>(t, U, p1);      ge_to_pe(pe, t);  tbl.store(7, pe);
+    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(4, pe);
+    ge_add_pe<true>(t, P2, p1);     ge_to_pe(pe, t);  tbl.store(5, pe);
+    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(8, pe);
+}
+
+// q <- -q when neg is all-ones: swap Y+X and Y-X, negate 2dT
+C25519_DEV void pe_cond_neg(ge_pe& q, u32 neg)
+{
+    fe t, n;
+    fe_select(t, neg, q.ymx, q.ypx);
+    fe_select(q.ymx, neg, q.ypx, q.ymx);
+    q.ypx = t;
+    fe_neg(n, q.t2d);                          // 2p - t2d: beta 2, accepted by ge_add_pe's products
+    fe_select(q.t2d, neg, n, q.t2d);
+}
+
+// ---- decoding the two points ---------------------------------------------------------------------------------------------
+// y from 32 bytes with bit 255 stripped; x with the requested parity.  Returns all-ones iff (x, y) is on the curve.
+// want_canonical additionally requires y < p and a sign bit that an encoder would have produced (x = 0 has sign 0).
+C25519_DEV u32 ge_decode_checked(ge_ext& P, const u32 (&w)[8], u32 parity_flip, bool want_canonical)
+{
+    u32 yw[8], cw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) yw[i] = w[i];
+    const u32 sign = yw[7] >> 31;
+    yw[7] &= 0x7fffffffu;
+    fe_from_words(P.Y, yw);
+    u32 ok = ge_calc_x_checked(P.X, P.Y, sign ^ parity_flip);
+    if (want_canonical) {
+        fe_to_words(cw, P.Y);
+        u32 diff = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) diff |= cw[i] ^ yw[i];
+        fe_to_words(cw, P.X);
+        ok &= (diff == 0 && ((cw[0] ^ sign ^ parity_flip) & 1u) == 0) ? 0xffffffffu : 0u;
+    }
+    fe_mul(P.T, P.X, P.Y);
+    fe_set_u32(P.Z, 1);
+    return ok;
+}
+
+// ---- the walk ----------------------------------------------------------------------------------------------------------
+// W = sigma*B + tau*Q + rho*Rn from the two window tables (Q and Rn = -R already carry the signs of tau and of the
+// equation), the biased scalars and the LDS base table; returns all-ones iff W is the neutral element.
+template <typename Tbl>
+C25519_DEV u32 ge_walk_is_neutral(u32 (&sigma)[8], const u32 (&tau_b)[5], const u32 (&rho_b)[5], const Tbl& tq, const Tbl& tr,
+                                  const u32* lds_tbl)
+{
+    ge_ext S;
+    ge_pe pe;
+    ge_pa pa;
+    auto lookup = [&](const Tbl& t, const u32 (&kb)[5], int i) {
+        u32 neg;
+        const u32 m = signed16_at(neg, kb, i);
+        t.load(pe, m);
+        pe_cond_neg(pe, neg);
+    };
+    lookup(tq, tau_b, WALK_DIGITS - 1);
+    ge_from_pe(S, pe);
+    lookup(tr, rho_b, WALK_DIGITS - 1);
+    ge_add_pe<false>(S, S, pe);
+    // sigma's 8-fold columns ride on the last 32 doublings (the reference's own trick, ed25519_verify.c:266-279)
+#pragma unroll 1
+    for (int i = WALK_DIGITS - 2; i >= 0; i--) {
+        if (i >= 8) {
+#pragma unroll 1
+            for (int j = 0; j < 3; j++) ge_double<false>(S);
+            ge_double<true>(S);
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                ge_double<true>(S);
+                lds_load_pa(pa, lds_tbl, fold8_next(sigma));
+                if (j == 3) ge_add_pa<true>(S, pa);     // T feeds the key-table addition that follows
+                else ge_add_pa<false>(S, pa);           // a doubling follows: T is not read
+            }
+        }
+        lookup(tq, tau_b, i);
+        ge_add_pe<true>(S, S, pe);
+        lookup(tr, rho_b, i);
+        ge_add_pe<false>(S, S, pe);
+    }
+    // neutral element: X == 0 and Y == Z (Z != 0 for on-curve inputs under the complete law)
+    u32 xw[8], dw[8], acc = 0;
+    fe d;
+    fe_sub(d, S.Y, S.Z);
+    fe_to_words(xw, S.X);
+    fe_to_words(dw, d);
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc |= xw[i] | dw[i];
+    return acc == 0 ? 0xffffffffu : 0u;
+}
+
+// ---- one lane, in three steps (three kernels in engine.hip; the CPU tests chain them) ----------------------------------------
+// step 1, integers only: h = H(R || pk || m) mod L, the short vector, sigma = rho * s mod L.  rho and tau come back
+// BIASED (bias_signed16), ready for the walk.  Returns all-ones if the vector fits the walk.
+C25519_DEV u32 ed_verify_fast_scalars(u32 (&sigma)[8], u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative, const u32 (&pkw)[8],
+                                      const u32 (&Rw)[8], const u32 (&Sw)[8], const uint8_t* msg, size_t len)
+{
+    u32 h[8];
+    {
+        u32 le[16];
+        u64 pre[8], dg[8];
+        sha512_words_from_le32(pre, Rw);
+        sha512_words_from_le32(pre + 4, pkw);
+        sha512_prefixed<8>(dg, pre, msg, len);
+        sha512_digest_le_words(le, dg);
+        sc_reduce512(h, le);
+        sc_mod(h);
+    }
+    const u32 lat_ok = sc_lattice_short(rho, tau, tau_negative, h);
+    sc_mul_short(sigma, rho, Sw);
+    u32 b[5];
+    bias_signed16(b, rho);
+#pragma unroll
+    for (int i = 0; i < 5; i++) rho[i] = b[i];
+    bias_signed16(b, tau);
+#pragma unroll
+    for (int i = 0; i < 5; i++) tau[i] = b[i];
+    return lat_ok;
+}
+
+// step 2, field work: decode -A (as ed25519_Verify_Init does, :191-197) and R, build the two window tables (of +-Q by
+// the sign of tau, and of -R).  Returns bit 0: R's bytes are the canonical encoding of a curve point (otherwise the
+// reference's byte comparison cannot succeed for an on-curve key); bit 1: the key is on the curve.
+template <typename Tbl>
+C25519_DEV u32 ed_verify_fast_points(const Tbl& tq, const Tbl& tr, const u32 (&pkw)[8], const u32 (&Rw)[8], u32 tau_negative)
+{
+    fe t;
+    u32 q_ok, r_ok;
+    {
+        ge_ext Q;
+        q_ok = ge_decode_checked(Q, pkw, 1u, false);
+        fe_neg(t, Q.X); fe_carry32(t, t); fe_select(Q.X, tau_negative, t, Q.X);   // tau < 0: walk |tau| on -Q
+        fe_neg(t, Q.T); fe_carry32(t, t); fe_select(Q.T, tau_negative, t, Q.T);
+        wtable_build(tq, Q);
+    }
+    {
+        ge_ext Rn;
+        r_ok = ge_decode_checked(Rn, Rw, 0u, true);
+        fe_neg(t, Rn.X); fe_carry32(Rn.X, t);                       // Rn = -R
+        fe_neg(t, Rn.T); fe_carry32(Rn.T, t);
+        wtable_build(tr, Rn);
+    }
+    return (r_ok & 1u) | (q_ok & 2u);
+}
+// step 3: ge_walk_is_neutral above.
+
+}  // namespace c25519

@@ -5,6 +5,7 @@
 // to establish that the kernels' indexing, LDS staging and scratch plumbing around these functions are right.
 // Not part of the product and not a fallback: libcurve25519_amd.so contains no host arithmetic.
 #include "lanes.cuh"
+#include "verify_fast.cuh"
 
 #include <mutex>
 #include <vector>
@@ -213,6 +214,40 @@ void emul_ed25519_verify(int* verdict, unsigned char* point /* may be NULL */, c
         u32 diff = 0;
         for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
         if (verdict) verdict[i] = diff == 0;
+    }
+}
+
+// the lattice fast path (verify_fast.cuh), one element at a time: verdicts (meaningful where need_slow[i] == 0) and the
+// need_slow flags
+void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char* sig, const unsigned char* pk,
+                              const unsigned char* msg, size_t len, size_t n)
+{
+    const u32* tbl = tables() + (size_t)(BASE_NT - 1) * BASE_TBL_WORDS;
+    std::vector<u32> q(2 * WTABLE_WORDS);
+    for (size_t i = 0; i < n; i++) {
+        u32 pkw[8], Rw[8], Sw[8], sigma[8], rho[5], tau[5], tau_neg;
+        rd32(pkw, pk, i);
+        rd32(Rw, sig, 2 * i);
+        rd32(Sw, sig, 2 * i + 1);
+        const QTableLimbs tq{ q.data() }, tr{ q.data() + WTABLE_WORDS };
+        const u32 lat_ok = ed_verify_fast_scalars(sigma, rho, tau, tau_neg, pkw, Rw, Sw, msg + len * i, len);
+        const u32 pts = ed_verify_fast_points(tq, tr, pkw, Rw, tau_neg);
+        const u32 neutral = ge_walk_is_neutral(sigma, tau, rho, tq, tr, tbl);
+        verdict[i] = ((pts & 1u) && neutral) ? 1 : 0;
+        need_slow[i] = (lat_ok && (pts & 2u)) ? 0 : 1;
+    }
+}
+
+// lattice reduction alone: h (n x 32) -> rho, tau (n x 20 bytes each), sign of tau, fits
+void emul_lattice(unsigned char* rho_out, unsigned char* tau_out, int* tau_neg, int* fits, const unsigned char* h, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        u32 hw[8], rho[5], tau[5], neg;
+        rd32(hw, h, i);
+        fits[i] = sc_lattice_short(rho, tau, neg, hw) ? 1 : 0;
+        tau_neg[i] = neg ? 1 : 0;
+        memcpy(rho_out + 20 * i, rho, 20);
+        memcpy(tau_out + 20 * i, tau, 20);
     }
 }
 

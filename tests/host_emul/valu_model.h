@@ -20,6 +20,8 @@ static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 struct emul_dim3 { unsigned x, y, z; };
 static const emul_dim3 threadIdx = { 0, 0, 0 }, blockIdx = { 0, 0, 0 }, blockDim = { 1, 1, 1 };
 static inline void __syncthreads() {}
+static inline int __syncthreads_or(int p) { return p; }
+static inline bool __any(bool p) { return p; }           // a "wave" of one lane
 
 namespace c25519 {
 

@@ -722,3 +722,61 @@ def test_bench_self_launches_two_ranks():
     line = json.loads(p.stdout)
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2 << 16 and line["value"] > 0
     assert line["verify"]["n_gpus"] == 2 and line["verify"]["rejects_exactly_the_corrupted"] is True
+
+
+def test_lattice_fast_path_and_reference_order_agree(api, oracle):
+    """ed25519_VerifySignature's default path decides on-curve workgroups with the exact lattice-shortened walk
+    (csrc/verify_fast.cuh) and runs the reference's operation order for the rest.  Every class of input where the two
+    could differ, against the oracle: corrupted signatures, S >= L, keys / R's with torsion components (a cofactored
+    check would accept eight times as many), small-order keys, R encodings no encoder produces, garbage.  The
+    accounting hook shows which path really ran."""
+    from curve25519_amd import _lib
+    import vectors
+    L = _lib.load()
+    n = 1 << 14
+    sk, msg = synth.random_bytes((n, 32), 0x111), synth.random_bytes((n, 40), 0x222)
+    pub, priv = api.ed25519_CreateKeyPair(sk)
+    sig = api.ed25519_SignMessage(priv, msg)
+    bsig, bmsg, bad = synth.corrupt_for_verify(sig, msg)
+    for i in range(0, 600, 3):                                           # S + L: accepted by the reference
+        S = int.from_bytes(bsig[i, 32:].tobytes(), "little")
+        if S + vectors.L < 2**256:
+            bsig[i, 32:] = vectors.le(S + vectors.L, 32)
+    ok = api.ed25519_VerifySignature(bsig, pub, bmsg)
+    assert L.c25519_amd_verify_last_slow_groups() == 0                  # all keys on the curve: the fast path took everything
+    assert np.array_equal(ok, oracle.ed25519_verify(bsig, pub, bmsg, threads=THREADS)) and np.array_equal(ok == 0, bad)
+    # torsion, small order, special R
+    tsig, tpk, tmsg = vectors.torsion_signature_cases(count=40)
+    ok = api.ed25519_VerifySignature(tsig, tpk, tmsg)
+    exp = oracle.ed25519_verify(tsig, tpk, tmsg)
+    assert np.array_equal(ok, exp) and 0 < exp.sum() < len(exp) // 4 and L.c25519_amd_verify_last_slow_groups() == 0
+    lo = vectors.small_order_keys()
+    gs, gm = synth.random_bytes((8, 64), 41), synth.random_bytes((8, 32), 42)
+    assert np.array_equal(api.ed25519_VerifySignature(gs, lo, gm), oracle.ed25519_verify(gs, lo, gm))
+    sp = vectors.special_r_encodings()
+    m = sp.shape[0]
+    ssig = np.ascontiguousarray(np.concatenate([sp, bsig[:m, 32:]], axis=1))
+    assert np.array_equal(api.ed25519_VerifySignature(ssig, pub[:m], bmsg[:m]), oracle.ed25519_verify(ssig, pub[:m], bmsg[:m]))
+    # one garbage key in a batch sends exactly its 256-element workgroup down the reference-order path
+    mixed = pub.copy()
+    gkey = synth.random_bytes((64, 32), 0x999)
+    off = next(k for k in gkey if vectors.ed_decode(int.from_bytes(k.tobytes(), "little") & (2**255 - 1), 0) is None)
+    mixed[1000], mixed[9000] = off, off
+    ok = api.ed25519_VerifySignature(bsig, mixed, bmsg)
+    assert L.c25519_amd_verify_last_slow_groups() == 2
+    assert np.array_equal(ok, oracle.ed25519_verify(bsig, mixed, bmsg, threads=THREADS))
+    # the same inputs with the fast path switched off give the same verdicts
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from curve25519_amd import api, _lib\n"
+        "d = np.load(sys.argv[1])\n"
+        "ok = api.ed25519_VerifySignature(d['sig'], d['pk'], d['msg'])\n"
+        "assert _lib.load().c25519_amd_verify_last_slow_groups() == -1\n"
+        "np.save(sys.argv[2], ok)\n") % ROOT
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), sig=bsig, pk=mixed, msg=bmsg)
+        p = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npy")],
+                           capture_output=True, text=True, timeout=600, env={**os.environ, "C25519_AMD_VERIFY_REFERENCE_ORDER": "1"})
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert np.array_equal(np.load(os.path.join(tmp, "out.npy")), ok)

@@ -1,0 +1,98 @@
+"""CPU tests of the exact lattice-accelerated verification path (curve25519_amd/csrc/verify_fast.cuh), run on the device
+source through the host emulation (tests/host_emul/): the short-vector search against its defining properties, and the
+path's verdicts against the oracle on every class of input where a shortcut could go wrong -- valid and corrupted
+signatures, S >= L, garbage keys (off-curve ones must ask for the reference-order path), R encodings an encoder never
+produces, keys and R's with torsion components (where a cofactored check would differ), small-order keys."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "host_emul"))
+from curve25519_amd import synth  # noqa: E402
+import vectors  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def emul():
+    import build as emul_build
+    lib = C.CDLL(emul_build.build())
+    lib.emul_mad_overflow_count.restype = C.c_ulonglong
+    yield lib
+    assert lib.emul_mad_overflow_count() == 0
+
+
+def run_fast(lib, sig, pk, msg):
+    n = sig.shape[0]
+    sig, pk = np.ascontiguousarray(sig), np.ascontiguousarray(pk)
+    msg = np.ascontiguousarray(msg).reshape(n, -1)
+    v, s = np.empty(n, np.int32), np.empty(n, np.int32)
+    lib.emul_ed25519_verify_fast(C.c_void_p(v.ctypes.data), C.c_void_p(s.ctypes.data), C.c_void_p(sig.ctypes.data),
+                                 C.c_void_p(pk.ctypes.data), C.c_void_p(msg.ctypes.data), C.c_size_t(msg.shape[1]), C.c_size_t(n))
+    return v, s
+
+
+def test_short_vector_properties(emul):
+    hs = vectors.lattice_inputs()
+    n = len(hs)
+    h = np.stack([vectors.le(x, 32) for x in hs])
+    rho, tau = np.empty((n, 20), np.uint8), np.empty((n, 20), np.uint8)
+    neg, fits = np.empty(n, np.int32), np.empty(n, np.int32)
+    emul.emul_lattice(C.c_void_p(rho.ctypes.data), C.c_void_p(tau.ctypes.data), C.c_void_p(neg.ctypes.data),
+                      C.c_void_p(fits.ctypes.data), C.c_void_p(h.ctypes.data), C.c_size_t(n))
+    for i, x in enumerate(hs):
+        if not fits[i]:
+            continue
+        r, t = int.from_bytes(rho[i].tobytes(), "little"), int.from_bytes(tau[i].tobytes(), "little")
+        t = -t if neg[i] else t
+        assert r % 2 == 1 and 0 < r < 2**142 and abs(t) < 2**142, (x, r, t)
+        assert (r * x - t) % vectors.N8L == 0, (x, r, t)                 # tau = rho * h modulo 8L, not just L
+    assert fits[12:6012].all(), "a random h practically always has a short vector that fits the walk"
+    # h = L-1, L-2, (L-1)/2 are close to -1, -2, -1/2 modulo L but not modulo 8L: their only short vectors have an even
+    # rho, so they (correctly) do not fit and go to the reference-order path; the other hand-picked values do
+    assert [int(f) for f in fits[:12]] == [1, 1, 1, 1, 0, 0, 1, 1, 1, 1, 0, 1]
+
+
+def test_fast_path_equals_the_oracle(emul, oracle):
+    n = 1500
+    sk, msg = synth.random_bytes((n, 32), 0x111), synth.random_bytes((n, 40), 0x222)
+    pub, priv = oracle.ed25519_keypair(sk, threads=8)
+    sig = oracle.ed25519_sign(priv, msg, threads=8)
+    bsig, bmsg, _ = synth.corrupt_for_verify(sig, msg)
+    bsig[5::7, 3] ^= 1
+    bsig[6::7, 40] ^= 2
+    for i in range(0, 60, 3):                                            # S + L: accepted by the reference
+        S = int.from_bytes(bsig[i, 32:].tobytes(), "little")
+        if S + vectors.L < 2**256:
+            bsig[i, 32:] = vectors.le(S + vectors.L, 32)
+    v, s = run_fast(emul, bsig, pub, bmsg)
+    exp = oracle.ed25519_verify(bsig, pub, bmsg, threads=8)
+    assert not s.any() and np.array_equal(v, exp) and 0 < exp.sum() < n
+    # garbage: on-curve "keys" are decided by the fast path (and must agree), off-curve ones must ask for the slow path
+    gs, gp, gm = synth.random_bytes((n, 64), 31), synth.random_bytes((n, 32), 32), synth.random_bytes((n, 40), 33)
+    v, s = run_fast(emul, gs, gp, gm)
+    exp = oracle.ed25519_verify(gs, gp, gm, threads=8)
+    assert 0.3 * n < s.sum() < 0.7 * n and np.array_equal(v[s == 0], exp[s == 0])
+    on_curve = np.array([vectors.ed_decode(int.from_bytes(k.tobytes(), "little") & (2**255 - 1), 0) is not None for k in gp])
+    assert np.array_equal(s == 0, on_curve)
+    # special R encodings against a valid key
+    sp = vectors.special_r_encodings()
+    m = sp.shape[0]
+    ssig = np.concatenate([sp, bsig[:m, 32:]], axis=1)
+    v, s = run_fast(emul, ssig, pub[:m], bmsg[:m])
+    assert not s.any() and np.array_equal(v, oracle.ed25519_verify(ssig, pub[:m], bmsg[:m]))
+
+
+def test_fast_path_on_torsion(emul, oracle):
+    sig, pk, msg = vectors.torsion_signature_cases()
+    v, s = run_fast(emul, sig, pk, msg)
+    exp = oracle.ed25519_verify(sig, pk, msg)
+    assert not s.any() and np.array_equal(v, exp)
+    assert 0 < exp.sum() < len(exp) // 4            # roughly one of the eight torsion offsets fits per key
+    lo = vectors.small_order_keys()
+    gs, gm = synth.random_bytes((8, 64), 41), synth.random_bytes((8, 32), 42)
+    v, s = run_fast(emul, gs, lo, gm)
+    assert not s.any() and np.array_equal(v, oracle.ed25519_verify(gs, lo, gm))

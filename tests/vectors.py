@@ -109,3 +109,102 @@ def check_field(op, out, pairs):
         if op in FIELD_OPS_B_REDUCED:
             y %= P
         assert got == f(x, y) % P, (op, hex(x), hex(y), hex(got))
+
+
+# ---- Ed25519 verification corner cases (for the lattice fast path, curve25519_amd/csrc/verify_fast.cuh) -----------------
+# A tiny affine Edwards implementation, only to BUILD inputs: keys and R's with torsion components, small-order keys.
+# Expected verdicts always come from the oracle / the reference, never from here.
+D_ED = (-121665 * pow(121666, P - 2, P)) % P
+N8L = 8 * L
+
+
+def ed_add(p, q):
+    x1, y1 = p
+    x2, y2 = q
+    k = D_ED * x1 * x2 * y1 * y2 % P
+    return ((x1 * y2 + x2 * y1) * pow(1 + k, P - 2, P) % P, (y1 * y2 + x1 * x2) * pow(1 - k, P - 2, P) % P)
+
+
+def ed_mul(k, p):
+    r = (0, 1)
+    while k:
+        if k & 1:
+            r = ed_add(r, p)
+        p = ed_add(p, p)
+        k >>= 1
+    return r
+
+
+def ed_enc(p):
+    return (p[1] | ((p[0] & 1) << 255)).to_bytes(32, "little")
+
+
+def ed_decode(y, sign):
+    u, v = (y * y - 1) % P, (D_ED * y * y + 1) % P
+    x = pow(u * pow(v, P - 2, P) % P, (P + 3) // 8, P)
+    if (x * x * v - u) % P:
+        x = x * pow(2, (P - 1) // 4, P) % P
+    if (x * x * v - u) % P:
+        return None
+    return (P - x if (x & 1) != sign else x, y)
+
+
+ED_B = ed_decode(4 * pow(5, P - 2, P) % P, 0)
+
+
+def ed_order8_point():
+    y = 2
+    while True:
+        pt = ed_decode(y, 0)
+        y += 1
+        if pt is None:
+            continue
+        t = ed_mul(L, pt)
+        if ed_mul(4, t) != (0, 1):
+            return t
+
+
+def torsion_signature_cases(count=15, seed=9):
+    """(sig[n,64], pk[n,32], msg[n,32]): keys A = a*B + t*T8 with a torsion component and, for each, the eight
+    signatures (r*B + j*T8, r + h*a): exactly those with j + h*t = 0 mod 8 satisfy the cofactorless equation the
+    reference checks; a cofactored check would accept all eight."""
+    import hashlib
+    import random
+    rnd = random.Random(seed)
+    T8 = ed_order8_point()
+    sigs, pks, msgs = [], [], []
+    for _ in range(count):
+        a, t = rnd.getrandbits(252) % L, rnd.choice([1, 2, 3, 4, 5, 6, 7])
+        pk = ed_enc(ed_add(ed_mul(a, ED_B), ed_mul(t, T8)))
+        m = rnd.getrandbits(256).to_bytes(32, "little")
+        r = rnd.getrandbits(252) % L
+        for j in range(8):
+            Rb = ed_enc(ed_add(ed_mul(r, ED_B), ed_mul(j, T8)))
+            h = int.from_bytes(hashlib.sha512(Rb + pk + m).digest(), "little") % L
+            sigs.append(Rb + ((r + h * a) % L).to_bytes(32, "little"))
+            pks.append(pk)
+            msgs.append(m)
+    f = lambda rows: np.stack([np.frombuffer(x, np.uint8) for x in rows])  # noqa: E731
+    return f(sigs), f(pks), f(msgs)
+
+
+def small_order_keys():
+    T8 = ed_order8_point()
+    return np.stack([np.frombuffer(ed_enc(ed_mul(k, T8)), np.uint8) for k in range(8)])
+
+
+def special_r_encodings():
+    """R byte strings an encoder never produces or that are special points: x = 0 with the sign bit, y >= p, the
+    neutral element, (0, -1), all-ones."""
+    vals = [1 | (1 << 255), P + 1, 1, P - 1, 2**255 - 1, 2**256 - 1, P, 0, (P - 1) | (1 << 255)]
+    return np.stack([le(v, 32) for v in vals])
+
+
+def lattice_inputs():
+    import random
+    rnd = random.Random(7)
+    hs = [0, 1, 2, 3, L - 1, L - 2, 2**128, 2**128 - 1, 2**127, 2**252, (L - 1) // 2, 2**129 + 1]
+    hs += [rnd.getrandbits(253) % L for _ in range(6000)]
+    hs += [rnd.getrandbits(k) for k in range(1, 253)]
+    hs += [(N8L * a // b) % L for a in range(1, 20) for b in range(a + 1, 21)]
+    return hs
