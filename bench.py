@@ -37,19 +37,23 @@ sys.path.insert(0, ROOT)
 BATCH = 1 << 20
 BYTES_PER_OP = {"x25519": 96, "sign": 160, "verify": 132}          # SURVEY.md 8(d), compulsory HBM bytes
 MACS_PER_OP = {"x25519": 184104, "sign": 52992, "verify": 245664}  # SURVEY.md 8(a), 32x32 MACs at 72/mul
+# what the device actually issues per operation (v_mad_u64_u32 count from the kernels' ISA): the
+# ladder does the reference's work in 100/55-MAD products; sign walks 7 doublings instead of 31; verification of
+# on-curve keys walks 140 doublings instead of 255
+EXECUTED_MACS_PER_OP = {"x25519": 191400, "sign": 27200, "verify": 196000}
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md
 
 PASS_KERNELS = {
     "x25519": ("k_x25519_fused",),
     "sign": ("k_ed25519_sign_mult", "k_batch_invert<FinishPack>", "k_ed25519_sign_finish"),
-    "verify": ("k_ed25519_verify_init<c25519::QTableLimbs>", "k_ed25519_verify_check<c25519::QTableLimbs>",
-               "k_batch_invert<FinishVerify>"),
+    "verify": ("k_ed25519_verify_fast_scalars", "k_ed25519_verify_fast_points", "k_ed25519_verify_fast_walk"),
 }
 METRIC_NAME = {
     "x25519": "X25519 shared-key ops/sec (batch=2^20 per GPU, variable-base Montgomery ladder) [+ Ed25519 verifies/sec "
               "in `verify`]",
     "sign": "Ed25519 signs/sec (batch=2^20 per GPU, 8-fold fixed-base walk, 32-byte messages)",
-    "verify": "Ed25519 verifies/sec (batch=2^20 per GPU, distinct keys, 4-fold + 8-fold double-scalar walk)",
+    "verify": "Ed25519 verifies/sec (batch=2^20 per GPU, distinct keys; exact lattice-shortened double-scalar walk for "
+              "on-curve keys, the reference's 4-fold + 8-fold order otherwise)",
     "mixed": "mixed X25519 + Ed25519 sign + verify ops/sec (contiguous thirds of 2^20 per GPU)",
 }
 WORKLOAD_NAME = {
@@ -116,6 +120,8 @@ def roofline_for(wl, n, kernel_ms):
                  "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s",
                  "frac": round(achieved_mac / peak_mac, 4) if peak_mac else None,
                  "algorithmic_macs_per_op": MACS_PER_OP[wl],
+                 "executed_macs_per_op": EXECUTED_MACS_PER_OP[wl],
+                 "frac_executed": round(EXECUTED_MACS_PER_OP[wl] * n / kernel_s / peak_mac, 4) if peak_mac else None,
                  "peak_source": f"profiles/{peak_src}" if peak_src else None},
     }
 

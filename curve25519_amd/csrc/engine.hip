@@ -370,6 +370,12 @@ struct FastScratch {
 };
 constexpr size_t FAST_TABLE_WORDS = 2 * WTABLE_WORDS;
 constexpr int FS_BLOCK = 256;
+#ifndef C25519_VW_WAVES
+#define C25519_VW_WAVES 2            // waves per SIMD the register allocator aims at: the walk ...
+#endif
+#ifndef C25519_VP_WAVES
+#define C25519_VP_WAVES 2            // ... and the point decoding / table kernel
+#endif
 
 // step 1: hash, short lattice vector, sigma -- integer work only (few registers, eight waves per SIMD)
 __global__ void __launch_bounds__(FS_BLOCK) k_ed25519_verify_fast_scalars(FastScratch fs, const void* sig, const void* pk,
@@ -389,7 +395,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_ed25519_verify_fast_scalars(FastSc
 }
 
 // step 2: decode both points, build the two window tables; decides which workgroups the fast path keeps
-__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_fast_points(FastScratch fs, const void* sig, const void* pk,
+__global__ void __launch_bounds__(ED_BLOCK, C25519_VP_WAVES) k_ed25519_verify_fast_points(FastScratch fs, const void* sig, const void* pk,
                                                                              size_t n)
 {
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
@@ -437,7 +443,7 @@ C25519_DEV int verify_reference_order_lane(const u32 (&pkw)[8], const void* sig,
 // step 3: the 140-doubling walk and the neutral-element test -- or, for a workgroup with an off-curve key or an
 // over-long vector among its 256 elements (rare), the reference's own operation order for all of them, in the same
 // launch (separate launches for these few workgroups cost 0.4 ms each even when they have nothing to do).
-__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_fast_walk(FastScratch fs, int* verdict, const void* sig,
+__global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fast_walk(FastScratch fs, int* verdict, const void* sig,
                                                                            const void* pk, Msgs msgs, size_t n,
                                                                            const u32* __restrict__ g_tbl)
 {
