@@ -1131,6 +1131,11 @@ long c25519_amd_verify_last_slow_groups(void)
     const LastVerify& lv = tl_last_verify;
     int dev = -1;
     if (!lv.wg_slow || hipGetDevice(&dev) != hipSuccess || dev != lv.device) return -1;
+    {   // the flags live in the thread's work slab: stale if that slab has been released or regrown since
+        const ThreadState::WorkSlab& w = tls().work[dev];
+        const char* lo = (const char*)w.ptr;
+        if (!lo || (const char*)lv.wg_slow < lo || (const char*)(lv.wg_slow + lv.groups) > lo + w.cap) return -1;
+    }
     if (hipStreamSynchronize(lv.stream) != hipSuccess) return -1;
     std::vector<u32> flags(lv.groups);
     if (hipMemcpy(flags.data(), lv.wg_slow, sizeof(u32) * lv.groups, hipMemcpyDeviceToHost) != hipSuccess) return -1;
