@@ -285,6 +285,20 @@ def main():
     chain250(den, R)
     to_words(mul(num, R, "fast u"), "fast to_words")
     print("edwards double / add / decompress / table build / encodings: ok")
+
+    # ---- verify_fast.cuh / blinding (lanes.cuh): rows negated on the fly, the on-curve check, the neutral-element test ----
+    t2d_neg = select(neg(R, "pe_cond_neg t2d"), R)           # beta 2 where the row was negated
+    for v in ge_add(R, R, R, R, R, R, t2d_neg, R):           # ge_add_pe with a conditionally negated row
+        need(all(v[i] <= R[i] for i in range(10)), "add with a negated row: output not reduced")
+    mul(t2d_neg, CANON, "from_pe T of a negated row")        # ge_from_pe: t2d is the FIRST operand (beta <= 5)
+    to_words(add(mul(sqr(R, "check x^2"), add(R, ONE), "check v x^2"), R), "calc check c + u")      # ge_calc_x_checked
+    to_words(sub(R, R, "neutral Y - Z"), "neutral test to_words")
+    carry32(neg(R, "negate X / T of R and Q"))
+    # ge_from_pa with the blinding context's random Z: all four coordinates times zr (reduced from words), Z = carry32(2 zr)
+    for v in (mul(carry32(sub(R, R, "blind x")), FROM_WORDS, "blind X*zr"), mul(R, FROM_WORDS, "blind T*zr"),
+              carry32(add(FROM_WORDS, FROM_WORDS))):
+        need(all(v[i] <= R[i] for i in range(10)), "blinded start not reduced")
+    print("lattice verification walk and blinded base walk: ok")
     print("all bounds hold")
 
 
