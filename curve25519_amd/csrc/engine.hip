@@ -441,8 +441,10 @@ C25519_DEV int verify_reference_order_lane(const u32 (&pkw)[8], const void* sig,
 }
 
 // step 3: the 140-doubling walk and the neutral-element test -- or, for a workgroup with an off-curve key or an
-// over-long vector among its 256 elements (rare), the reference's own operation order for all of them, in the same
-// launch (separate launches for these few workgroups cost 0.4 ms each even when they have nothing to do).
+// over-long vector among its 256 elements (about six workgroups per 2^20 valid signatures), the reference's own
+// operation order for all of them, in the same launch: behind the walk, in launches of their own, those few workgroups
+// run alone at single-wave issue speed and their latency (0.4 ms per kernel) is paid in full; here it hides under the
+// other workgroups' walks.
 __global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fast_walk(FastScratch fs, int* verdict, const void* sig,
                                                                            const void* pk, Msgs msgs, size_t n,
                                                                            const u32* __restrict__ g_tbl)

@@ -32,7 +32,7 @@ namespace c25519 {
 //   * exact shift-subtract steps finish: until the smaller remainder is below 2^128, and then the other vector only
 //     until its remainder is below 2^129, which keeps its cofactor as short as the lattice allows.
 // Whatever comes out is checked (odd, short enough) before it is used.
-constexpr int LAT_CAP_BITS = 142;          // what the 36-digit signed walk can take (a random h exceeds it with p ~ 2^-22)
+constexpr int LAT_CAP_BITS = 142;          // what the 36-digit signed walk can take (a random h exceeds it with p ~ 6e-6: measured, 6 of 2^20)
 constexpr int LAT_R = 8, LAT_T = 6;        // words of a remainder (unsigned) / of a cofactor (two's complement)
 
 template <int W>
