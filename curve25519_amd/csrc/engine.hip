@@ -23,6 +23,7 @@
 #include <condition_variable>
 #include <initializer_list>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -834,11 +835,15 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
         return 0;
     };
 
-    if (nchunks == 1) {                                   // small batch: no helper threads
-        stage_in(0);
-        C25519_RC(submit(0));
-        return drain(0);
-    }
+    auto sequential = [&]() -> int {                      // no helper threads: one piece after the other
+        for (size_t c = 0; c < nchunks; c++) {
+            stage_in(c);
+            C25519_RC(submit(c));
+            C25519_RC(drain(c));
+        }
+        return 0;
+    };
+    if (nchunks == 1) return sequential();
 
     std::mutex mu;
     std::condition_variable cv;
@@ -847,7 +852,9 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     int failed = 0;                                       // first error of any role; everybody stops
     constexpr int STAGERS = 2;
     std::thread helpers[STAGERS + 1];
-    for (int sidx = 0; sidx < STAGERS; sidx++)
+    int started = 0;
+    try {
+    for (int sidx = 0; sidx < STAGERS; sidx++, started++)
         helpers[sidx] = std::thread([&, sidx] {
             for (size_t c = sidx; c < nchunks; c += STAGERS) {
                 {   // the lane's previous piece must have left its pinned buffers
@@ -876,6 +883,13 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
             cv.notify_all();
         }
     });
+    started++;
+    } catch (const std::system_error&) {                  // the process cannot have more threads: do without them
+        { std::lock_guard<std::mutex> lk(mu); failed = -1; }
+        cv.notify_all();
+        for (int i = 0; i < started; i++) helpers[i].join();
+        return sequential();
+    }
     for (size_t c = 0; c < nchunks; c++) {
         {
             std::unique_lock<std::mutex> lk(mu);

@@ -359,6 +359,43 @@ C25519_DEV void pe_cond_neg(ge_pe& q, u32 neg)
     fe_select(q.t2d, neg, n, q.t2d);
 }
 
+// S += (neg ? -row : row), the row read from memory one field at a time, each right before the product that consumes it:
+// a whole row in registers (40) on top of the accumulator (40) and the addition's temporaries is what pushes the walk
+// over the register budget of three waves per SIMD.  Negation is free here: -q swaps Y+X and Y-X (two base offsets)
+// and negates 2dT (ten subtractions), instead of thirty selects on a loaded row.
+C25519_DEV void load_fe_words(fe& f, const u32* p)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) f.v[i] = p[i];
+}
+template <bool NEED_T>
+C25519_DEV void ge_add_pe_row(ge_ext& S, const u32* row, u32 neg)
+{
+    const u32* p_ypx = row + (neg ? 10 : 0);        // field that multiplies Y+X
+    const u32* p_ymx = row + (neg ? 0 : 10);        // field that multiplies Y-X
+    fe q, a, b, c, d, e, f, g, h;
+    fe_sub(a, S.Y, S.X);
+    load_fe_words(q, p_ymx);
+    fe_mul(a, a, q);
+    fe_add(b, S.Y, S.X);
+    load_fe_words(q, p_ypx);
+    fe_mul(b, b, q);
+    load_fe_words(q, row + 20);
+    fe_neg(c, q);                                    // 2p - t2d: beta 2, fine as the second operand of a product
+    fe_select(q, neg, c, q);
+    fe_mul(c, S.T, q);
+    load_fe_words(q, row + 30);
+    fe_mul(d, S.Z, q);
+    fe_sub(e, b, a);
+    fe_add(h, b, a);
+    fe_sub(f, d, c);
+    fe_add(g, d, c);
+    fe_mul(S.X, e, f);
+    fe_mul(S.Y, g, h);
+    if (NEED_T) fe_mul(S.T, e, h);
+    fe_mul(S.Z, f, g);
+}
+
 // ---- decoding the two points ---------------------------------------------------------------------------------------------
 // y from 32 bytes with bit 255 stripped; x with the requested parity.  Returns all-ones iff (x, y) is on the curve.
 // want_canonical additionally requires y < p and a sign bit that an encoder would have produced (x = 0 has sign 0).
@@ -392,18 +429,22 @@ C25519_DEV u32 ge_walk_is_neutral(u32 (&sigma)[8], const u32 (&tau_b)[5], const 
                                   const u32* lds_tbl)
 {
     ge_ext S;
-    ge_pe pe;
     ge_pa pa;
-    auto lookup = [&](const Tbl& t, const u32 (&kb)[5], int i) {
+    {
+        ge_pe pe;
+        u32 neg;
+        const u32 m = signed16_at(neg, tau_b, WALK_DIGITS - 1);
+        tq.load(pe, m);
+        pe_cond_neg(pe, neg);
+        ge_from_pe(S, pe);
+    }
+    auto add_row = [&](const Tbl& t, const u32 (&kb)[5], int i, bool need_t) {
         u32 neg;
         const u32 m = signed16_at(neg, kb, i);
-        t.load(pe, m);
-        pe_cond_neg(pe, neg);
+        if (need_t) ge_add_pe_row<true>(S, t.base + (size_t)m * PE_WORDS, neg);
+        else ge_add_pe_row<false>(S, t.base + (size_t)m * PE_WORDS, neg);
     };
-    lookup(tq, tau_b, WALK_DIGITS - 1);
-    ge_from_pe(S, pe);
-    lookup(tr, rho_b, WALK_DIGITS - 1);
-    ge_add_pe<false>(S, S, pe);
+    add_row(tr, rho_b, WALK_DIGITS - 1, false);
     // sigma's 8-fold columns ride on the last 32 doublings (the reference's own trick, ed25519_verify.c:266-279)
 #pragma unroll 1
     for (int i = WALK_DIGITS - 2; i >= 0; i--) {
@@ -420,10 +461,8 @@ C25519_DEV u32 ge_walk_is_neutral(u32 (&sigma)[8], const u32 (&tau_b)[5], const 
                 else ge_add_pa<false>(S, pa);           // a doubling follows: T is not read
             }
         }
-        lookup(tq, tau_b, i);
-        ge_add_pe<true>(S, S, pe);
-        lookup(tr, rho_b, i);
-        ge_add_pe<false>(S, S, pe);
+        add_row(tq, tau_b, i, true);
+        add_row(tr, rho_b, i, false);
     }
     // neutral element: X == 0 and Y == Z (Z != 0 for on-curve inputs under the complete law)
     u32 xw[8], dw[8], acc = 0;
