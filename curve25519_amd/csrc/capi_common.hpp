@@ -70,15 +70,19 @@ inline void arm_exit_guard()
 // device's staging is released first, on that device.  Work scratch of the *_dev functions is kept per device.
 // Everything is released by c25519_amd_thread_release(), or when the thread exits while the runtime is still alive.
 struct ThreadState {
-    static constexpr int LANES = 4;        // pipeline depth of the host-pointer (*_batch) entry points
-    static constexpr int SLOTS = 5;        // arrays per lane (inputs, outputs, in/out)
+    // the host-pointer (*_batch) pipeline: pieces rotate over SETS buffer sets (so staging a piece in never waits for
+    // an earlier piece to be copied out) and over LANES streams (the runtime drives four hardware queues by default:
+    // more streams than that only queue up behind each other, measured)
+    static constexpr int LANES = 4;
+    static constexpr int SETS = 8;
+    static constexpr int SLOTS = 5;        // arrays per set (inputs, outputs, in/out)
     int device = -1;
     hipStream_t stream[LANES] = {};
-    hipEvent_t done[LANES] = {};           // end of a lane's last download
-    void* dbuf[LANES][SLOTS] = {};         // device staging
-    size_t dcap[LANES][SLOTS] = {};
-    void* hbuf[LANES][SLOTS] = {};         // pinned host staging (hipHostMalloc)
-    size_t hcap[LANES][SLOTS] = {};
+    hipEvent_t done[SETS] = {};            // end of a set's last download
+    void* dbuf[SETS][SLOTS] = {};          // device staging
+    size_t dcap[SETS][SLOTS] = {};
+    void* hbuf[SETS][SLOTS] = {};          // pinned host staging (hipHostMalloc)
+    size_t hcap[SETS][SLOTS] = {};
     // work scratch of the *_dev entry points: one grow-only slab PER DEVICE (a thread may drive several GPUs, see
     // multi_device.hip); consecutive calls reuse it in stream order, a call on another stream first waits for the
     // previous use
@@ -91,6 +95,22 @@ struct ThreadState {
         bool used = false;
     };
     WorkSlab work[MAX_DEV];
+    WorkSlab lane_work[LANES];             // ... and one per pipeline lane, so that the pieces of a *_batch call do not
+                                           // wait for each other's kernels (they belong to the staging device)
+
+    WorkSlab* slab_for(hipStream_t s, int dev)
+    {
+        if (s && dev == device)
+            for (int l = 0; l < LANES; l++)
+                if (s == stream[l]) return &lane_work[l];
+        return &work[dev];
+    }
+    static void free_slab(WorkSlab& w)     // on the slab's device, after a synchronize
+    {
+        if (w.ptr) { (void)hipMemset(w.ptr, 0, w.cap); (void)hipFree(w.ptr); }
+        if (w.done) (void)hipEventDestroy(w.done);
+        w = WorkSlab();
+    }
 
     // bind to the current device (creating streams/events on first use)
     int ensure()
@@ -103,15 +123,13 @@ struct ThreadState {
             C25519_TRY(hipSetDevice(dev));
         }
         if (device < 0) {
-            for (int l = 0; l < LANES; l++) {
-                C25519_TRY(hipStreamCreateWithFlags(&stream[l], hipStreamNonBlocking));
-                C25519_TRY(hipEventCreateWithFlags(&done[l], hipEventDisableTiming));
-            }
+            for (int l = 0; l < LANES; l++) C25519_TRY(hipStreamCreateWithFlags(&stream[l], hipStreamNonBlocking));
+            for (int l = 0; l < SETS; l++) C25519_TRY(hipEventCreateWithFlags(&done[l], hipEventDisableTiming));
             device = dev;
         }
         return 0;
     }
-    int reserve_dev(int lane, int slot, size_t bytes)
+    int reserve_dev(int lane /* = buffer set */, int slot, size_t bytes)
     {
         if (bytes <= dcap[lane][slot]) return 0;
         if (dbuf[lane][slot]) { C25519_TRY(hipFree(dbuf[lane][slot])); dbuf[lane][slot] = nullptr; dcap[lane][slot] = 0; }
@@ -135,7 +153,7 @@ struct ThreadState {
         C25519_TRY(hipGetDevice(&dev));
         if (dev < 0 || dev >= MAX_DEV) return bad_arg("device ordinal out of range");
         arm_exit_guard();
-        WorkSlab& w = work[dev];
+        WorkSlab& w = *slab_for(s, dev);
         if (w.ptr && bytes > w.cap) {
             C25519_TRY(hipDeviceSynchronize());
             C25519_TRY(hipFree(w.ptr));
@@ -155,7 +173,7 @@ struct ThreadState {
     {
         int dev = 0;
         C25519_TRY(hipGetDevice(&dev));
-        WorkSlab& w = work[dev];
+        WorkSlab& w = *slab_for(s, dev);
         C25519_TRY(hipEventRecord(w.done, s));
         w.last = s; w.used = true;
         return 0;
@@ -168,15 +186,19 @@ struct ThreadState {
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
-        for (int l = 0; l < LANES; l++) {
+        for (int l = 0; l < SETS; l++) {
             for (int i = 0; i < SLOTS; i++) {
                 if (dbuf[l][i]) { (void)hipMemset(dbuf[l][i], 0, dcap[l][i]); (void)hipFree(dbuf[l][i]); }
                 if (hbuf[l][i]) { memset(hbuf[l][i], 0, hcap[l][i]); (void)hipHostFree(hbuf[l][i]); }
                 dbuf[l][i] = hbuf[l][i] = nullptr; dcap[l][i] = hcap[l][i] = 0;
             }
-            if (stream[l]) (void)hipStreamDestroy(stream[l]);
             if (done[l]) (void)hipEventDestroy(done[l]);
-            stream[l] = nullptr; done[l] = nullptr;
+            done[l] = nullptr;
+        }
+        for (int l = 0; l < LANES; l++) {
+            free_slab(lane_work[l]);
+            if (stream[l]) (void)hipStreamDestroy(stream[l]);
+            stream[l] = nullptr;
         }
         (void)hipGetLastError();
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
@@ -193,9 +215,7 @@ struct ThreadState {
             if (!w.ptr && !w.done) continue;
             (void)hipSetDevice(d);
             (void)hipDeviceSynchronize();
-            if (w.ptr) { (void)hipMemset(w.ptr, 0, w.cap); (void)hipFree(w.ptr); }
-            if (w.done) (void)hipEventDestroy(w.done);
-            w = WorkSlab();
+            free_slab(w);
         }
         (void)hipGetLastError();
         if (cur >= 0) (void)hipSetDevice(cur);

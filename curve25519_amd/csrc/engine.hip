@@ -763,20 +763,30 @@ int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t 
 }
 
 // ---- host-pointer pipeline used by the *_batch entry points -------------------------------------------------------
-// A call is cut into pieces that rotate over LANES (stream, pinned host buffers, device buffers) sets; three roles
-// work on different pieces at the same time:
-//     stage-in  : two helper threads copy the caller's (pageable) arrays into a lane's pinned buffers
+// A call is cut into pieces; piece c uses buffer set c % SETS (pinned host + device staging) and stream c % LANES,
+// and three roles work on different pieces at the same time:
+//     stage-in  : helper threads (2; C25519_AMD_STAGERS) copy the caller's pageable arrays into a set's pinned buffers
 //     submit    : the calling thread enqueues H2D copies, the *_dev kernels and D2H copies into pinned buffers, all
-//                 asynchronous on the lane's stream (pinned memory: hipMemcpyAsync is a real DMA, not a staged copy)
-//     stage-out : a helper thread waits for the lane's event and copies the results into the caller's arrays
+//                 asynchronous on the piece's stream (pinned memory: hipMemcpyAsync is a real DMA, not a staged copy)
+//     stage-out : a helper thread (C25519_AMD_DRAINERS) waits for the set's event and copies the results out
 // so both CPU copies and both PCIe directions ride under the kernels of the neighbouring pieces.  Pieces are n/8 for
 // big batches: the chip needs ~2^19 lanes in flight to run at full rate, and a piece cannot finish faster than one
-// ladder's latency (~1.2 ms), so fewer, larger pieces in flight beat many small ones (measured, profiles/r02_hostapi.txt).
+// ladder's latency (~1.2 ms), so fewer, larger pieces in flight beat many small ones.  Eight buffer sets let a 2^20
+// call stage every piece in without waiting for an earlier one to leave; four streams because the runtime drives four
+// hardware queues (timelines and the rejected shapes: profiles/r02_hostapi_trace.txt, rates: profiles/r02_hostapi.txt).
 struct Arr {
     const void* in;      // caller's source (nullptr: output only)
     void* out;           // caller's destination (nullptr: input only); in and out may both be set (IN/OUT array)
     size_t elem;         // bytes per element
 };
+
+constexpr int MAX_STAGERS = 8, MAX_DRAINERS = 4;
+inline int env_count(const char* name, int dflt, int max)
+{
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= max ? v : dflt;
+}
 
 template <typename Launch>
 int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
@@ -793,25 +803,27 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     const size_t cap = round_up(((size_t)256 << 20) / (row ? row : 1) + 1, 256);       // <= 256 MiB of staging per lane
     if (chunk > cap) chunk = cap;
     const size_t nchunks = (n + chunk - 1) / chunk;
-    const int lanes = nchunks < (size_t)ThreadState::LANES ? (int)nchunks : ThreadState::LANES;
-    for (int l = 0; l < lanes; l++)
+    const int sets = nchunks < (size_t)ThreadState::SETS ? (int)nchunks : ThreadState::SETS;
+    for (int l = 0; l < sets; l++)
         for (int a = 0; a < na; a++) {
             C25519_RC(t.reserve_dev(l, a, arr[a].elem * chunk));
             C25519_RC(t.reserve_host(l, a, arr[a].elem * chunk));
         }
     auto span = [&](size_t c, size_t& lo, size_t& cnt) { lo = c * chunk; cnt = (n - lo < chunk) ? n - lo : chunk; };
-    auto stage_in = [&](size_t c) {
+    auto stage_in = [&](size_t c, int part, int parts) {   // rows [part, part+1) / parts of piece c
         size_t lo, cnt;
         span(c, lo, cnt);
-        const int l = (int)(c % lanes);
+        const size_t r0 = cnt * part / parts, r1 = cnt * (part + 1) / parts;
+        const int l = (int)(c % sets);
         for (int a = 0; a < na; a++)
-            if (arr[a].in && cnt * arr[a].elem) memcpy(t.hbuf[l][a], (const char*)arr[a].in + lo * arr[a].elem, cnt * arr[a].elem);
+            if (arr[a].in && (r1 - r0) * arr[a].elem)
+                memcpy((char*)t.hbuf[l][a] + r0 * arr[a].elem, (const char*)arr[a].in + (lo + r0) * arr[a].elem, (r1 - r0) * arr[a].elem);
     };
     auto submit = [&](size_t c) -> int {
         size_t lo, cnt;
         span(c, lo, cnt);
-        const int l = (int)(c % lanes);
-        hipStream_t st = t.stream[l];
+        const int l = (int)(c % sets);
+        hipStream_t st = t.stream[c % ThreadState::LANES];
         void* dptr[ThreadState::SLOTS] = {};
         for (int a = 0; a < na; a++) {
             dptr[a] = t.dbuf[l][a];
@@ -828,7 +840,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     auto drain = [&](size_t c) -> int {
         size_t lo, cnt;
         span(c, lo, cnt);
-        const int l = (int)(c % lanes);
+        const int l = (int)(c % sets);
         C25519_TRY(hipEventSynchronize(t.done[l]));
         for (int a = 0; a < na; a++)
             if (arr[a].out && cnt * arr[a].elem) memcpy((char*)arr[a].out + lo * arr[a].elem, t.hbuf[l][a], cnt * arr[a].elem);
@@ -837,7 +849,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
 
     auto sequential = [&]() -> int {                      // no helper threads: one piece after the other
         for (size_t c = 0; c < nchunks; c++) {
-            stage_in(c);
+            stage_in(c, 0, 1);
             C25519_RC(submit(c));
             C25519_RC(drain(c));
         }
@@ -847,43 +859,45 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
 
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<char> staged(nchunks, 0);
-    size_t submitted = 0, drained = 0;
+    std::vector<char> staged(nchunks, 0), drained(nchunks, 0);
+    size_t submitted = 0;
     int failed = 0;                                       // first error of any role; everybody stops
-    constexpr int STAGERS = 2;
-    std::thread helpers[STAGERS + 1];
+    static const int STAGERS = env_count("C25519_AMD_STAGERS", 2, MAX_STAGERS);
+    static const int DRAINERS = env_count("C25519_AMD_DRAINERS", 1, MAX_DRAINERS);
+    std::thread helpers[MAX_STAGERS + MAX_DRAINERS];
     int started = 0;
     try {
     for (int sidx = 0; sidx < STAGERS; sidx++, started++)
-        helpers[sidx] = std::thread([&, sidx] {
-            for (size_t c = sidx; c < nchunks; c += STAGERS) {
-                {   // the lane's previous piece must have left its pinned buffers
+        helpers[started] = std::thread([&, sidx] {
+            for (size_t c = 0; c < nchunks; c++) {        // every stager copies its share of every piece: pieces
+                                                          // become ready in order, each in 1/STAGERS of the time
+                {   // the previous piece in this buffer set must have left its pinned buffers
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return failed || c < (size_t)lanes || drained > c - lanes; });
+                    cv.wait(lk, [&] { return failed || c < (size_t)sets || drained[c - sets]; });
                     if (failed) return;
                 }
-                stage_in(c);
-                { std::lock_guard<std::mutex> lk(mu); staged[c] = 1; }
+                stage_in(c, sidx, STAGERS);
+                { std::lock_guard<std::mutex> lk(mu); staged[c]++; }
                 cv.notify_all();
             }
         });
-    helpers[STAGERS] = std::thread([&] {
-        for (size_t c = 0; c < nchunks; c++) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return failed || submitted > c; });
-                if (failed) return;
+    for (int didx = 0; didx < DRAINERS; didx++, started++)
+        helpers[started] = std::thread([&, didx] {
+            for (size_t c = didx; c < nchunks; c += DRAINERS) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return failed || submitted > c; });
+                    if (failed) return;
+                }
+                const int rc = drain(c);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (rc && !failed) failed = rc;
+                    drained[c] = 1;
+                }
+                cv.notify_all();
             }
-            const int rc = drain(c);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (rc && !failed) failed = rc;
-                drained = c + 1;
-            }
-            cv.notify_all();
-        }
-    });
-    started++;
+        });
     } catch (const std::system_error&) {                  // the process cannot have more threads: do without them
         { std::lock_guard<std::mutex> lk(mu); failed = -1; }
         cv.notify_all();
@@ -893,7 +907,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     for (size_t c = 0; c < nchunks; c++) {
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return failed || staged[c]; });
+            cv.wait(lk, [&] { return failed || staged[c] == STAGERS; });
             if (failed) break;
         }
         const int rc = submit(c);
@@ -905,7 +919,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
         cv.notify_all();
         if (rc) break;
     }
-    for (auto& h : helpers) h.join();
+    for (int i = 0; i < started; i++) helpers[i].join();
     return failed;
 }
 
