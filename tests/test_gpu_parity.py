@@ -780,3 +780,40 @@ def test_lattice_fast_path_and_reference_order_agree(api, oracle):
                            capture_output=True, text=True, timeout=600, env={**os.environ, "C25519_AMD_VERIFY_REFERENCE_ORDER": "1"})
         assert p.returncode == 0, p.stderr[-2000:]
         assert np.array_equal(np.load(os.path.join(tmp, "out.npy")), ok)
+
+
+@pytest.mark.parametrize("knobs", [{"C25519_AMD_BATCH_PIECES": "24", "C25519_AMD_STAGERS": "3", "C25519_AMD_DRAINERS": "2"},
+                                   {"C25519_AMD_BATCH_PIECES": "2", "C25519_AMD_STAGERS": "1", "C25519_AMD_DRAINERS": "1"}])
+def test_host_pipeline_shapes_give_the_same_bytes(api, oracle, knobs):
+    """The *_batch pipeline (engine.hip run_batch) in shapes the default call never takes: more pieces than buffer
+    sets (a set is reused only after its previous piece was copied out), several stage-in / stage-out threads, and the
+    two-piece minimum.  Same bytes as the default shape, and a sample of them against the oracle."""
+    n = 300001
+    sk, pk = synth.x25519_inputs(n)
+    esk, msg = synth.ed25519_inputs(n)
+    shared, _ = api.curve25519_dh_CreateSharedKey(pk, sk)
+    pub, priv = api.ed25519_CreateKeyPair(esk)
+    sig = api.ed25519_SignMessage(priv, msg)
+    bsig, bmsg, bad = synth.corrupt_for_verify(sig, msg)
+    ok = api.ed25519_VerifySignature(bsig, pub, bmsg)
+    assert np.array_equal(ok == 0, bad)
+    idx = np.arange(0, n, 997)
+    assert np.array_equal(shared[idx], oracle.x25519_shared(np.ascontiguousarray(pk[idx]), np.ascontiguousarray(sk[idx]))[0])
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from curve25519_amd import api\n"
+        "d = np.load(sys.argv[1])\n"
+        "shared, _ = api.curve25519_dh_CreateSharedKey(d['pk'], d['sk'])\n"
+        "pub, priv = api.ed25519_CreateKeyPair(d['esk'])\n"
+        "sig = api.ed25519_SignMessage(priv, d['msg'])\n"
+        "ok = api.ed25519_VerifySignature(d['bsig'], pub, d['bmsg'])\n"
+        "np.savez(sys.argv[2], shared=shared, pub=pub, priv=priv, sig=sig, ok=ok)\n") % ROOT
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), pk=pk, sk=sk, esk=esk, msg=msg, bsig=bsig, bmsg=bmsg)
+        p = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")],
+                           capture_output=True, text=True, timeout=600, env={**os.environ, **knobs})
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = np.load(os.path.join(tmp, "out.npz"))
+        for name, want in (("shared", shared), ("pub", pub), ("priv", priv), ("sig", sig), ("ok", ok)):
+            assert np.array_equal(out[name], want), name
