@@ -247,6 +247,31 @@ __global__ void __launch_bounds__(256) k_rate(unsigned* out, unsigned seed, unsi
 #define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(q##i) : "v"(a) : "vcc");
             REP8(X) REP8(X)
 #undef X
+        } else if constexpr (KIND == 48) {  // the ladder's select: ONE v_cmp writes vcc, 16 v_cndmask_b32 (VOP2) read it
+            asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a), "v"(b) : "vcc");
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r##i) : "v"(a) : );
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 49) {  // select by mask arithmetic: r ^= (r ^ a) & m   (3 full-rate VOP2 per select; counts 15 + 1)
+#define X(i) asm volatile("v_xor_b32 %1, %0, %2\n\tv_and_b32 %1, %1, %3\n\tv_xor_b32 %0, %0, %1" : "+v"(r##i), "+v"(t##i) : "v"(a), "v"(b));
+            X(0) X(1) X(2) X(3) X(4)
+            asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r5) : "v"(a));
+#undef X
+        } else if constexpr (KIND == 50) {  // v_cndmask_b32 (VOP2, vcc) with vcc written by an SALU move every iteration
+            asm volatile("s_mov_b64 vcc, s[22:23]" : : : "vcc");
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r##i) : "v"(a) : );
+            REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == 51) {  // v_cndmask_b32(vcc) alternating with an independent v_xor_b32 (8 + 8)
+            asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a), "v"(b) : "vcc");
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %2, vcc\n\tv_xor_b32 %1, %1, %2" : "+v"(r##i), "+v"(t##i) : "v"(a) : );
+            REP8(X)
+#undef X
+        } else if constexpr (KIND == 52) {  // v_cndmask_b32(vcc) with 3 independent VALU ops between (4 + 12)
+            asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a), "v"(b) : "vcc");
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %2, vcc\n\tv_xor_b32 %1, %1, %2\n\tv_add_u32 %1, %1, %2\n\tv_xor_b32 %1, %1, %0" : "+v"(r##i), "+v"(t##i) : "v"(a) : );
+            X(0) X(1) X(2) X(3)
+#undef X
         } else if constexpr (KIND == 23) {  // v_mad_i32_i24 ... placeholder for v_perm/v_bfe: v_bfe_u32
 #define X(i) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(r##i));
             REP8(X) REP8(X)
@@ -279,6 +304,9 @@ static const Kind kinds[] = {
     {40, "mad64+addc pair (saturated radix)"}, {41, "v_lshl_add_u32"}, {42, "v_or_b32"},
     {44, "v_mad_u64_u32(dependent, ping-pong dst)"}, {45, "v_mad_u64_u32(operands in 4 banks)"},
     {46, "v_mad_u64_u32(operands in 1 bank)"}, {47, "v_mad_u64_u32(src0 == src1)"},
+    {48, "1 v_cmp + 16 v_cndmask_b32(vcc)"}, {49, "select by xor/and/xor (per VALU instr)"},
+    {50, "s_mov vcc + 16 v_cndmask_b32(vcc)"}, {51, "v_cndmask_b32(vcc) : v_xor alternating"},
+    {52, "1 v_cndmask_b32(vcc) : 3 VALU"},
 };
 
 static unsigned long long* g_ticks;
@@ -290,7 +318,7 @@ static void dispatch(int kind, int blocks, unsigned* d, hipStream_t s)
 #define C(k) case k: launch<k>(blocks, d, s); break;
         C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(18)
         C(19) C(20) C(21) C(22) C(23) C(24) C(25) C(26) C(27) C(28) C(29) C(30) C(31) C(32) C(33) C(34) C(35) C(36)
-        C(37) C(38) C(39) C(40) C(41) C(42) C(43) C(44) C(45) C(46) C(47)
+        C(37) C(38) C(39) C(40) C(41) C(42) C(43) C(44) C(45) C(46) C(47) C(48) C(49) C(50) C(51) C(52)
 #undef C
     }
 }
