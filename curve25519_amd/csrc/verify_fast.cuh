@@ -33,6 +33,11 @@ namespace c25519 {
 //     until its remainder is below 2^129, which keeps its cofactor as short as the lattice allows.
 // Whatever comes out is checked (odd, short enough) before it is used.
 constexpr int LAT_CAP_BITS = 142;          // what the 36-digit signed walk can take (a random h exceeds it with p ~ 6e-6: measured, 6 of 2^20)
+#ifndef C25519_LAT_COUNT
+#define C25519_LAT_COUNT(what)          // the host emulation counts loop trips here (tests/host_emul)
+#endif
+constexpr int LAT_LEHMER_STOP = 128;        // Lehmer steps bring the smaller remainder down to this many bits; the
+                                            // exact steps (ten times dearer per bit) only finish: 128 / 129 bits
 constexpr int LAT_R = 8, LAT_T = 6;        // words of a remainder (unsigned) / of a cofactor (two's complement)
 
 template <int W>
@@ -149,6 +154,7 @@ C25519_DEV bool lat_lehmer_step(u32 (&r0)[LAT_R], u32 (&t0)[LAT_T], u32 (&r1)[LA
     const int l0 = bitlen_words<LAT_R>(r0), l1 = bitlen_words<LAT_R>(r1);
     const int top = l0 > l1 ? l0 : l1;
     const bool words = __any(active && top > 62 + 31);
+    const int scale = top > 62 ? top - 62 : 0;            // x0, x1 are the remainders >> scale
     u64 x0 = leading62<LAT_R>(r0, top, words), x1 = leading62<LAT_R>(r1, top, words);
     // x0 = A*a - B*b, x1 = -C*a + D*b for the original leading parts (a, b); entries only ever grow
     u32 A = 1, B = 0, C = 0, D = 1;
@@ -161,9 +167,12 @@ C25519_DEV bool lat_lehmer_step(u32 (&r0)[LAT_R], u32 (&t0)[LAT_T], u32 (&r1)[LA
         u64 sh = small << k;
         if (sh > big) { k -= 1; sh >>= 1; }
         const u64 n0 = (u64)mb0 + ((u64)ms0 << k), n1 = (u64)mb1 + ((u64)ms1 << k);
-        // keep the matrix below 2^31 and the smaller leading part above 2^33 (below that its low bits are noise)
-        const bool go = active && small >= ((u64)1 << 33) && k < 31 && n0 < ((u64)1 << 31) && n1 < ((u64)1 << 31);
+        // keep the matrix below 2^31 and the smaller leading part above 2^33 (below that its low bits are noise); stop
+        // where the exact steps take over (the smaller remainder down to LAT_LEHMER_STOP bits)
+        const bool go = active && small >= ((u64)1 << 33) && k < 31 && n0 < ((u64)1 << 31) && n1 < ((u64)1 << 31)
+                        && bitlen64(small) + scale > LAT_LEHMER_STOP;
         if (!__any(go)) break;
+        C25519_LAT_COUNT(lehmer_inner);
         if (go) {
             const u64 nb = big - sh;
             x0 = c ? nb : x0; x1 = c ? x1 : nb;
@@ -214,8 +223,9 @@ C25519_DEV u32 sc_lattice_short(u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative,
 #pragma unroll 1
         for (int guard = 0; guard < 16; guard++) {
             const int l0 = bitlen_words<LAT_R>(r0), l1 = bitlen_words<LAT_R>(r1);
-            active = active && sane && (l0 < l1 ? l0 : l1) > 160;
+            active = active && sane && (l0 < l1 ? l0 : l1) > LAT_LEHMER_STOP;
             if (!__any(active)) break;
+            C25519_LAT_COUNT(lehmer_outer);
             active = lat_lehmer_step(r0, t0, r1, t1, active, sane) && active;
         }
     }
@@ -237,6 +247,7 @@ C25519_DEV u32 sc_lattice_short(u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative,
         const bool want = sane && !stopped && room && lsmall != 0 && (lsmall > 128 || lbig > 129);
         stopped = stopped || (sane && !room);
         if (!__any(want)) break;
+        C25519_LAT_COUNT(exact_steps);
         u32 big[LAT_R], small[LAT_R], tb[LAT_T], ts[LAT_T], sh[LAT_R], tsh[LAT_T];
 #pragma unroll
         for (int i = 0; i < LAT_R; i++) { big[i] = c ? r0[i] : r1[i]; small[i] = c ? r1[i] : r0[i]; }

@@ -12,7 +12,7 @@
 
 using namespace c25519;
 
-namespace c25519 { unsigned long long emul_mad_overflows = 0; }
+namespace c25519 { unsigned long long emul_mad_overflows = 0; LatCounters emul_lat_counters = { 0, 0, 0 }; }
 
 namespace {
 
@@ -236,6 +236,13 @@ void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char*
         verdict[i] = ((pts & 1u) && neutral) ? 1 : 0;
         need_slow[i] = (lat_ok && (pts & 2u)) ? 0 : 1;
     }
+}
+
+// loop trips of the lattice reduction since the last call (outer Lehmer steps, their inner iterations, exact steps)
+void emul_lattice_counters(unsigned long long* out3)
+{
+    out3[0] = emul_lat_counters.lehmer_outer; out3[1] = emul_lat_counters.lehmer_inner; out3[2] = emul_lat_counters.exact_steps;
+    emul_lat_counters = LatCounters{ 0, 0, 0 };
 }
 
 // lattice reduction alone: h (n x 32) -> rho, tau (n x 20 bytes each), sign of tau, fits

@@ -28,6 +28,11 @@ namespace c25519 {
 typedef uint32_t u32;
 typedef uint64_t u64;
 
+// loop-trip counters of the lattice reduction (verify_fast.cuh), read by tests/test_verify_fast.py
+struct LatCounters { unsigned long long lehmer_outer, lehmer_inner, exact_steps; };
+extern LatCounters emul_lat_counters;
+#define C25519_LAT_COUNT(what) (++::c25519::emul_lat_counters.what)
+
 inline u32 dbl32(u32 x) { return x + x; }
 inline u32 alignbit32(u32 hi, u32 lo, int s) { return (u32)((((u64)hi << 32) | lo) >> s); }
 

@@ -41,8 +41,14 @@ def test_short_vector_properties(emul):
     h = np.stack([vectors.le(x, 32) for x in hs])
     rho, tau = np.empty((n, 20), np.uint8), np.empty((n, 20), np.uint8)
     neg, fits = np.empty(n, np.int32), np.empty(n, np.int32)
+    trips = (C.c_ulonglong * 3)()
+    emul.emul_lattice_counters(trips)
     emul.emul_lattice(C.c_void_p(rho.ctypes.data), C.c_void_p(tau.ctypes.data), C.c_void_p(neg.ctypes.data),
                       C.c_void_p(fits.ctypes.data), C.c_void_p(h.ctypes.data), C.c_size_t(n))
+    emul.emul_lattice_counters(trips)
+    # where the time goes: ~5 Lehmer steps (22 inner iterations each) do the work, the ten-times-dearer exact steps only
+    # finish (they were 17 per element before the Lehmer phase was run down to 128 bits)
+    assert trips[0] / n < 5.5 and trips[1] / n < 120 and trips[2] / n < 4, list(trips)   # (structured inputs included: 2.6; random: 0.8)
     for i, x in enumerate(hs):
         if not fits[i]:
             continue
