@@ -936,7 +936,7 @@ inline size_t verify_scratch_bytes(size_t n)
 // short vectors fit; the others run the reference's order inside the same walk kernel.  fast = false: reference order
 // for everything in its own kernels, and Fin decides what leaves it: the verdict, or enc(T) for the test hook.
 // where the calling thread's last fast-path verification left its per-workgroup flags (c25519_amd_verify_last_slow_groups)
-struct LastVerify { const u32* wg_slow = nullptr; unsigned groups = 0; hipStream_t stream = nullptr; int device = -1; };
+struct LastVerify { const u32* wg_slow = nullptr; unsigned groups = 0; hipStream_t stream = nullptr; int device = -1; const ThreadState::WorkSlab* slab = nullptr; };
 thread_local LastVerify tl_last_verify;
 
 template <typename MakeFin>
@@ -965,6 +965,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
         C25519_TRY(hipGetLastError());
         tl_last_verify.wg_slow = fs.wg_slow; tl_last_verify.groups = grid; tl_last_verify.stream = stream;
         (void)hipGetDevice(&tl_last_verify.device);
+        tl_last_verify.slab = tls().slab_for(stream, tl_last_verify.device);
         return tls().release_work(stream);
     }
     tl_last_verify = LastVerify();
@@ -1161,10 +1162,9 @@ long c25519_amd_verify_last_slow_groups(void)
     const LastVerify& lv = tl_last_verify;
     int dev = -1;
     if (!lv.wg_slow || hipGetDevice(&dev) != hipSuccess || dev != lv.device) return -1;
-    {   // the flags live in the thread's work slab: stale if that slab has been released or regrown since
-        const ThreadState::WorkSlab& w = tls().work[dev];
-        const char* lo = (const char*)w.ptr;
-        if (!lo || (const char*)lv.wg_slow < lo || (const char*)(lv.wg_slow + lv.groups) > lo + w.cap) return -1;
+    {   // the flags live in one of the thread's work slabs: stale if that slab has been released or regrown since
+        const char* lo = lv.slab ? (const char*)lv.slab->ptr : nullptr;
+        if (!lo || (const char*)lv.wg_slow < lo || (const char*)(lv.wg_slow + lv.groups) > lo + lv.slab->cap) return -1;
     }
     if (hipStreamSynchronize(lv.stream) != hipSuccess) return -1;
     std::vector<u32> flags(lv.groups);

@@ -103,7 +103,8 @@ int ed25519_VerifySignature_ragged_dev(void *verdict, const void *sig, const voi
  * lattice-shortened walk (csrc/verify_fast.cuh, 140 doublings instead of 255) and run the reference's own operation
  * order only for the others (set C25519_AMD_VERIFY_REFERENCE_ORDER=1 to force it for everything).  This reports how many
  * workgroups of the calling thread's last verification on the current device took the reference-order kernels; -1 when
- * there is nothing to report.  Synchronises with that call's stream. */
+ * there is nothing to report (a *_batch call that was cut into pieces reports its last piece).  Synchronises with that
+ * call's stream. */
 long c25519_amd_verify_last_slow_groups(void);
 
 /* bytes of device scratch ed25519_VerifySignature_dev needs for n elements (per-lane 4-fold tables);

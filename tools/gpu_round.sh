@@ -11,9 +11,10 @@ WHAT=${*:-all}
 has() { [[ " $WHAT " == *" $1 "* || " $WHAT " == *" all "* ]]; }
 
 if has tests; then
-  timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 > $OUT/pytest_gpu.log
-  echo "pytest rc=$?" >> $OUT/pytest_gpu.log
-  tail -5 $OUT/pytest_gpu.log
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.full 2>&1
+  echo "pytest rc=$?" > $OUT/pytest_gpu.rc                      # pytest's own exit code, not a pipe's
+  tail -30 $OUT/pytest_gpu.full > $OUT/pytest_gpu.log; cat $OUT/pytest_gpu.rc >> $OUT/pytest_gpu.log; rm -f $OUT/pytest_gpu.full
+  grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -3; cat $OUT/pytest_gpu.rc
 fi
 if has bench; then
   timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
