@@ -28,6 +28,8 @@ SIGNATURES = {
     "ed25519_VerifySignature_dev": [_vp, _vp, _vp, _vp, _sz, _sz, _vp],
     "ed25519_VerifySignature_scratch_bytes": [_sz],
     "c25519_amd_verify_last_slow_groups": [],
+    "c25519_amd_host_register": [_vp, _sz],
+    "c25519_amd_host_unregister": [_vp],
     "ed25519_Verify_Init_batch": [_vp, _vp, _sz],
     "ed25519_Verify_Init_dev": [_vp, _vp, _sz, _vp],
     "ed25519_Verify_Check_batch": [_vp, _vp, _vp, _vp, _sz, _sz],

@@ -23,6 +23,7 @@ inline int fail(hipError_t err, const char* what, const char* file, int line)
     char buf[512];
     snprintf(buf, sizeof buf, "%s: %s (%s:%d)", what, hipGetErrorString(err), file, line);
     last_error() = buf;
+    (void)hipGetLastError();       // reported through rc + text: do not leave it for the next launch check to trip over
     return (int)err ? (int)err : -1;
 }
 

@@ -788,6 +788,19 @@ inline int env_count(const char* name, int dflt, int max)
     return v >= 1 && v <= max ? v : dflt;
 }
 
+// is [p, p + bytes) page-locked host memory the device can DMA from (hipHostMalloc / hipHostRegister /
+// c25519_amd_host_register)?  Such arrays skip the staging copies: the H2D / D2H copies run on the caller's memory.
+inline bool host_pinned(const void* p, size_t bytes)
+{
+    if (!p || !bytes) return false;
+    for (const char* q : { (const char*)p, (const char*)p + bytes - 1 }) {
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }   // pageable
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
 template <typename Launch>
 int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
 {
@@ -804,10 +817,15 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     if (chunk > cap) chunk = cap;
     const size_t nchunks = (n + chunk - 1) / chunk;
     const int sets = nchunks < (size_t)ThreadState::SETS ? (int)nchunks : ThreadState::SETS;
+    bool direct[ThreadState::SLOTS] = {};                  // the caller's array is pinned: no staging copy either way
+    for (int a = 0; a < na; a++) {
+        direct[a] = (!arr[a].in || host_pinned(arr[a].in, n * arr[a].elem)) && (!arr[a].out || host_pinned(arr[a].out, n * arr[a].elem));
+        if (arr[a].in && arr[a].out && arr[a].in != arr[a].out) direct[a] = false;
+    }
     for (int l = 0; l < sets; l++)
         for (int a = 0; a < na; a++) {
             C25519_RC(t.reserve_dev(l, a, arr[a].elem * chunk));
-            C25519_RC(t.reserve_host(l, a, arr[a].elem * chunk));
+            if (!direct[a]) C25519_RC(t.reserve_host(l, a, arr[a].elem * chunk));
         }
     auto span = [&](size_t c, size_t& lo, size_t& cnt) { lo = c * chunk; cnt = (n - lo < chunk) ? n - lo : chunk; };
     auto stage_in = [&](size_t c, int part, int parts) {   // rows [part, part+1) / parts of piece c
@@ -816,7 +834,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
         const size_t r0 = cnt * part / parts, r1 = cnt * (part + 1) / parts;
         const int l = (int)(c % sets);
         for (int a = 0; a < na; a++)
-            if (arr[a].in && (r1 - r0) * arr[a].elem)
+            if (arr[a].in && !direct[a] && (r1 - r0) * arr[a].elem)
                 memcpy((char*)t.hbuf[l][a] + r0 * arr[a].elem, (const char*)arr[a].in + (lo + r0) * arr[a].elem, (r1 - r0) * arr[a].elem);
     };
     auto submit = [&](size_t c) -> int {
@@ -828,12 +846,14 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
         for (int a = 0; a < na; a++) {
             dptr[a] = t.dbuf[l][a];
             if (arr[a].in && cnt * arr[a].elem)
-                C25519_TRY(hipMemcpyAsync(dptr[a], t.hbuf[l][a], cnt * arr[a].elem, hipMemcpyHostToDevice, st));
+                C25519_TRY(hipMemcpyAsync(dptr[a], direct[a] ? (const char*)arr[a].in + lo * arr[a].elem : (const char*)t.hbuf[l][a],
+                                          cnt * arr[a].elem, hipMemcpyHostToDevice, st));
         }
         C25519_RC(launch(dptr, cnt, lo, st));
         for (int a = 0; a < na; a++)
             if (arr[a].out && cnt * arr[a].elem)
-                C25519_TRY(hipMemcpyAsync(t.hbuf[l][a], dptr[a], cnt * arr[a].elem, hipMemcpyDeviceToHost, st));
+                C25519_TRY(hipMemcpyAsync(direct[a] ? (char*)arr[a].out + lo * arr[a].elem : (char*)t.hbuf[l][a], dptr[a],
+                                          cnt * arr[a].elem, hipMemcpyDeviceToHost, st));
         C25519_TRY(hipEventRecord(t.done[l], st));
         return 0;
     };
@@ -843,7 +863,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
         const int l = (int)(c % sets);
         C25519_TRY(hipEventSynchronize(t.done[l]));
         for (int a = 0; a < na; a++)
-            if (arr[a].out && cnt * arr[a].elem) memcpy((char*)arr[a].out + lo * arr[a].elem, t.hbuf[l][a], cnt * arr[a].elem);
+            if (arr[a].out && !direct[a] && cnt * arr[a].elem) memcpy((char*)arr[a].out + lo * arr[a].elem, t.hbuf[l][a], cnt * arr[a].elem);
         return 0;
     };
 
@@ -989,6 +1009,20 @@ int c25519_amd_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
+}
+
+int c25519_amd_host_register(void* p, size_t bytes)
+{
+    if (!p || !bytes) return bad_arg("null pointer or empty range");
+    C25519_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return 0;
+}
+
+int c25519_amd_host_unregister(void* p)
+{
+    if (!p) return bad_arg("null pointer");
+    C25519_TRY(hipHostUnregister(p));
+    return 0;
 }
 
 int c25519_amd_set_device(int device)

@@ -34,11 +34,18 @@ const char *c25519_amd_version(void);
 const char *c25519_amd_last_error(void);               /* per-thread, "" when none */
 int  c25519_amd_device_count(void);                    /* usable HIP devices (0 when none) */
 int  c25519_amd_set_device(int device);                /* device used by this host thread */
-/* Each host thread that calls into the library owns four streams, pinned + device staging buffers and a work
- * scratch slab, all on the device that was current at its first call (they follow the thread to another device on
+/* Each host thread that calls into the library owns four streams, eight sets of pinned + device staging buffers and work
+ * scratch slabs, all on the device that was current at its first call (they follow the thread to another device on
  * the next call, released on the old one first).  They are freed when the thread exits; a long-lived thread can
  * give them back earlier with this call.  Staging buffers are zeroed before they are freed. */
 void c25519_amd_thread_release(void);
+
+/* Optional: page-lock a host array the caller is going to pass to *_batch functions again and again (hipHostRegister).
+ * A *_batch call recognises page-locked arguments (registered here, or allocated with hipHostMalloc) and lets the DMA
+ * engines read / write them directly instead of staging them through its own pinned buffers: no CPU copy at all.
+ * Registration costs about a millisecond per 100 MB: worth it for buffers that are reused.  Unregister before free(). */
+int c25519_amd_host_register(void *p, size_t bytes);
+int c25519_amd_host_unregister(void *p);
 
 /* X25519 ------------------------------------------------------------------------------------ */
 /* n x curve25519_dh_CreateSharedKey (reference include/curve25519_dh.h:45); sk is clamped in place */

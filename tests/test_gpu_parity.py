@@ -817,3 +817,54 @@ def test_host_pipeline_shapes_give_the_same_bytes(api, oracle, knobs):
         out = np.load(os.path.join(tmp, "out.npz"))
         for name, want in (("shared", shared), ("pub", pub), ("priv", priv), ("sig", sig), ("ok", ok)):
             assert np.array_equal(out[name], want), name
+
+
+def test_page_locked_caller_arrays_are_used_in_place(api, oracle):
+    """*_batch recognises page-locked arguments (c25519_amd_host_register, or hipHostMalloc memory such as torch's
+    pinned tensors) and lets the copy engines work on them directly; any mix of locked and pageable arguments, the
+    IN/OUT secret-key array included, gives the bytes of the ordinary call."""
+    import torch
+    from curve25519_amd import _lib
+    L = _lib.load()
+    n = 200003
+    P = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    sk, pk = synth.x25519_inputs(n)
+    want, want_sk = api.curve25519_dh_CreateSharedKey(pk, sk)
+    # every argument registered
+    r_sk, r_pk, r_out = sk.copy(), pk.copy(), np.zeros((n, 32), np.uint8)
+    for a in (r_sk, r_pk, r_out):
+        assert L.c25519_amd_host_register(P(a), a.nbytes) == 0
+    assert L.curve25519_dh_CreateSharedKey_batch(P(r_out), P(r_pk), P(r_sk), n) == 0
+    assert np.array_equal(r_out, want) and np.array_equal(r_sk, want_sk), "clamped in place, in the caller's locked array"
+    # only the output registered, inputs pageable; then only one input
+    p_sk = sk.copy()
+    r_out[:] = 0
+    assert L.curve25519_dh_CreateSharedKey_batch(P(r_out), P(pk), P(p_sk), n) == 0
+    assert np.array_equal(r_out, want) and np.array_equal(p_sk, want_sk)
+    out = np.zeros((n, 32), np.uint8)
+    p_sk = sk.copy()
+    assert L.curve25519_dh_CreateSharedKey_batch(P(out), P(r_pk), P(p_sk), n) == 0
+    assert np.array_equal(out, want)
+    # a window into a registered array that ends at its last byte, and one that starts inside it
+    m = 70001
+    out = np.zeros((m, 32), np.uint8)
+    t_sk = r_sk[n - m:].copy()
+    assert L.curve25519_dh_CreateSharedKey_batch(P(out), P(r_pk[n - m:]), P(t_sk), m) == 0
+    assert np.array_equal(out, want[n - m:])
+    for a in (r_sk, r_pk, r_out):
+        assert L.c25519_amd_host_unregister(P(a)) == 0
+    assert L.c25519_amd_host_unregister(P(out)) != 0 and b"hipHostUnregister" in L.c25519_amd_last_error()
+    # torch's pinned tensors (hipHostMalloc) through sign + verify
+    esk, msg = synth.ed25519_inputs(n)
+    pub, priv = api.ed25519_CreateKeyPair(esk)
+    sig = api.ed25519_SignMessage(priv, msg)
+    pin = {k: torch.from_numpy(v).pin_memory() for k, v in dict(priv=priv, msg=msg, pub=pub).items()}
+    t_sig = torch.zeros((n, 64), dtype=torch.uint8).pin_memory()
+    t_ok = torch.zeros(n, dtype=torch.int32).pin_memory()
+    D = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    assert L.ed25519_SignMessage_batch(D(t_sig), D(pin["priv"]), D(pin["msg"]), msg.shape[1], n) == 0
+    assert np.array_equal(t_sig.numpy(), sig)
+    bsig, bmsg, bad = synth.corrupt_for_verify(sig, msg)
+    t_sig.copy_(torch.from_numpy(bsig))
+    assert L.ed25519_VerifySignature_batch(D(t_ok), D(t_sig), D(pin["pub"]), P(bmsg), bmsg.shape[1], n) == 0
+    assert np.array_equal(t_ok.numpy() == 0, bad)

@@ -59,26 +59,39 @@ from curve25519_amd import _lib  # noqa: E402
 L = _lib.load()
 h32, h64, hok = np.zeros((n, 32), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32)
 P = lambda a: a.ctypes.data  # noqa: E731
+# the same arrays page-locked by the caller (c25519_amd_host_register): *_batch then skips its staging copies
+reg = {k: v.copy() for k, v in dict(h32=h32, h64=h64, hok=hok, pk=pk, sk=sk, priv=priv, msg=msg, sig=sig, pub=pub).items()}
+for v in reg.values():
+    assert L.c25519_amd_host_register(P(v), v.nbytes) == 0
+R = lambda k: reg[k].ctypes.data  # noqa: E731
 rows = {}
-for name, cfn, pfn, dfn, moved in (
+for name, cfn, rfn, pfn, dfn, moved in (
         ("x25519", lambda: L.curve25519_dh_CreateSharedKey_batch(P(h32), P(pk), P(sk), n),
+         lambda: L.curve25519_dh_CreateSharedKey_batch(R("h32"), R("pk"), R("sk"), n),
          lambda: api.curve25519_dh_CreateSharedKey(pk, sk),
          lambda: api.curve25519_dh_CreateSharedKey_dev(o32, d["pk"], d["sk"]), 128),
         ("sign", lambda: L.ed25519_SignMessage_batch(P(h64), P(priv), P(msg), 32, n),
+         lambda: L.ed25519_SignMessage_batch(R("h64"), R("priv"), R("msg"), 32, n),
          lambda: api.ed25519_SignMessage(priv, msg),
          lambda: api.ed25519_SignMessage_dev(o64, d["priv"], d["msg"]), 160),
         ("verify", lambda: L.ed25519_VerifySignature_batch(P(hok), P(sig), P(pub), P(msg), 32, n),
+         lambda: L.ed25519_VerifySignature_batch(R("hok"), R("sig"), R("pub"), R("msg"), 32, n),
          lambda: api.ed25519_VerifySignature(sig, pub, msg),
          lambda: api.ed25519_VerifySignature_dev(ok, d["sig"], d["pub"], d["msg"]), 132)):
-    assert cfn() == 0
-    tc, tp, td = host_rate(cfn), host_rate(pfn), dev_rate(dfn)
+    assert cfn() == 0 and rfn() == 0
+    tc, tr, tp, td = host_rate(cfn), host_rate(rfn), host_rate(pfn), dev_rate(dfn)
     rows[name] = {"c_abi_ms": round(tc * 1e3, 3), "c_abi_Mops": round(n / tc / 1e6, 2),
                   "numpy_wrapper_ms": round(tp * 1e3, 3), "dev_ms": round(td * 1e3, 3),
                   "dev_Mops": round(n / td / 1e6, 2), "c_abi_over_dev": round(td / tc, 3),
-                  "pcie_GBps": round(moved * n / tc / 1e9, 2)}
+                  "pcie_GBps": round(moved * n / tc / 1e9, 2), "registered_ms": round(tr * 1e3, 3),
+                  "registered_Mops": round(n / tr / 1e6, 2), "registered_over_dev": round(td / tr, 3)}
     print(f"{name:7s} *_batch (host pointers) {tc * 1e3:8.2f} ms per 2^{int(np.log2(n))} = {n / tc / 1e6:7.1f} M ops/s "
           f"({moved * n / tc / 1e9:5.1f} GB/s moved, staging inclusive; numpy wrapper {tp * 1e3:7.2f} ms) | *_dev "
-          f"{td * 1e3:7.2f} ms = {n / td / 1e6:7.1f} M ops/s | ratio {td / tc:.2f}")
-assert np.array_equal(hok, np.ones(n, np.int32))
+          f"{td * 1e3:7.2f} ms = {n / td / 1e6:7.1f} M ops/s | ratio {td / tc:.2f} | caller's arrays registered "
+          f"{tr * 1e3:7.2f} ms = {n / tr / 1e6:7.1f} M ops/s, ratio {td / tr:.2f}")
+assert np.array_equal(hok, np.ones(n, np.int32)) and np.array_equal(reg["hok"], hok)
+assert np.array_equal(reg["h32"], h32) and np.array_equal(reg["h64"], h64)
+for v in reg.values():
+    assert L.c25519_amd_host_unregister(P(v)) == 0
 if args.json:
     json.dump({"n": n, "rows": rows}, open(args.json, "w"), indent=1)
