@@ -72,14 +72,16 @@ inline void arm_exit_guard()
 // Everything is released by c25519_amd_thread_release(), or when the thread exits while the runtime is still alive.
 struct ThreadState {
     // the host-pointer (*_batch) pipeline: pieces rotate over SETS buffer sets (so staging a piece in never waits for
-    // an earlier piece to be copied out) and over LANES streams (the runtime drives four hardware queues by default:
-    // more streams than that only queue up behind each other, measured)
+    // an earlier piece to be copied out); LANES streams -- two for kernels, one per copy direction (the runtime drives
+    // four hardware queues by default: more streams than that only queue up behind each other, measured)
     static constexpr int LANES = 4;
     static constexpr int SETS = 8;
     static constexpr int SLOTS = 5;        // arrays per set (inputs, outputs, in/out)
     int device = -1;
-    hipStream_t stream[LANES] = {};
+    hipStream_t stream[LANES] = {};        // [0], [1]: kernels of even / odd pieces; [2]: uploads; [3]: downloads
     hipEvent_t done[SETS] = {};            // end of a set's last download
+    hipEvent_t uploaded[SETS] = {};        // end of a set's last upload
+    hipEvent_t computed[SETS] = {};        // end of a set's last kernels
     void* dbuf[SETS][SLOTS] = {};          // device staging
     size_t dcap[SETS][SLOTS] = {};
     void* hbuf[SETS][SLOTS] = {};          // pinned host staging (hipHostMalloc)
@@ -125,7 +127,11 @@ struct ThreadState {
         }
         if (device < 0) {
             for (int l = 0; l < LANES; l++) C25519_TRY(hipStreamCreateWithFlags(&stream[l], hipStreamNonBlocking));
-            for (int l = 0; l < SETS; l++) C25519_TRY(hipEventCreateWithFlags(&done[l], hipEventDisableTiming));
+            for (int l = 0; l < SETS; l++) {
+                C25519_TRY(hipEventCreateWithFlags(&done[l], hipEventDisableTiming));
+                C25519_TRY(hipEventCreateWithFlags(&uploaded[l], hipEventDisableTiming));
+                C25519_TRY(hipEventCreateWithFlags(&computed[l], hipEventDisableTiming));
+            }
             device = dev;
         }
         return 0;
@@ -193,8 +199,10 @@ struct ThreadState {
                 if (hbuf[l][i]) { memset(hbuf[l][i], 0, hcap[l][i]); (void)hipHostFree(hbuf[l][i]); }
                 dbuf[l][i] = hbuf[l][i] = nullptr; dcap[l][i] = hcap[l][i] = 0;
             }
-            if (done[l]) (void)hipEventDestroy(done[l]);
-            done[l] = nullptr;
+            for (hipEvent_t* e : { &done[l], &uploaded[l], &computed[l] }) {
+                if (*e) (void)hipEventDestroy(*e);
+                *e = nullptr;
+            }
         }
         for (int l = 0; l < LANES; l++) {
             free_slab(lane_work[l]);

@@ -763,14 +763,16 @@ int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t 
 }
 
 // ---- host-pointer pipeline used by the *_batch entry points -------------------------------------------------------
-// A call is cut into pieces; piece c uses buffer set c % SETS (pinned host + device staging) and stream c % LANES,
-// and three roles work on different pieces at the same time:
-//     stage-in  : helper threads (2; C25519_AMD_STAGERS) copy the caller's pageable arrays into a set's pinned buffers
-//     submit    : the calling thread enqueues H2D copies, the *_dev kernels and D2H copies into pinned buffers, all
-//                 asynchronous on the piece's stream (pinned memory: hipMemcpyAsync is a real DMA, not a staged copy)
-//     stage-out : a helper thread (C25519_AMD_DRAINERS) waits for the set's event and copies the results out
+// A call is cut into pieces; piece c uses buffer set c % SETS (pinned host + device staging), and these roles work on
+// different pieces at the same time:
+//     stage-in  : helper threads (4, or 2 on a small host; C25519_AMD_STAGERS) copy the caller's pageable arrays into a set's pinned buffers
+//     submit    : the calling thread enqueues the piece: upload on the upload stream, the *_dev kernels on one of two
+//                 kernel streams, download on the download stream, chained by events (pinned memory: hipMemcpyAsync is
+//                 a real DMA).  With copies and kernels on the same stream, piece c+4's upload queued behind piece c's
+//                 kernels and the device idled between rounds of four.
+//     stage-out : helper threads (2, or 1; C25519_AMD_DRAINERS) wait for the set's event and copies the results out
 // so both CPU copies and both PCIe directions ride under the kernels of the neighbouring pieces.  Pieces are n/8 for
-// big batches: the chip needs ~2^19 lanes in flight to run at full rate, and a piece cannot finish faster than one
+// big batches: two of them (2^18 lanes) fill every kernel's occupancy, and a piece cannot finish faster than one
 // ladder's latency (~1.2 ms), so fewer, larger pieces in flight beat many small ones.  Eight buffer sets let a 2^20
 // call stage every piece in without waiting for an earlier one to leave; four streams because the runtime drives four
 // hardware queues (timelines and the rejected shapes: profiles/r02_hostapi_trace.txt, rates: profiles/r02_hostapi.txt).
@@ -837,24 +839,36 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
             if (arr[a].in && !direct[a] && (r1 - r0) * arr[a].elem)
                 memcpy((char*)t.hbuf[l][a] + r0 * arr[a].elem, (const char*)arr[a].in + (lo + r0) * arr[a].elem, (r1 - r0) * arr[a].elem);
     };
-    auto submit = [&](size_t c) -> int {
+    // one piece: upload on the upload stream, kernels on one of the two kernel streams, download on the download
+    // stream, chained by events -- so the upload of a later piece never queues behind an earlier piece's kernels, and
+    // two pieces' kernels (2^18 lanes: full occupancy for every pass) are in flight while others move over PCIe
+    auto submit = [&](size_t c, bool one_stream) -> int {
         size_t lo, cnt;
         span(c, lo, cnt);
         const int l = (int)(c % sets);
-        hipStream_t st = t.stream[c % ThreadState::LANES];
+        hipStream_t kern = t.stream[c & 1];
+        hipStream_t up = one_stream ? kern : t.stream[2], down = one_stream ? kern : t.stream[3];
         void* dptr[ThreadState::SLOTS] = {};
         for (int a = 0; a < na; a++) {
             dptr[a] = t.dbuf[l][a];
             if (arr[a].in && cnt * arr[a].elem)
                 C25519_TRY(hipMemcpyAsync(dptr[a], direct[a] ? (const char*)arr[a].in + lo * arr[a].elem : (const char*)t.hbuf[l][a],
-                                          cnt * arr[a].elem, hipMemcpyHostToDevice, st));
+                                          cnt * arr[a].elem, hipMemcpyHostToDevice, up));
         }
-        C25519_RC(launch(dptr, cnt, lo, st));
+        if (!one_stream) {
+            C25519_TRY(hipEventRecord(t.uploaded[l], up));
+            C25519_TRY(hipStreamWaitEvent(kern, t.uploaded[l], 0));
+        }
+        C25519_RC(launch(dptr, cnt, lo, kern));
+        if (!one_stream) {
+            C25519_TRY(hipEventRecord(t.computed[l], kern));
+            C25519_TRY(hipStreamWaitEvent(down, t.computed[l], 0));
+        }
         for (int a = 0; a < na; a++)
             if (arr[a].out && cnt * arr[a].elem)
                 C25519_TRY(hipMemcpyAsync(direct[a] ? (char*)arr[a].out + lo * arr[a].elem : (char*)t.hbuf[l][a], dptr[a],
-                                          cnt * arr[a].elem, hipMemcpyDeviceToHost, st));
-        C25519_TRY(hipEventRecord(t.done[l], st));
+                                          cnt * arr[a].elem, hipMemcpyDeviceToHost, down));
+        C25519_TRY(hipEventRecord(t.done[l], down));
         return 0;
     };
     auto drain = [&](size_t c) -> int {
@@ -870,7 +884,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     auto sequential = [&]() -> int {                      // no helper threads: one piece after the other
         for (size_t c = 0; c < nchunks; c++) {
             stage_in(c, 0, 1);
-            C25519_RC(submit(c));
+            C25519_RC(submit(c, true));
             C25519_RC(drain(c));
         }
         return 0;
@@ -882,8 +896,11 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     std::vector<char> staged(nchunks, 0), drained(nchunks, 0);
     size_t submitted = 0;
     int failed = 0;                                       // first error of any role; everybody stops
-    static const int STAGERS = env_count("C25519_AMD_STAGERS", 2, MAX_STAGERS);
-    static const int DRAINERS = env_count("C25519_AMD_DRAINERS", 1, MAX_DRAINERS);
+    // helper threads: 4 + 2 on a machine with cores to spare (sign moves 160 B per 1.8 ns of kernel time: one copier
+    // per direction cannot keep up), 2 + 1 on a small one
+    static const bool roomy = std::thread::hardware_concurrency() >= 16;
+    static const int STAGERS = env_count("C25519_AMD_STAGERS", roomy ? 4 : 2, MAX_STAGERS);
+    static const int DRAINERS = env_count("C25519_AMD_DRAINERS", roomy ? 2 : 1, MAX_DRAINERS);
     std::thread helpers[MAX_STAGERS + MAX_DRAINERS];
     int started = 0;
     try {
@@ -930,7 +947,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
             cv.wait(lk, [&] { return failed || staged[c] == STAGERS; });
             if (failed) break;
         }
-        const int rc = submit(c);
+        const int rc = submit(c, false);
         {
             std::lock_guard<std::mutex> lk(mu);
             if (rc && !failed) failed = rc;
