@@ -73,14 +73,16 @@ def latest_profile(pattern):
 
 
 def measured_mad_peak():
-    """lane-MAC/s of v_mad_u64_u32 in its ACCUMULATING form (d = a*b + d, what a multi-precision column is made of),
-    measured by tools/ubench/valu_rates on MI355X at 8 waves per SIMD (committed summary).  The same file also has the
-    non-accumulating forms (zero addend, SGPR factor: ~9 % faster issue), which no column chain can use."""
+    """lane-MAC/s of v_mad_u64_u32 in its ACCUMULATING form (d = a*b + d, what a multi-precision column is made of) on
+    MI355X at 8 waves per SIMD: tools/ubench/mad_peak -- a whole-asm loop of 128 MADs per trip over eight independent
+    chains (committed summary).  It is the half-rate class' ~37.5 T.  The compiler-generated 16-per-trip loops of
+    tools/ubench/valu_rates, which rounds 1 and early 2 divided by, read 28-32 T: loop overhead, fetch-line placement
+    of the loop top and s_nop padding between asm statements, not the instruction (profiles/README.md)."""
     try:
-        path = latest_profile("r[0-9][0-9]_valu_rates.json")
+        path = latest_profile("r[0-9][0-9]_mad_peak.json")
         with open(path) as f:
             rates = json.load(f)["rates"]
-        return max(v for k, v in rates.items() if k.startswith("v_mad_u64_u32@")), os.path.basename(path)
+        return rates["v_mad_u64_u32"], os.path.basename(path)
     except Exception:
         return None, None
 

@@ -4,10 +4,11 @@
 // these primitives, so the CPU unit tests can run that same source against a C model of them
 // (tests/host_emul/valu_model.h).  This header is the only one with inline assembly.
 //
-// Measured issue classes on MI355X (tools/ubench/valu_rates.hip, profiles/r02_valu_rates.txt):
-//   v_mad_u64_u32                      one per ~4.3 cycles per wave   (32x32+64 -> 64, carry-out to an SGPR pair)
-//   v_lshrrev_b64 / v_mul_lo_u32 / ... one per ~4 cycles   ("half-rate" class: shifts, 64-bit, VOP3 integer)
-//   v_add_u32 / v_and_b32 / v_sub_u32  one per ~2 cycles   ("full-rate" class)
+// Measured issue classes on MI355X at 8 waves per SIMD (tools/ubench/mad_peak.hip, profiles/r02_mad_peak.txt):
+//   v_mad_u64_u32                      one per 4.0 cycles per SIMD: plain half rate (32x32+64 -> 64, carry-out to an
+//                                      SGPR pair); 4.4-4.5 when every MAD waits for the previous one, as in a column
+//   v_lshrrev_b64 / v_mul_lo_u32 / ... one per 4.0 cycles   ("half-rate" class: shifts, 64-bit, every VOP3 integer op)
+//   v_add_u32 / v_and_b32 / v_sub_u32  one per 2.1-2.3 cycles   ("full-rate" class, VOP2 encodings)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -25,6 +25,7 @@ if has bench; then
 fi
 if has ubench; then
   timeout 300 tools/ubench/valu_rates $OUT/valu_rates.json > $OUT/valu_rates.txt 2>&1; echo "ubench rc=$?"
+  timeout 300 tools/ubench/mad_peak $OUT/mad_peak.json > $OUT/mad_peak.txt 2>&1; echo "mad_peak rc=$?"; cat $OUT/mad_peak.txt
   [ -x tools/ubench/field_ab ] && { timeout 300 tools/ubench/field_ab > $OUT/field_ab.txt 2>&1; echo "field_ab rc=$?"; cat $OUT/field_ab.txt; }
 fi
 if has ab && ls build_ab/*.so >/dev/null 2>&1; then

@@ -1,0 +1,189 @@
+// tools/ubench/mad_peak.hip -- issue rates from WHOLE-ASM loops (one asm statement holds the loop, so the compiler can
+// neither pad instruction boundaries with s_nop nor move the loop top), 8 independent chains in fixed registers:
+//   * how much of a short loop's v_mad_u64_u32 rate is the instruction and how much is the loop: 16 / 64 / 128 / 256
+//     MADs per trip, loop top on a 64-byte line or pushed off it
+//   * the long-trip (128 per trip) rate of every instruction class the field arithmetic uses, and of one product
+//     column as the kernels issue it (10 dependent MADs + mask + 64-bit shift)
+// The long-trip accumulating-MAD figure is the denominator of bench.py's roofline.valu (JSON: argv[1]).
+// Build: hipcc --offload-arch=gfx950 -O3 mad_peak.hip -o mad_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+// eight instructions, one per chain; chain c lives in v[40+2c : 41+2c], factors in v38, v39
+#define I8(op, tail) \
+    op " v[40:41]" tail(40) "\n\t" op " v[42:43]" tail(42) "\n\t" op " v[44:45]" tail(44) "\n\t" op " v[46:47]" tail(46) "\n\t" \
+    op " v[48:49]" tail(48) "\n\t" op " v[50:51]" tail(50) "\n\t" op " v[52:53]" tail(52) "\n\t" op " v[54:55]" tail(54) "\n\t"
+#define S8(op, tail) \
+    op " v40" tail(40) "\n\t" op " v42" tail(42) "\n\t" op " v44" tail(44) "\n\t" op " v46" tail(46) "\n\t" \
+    op " v48" tail(48) "\n\t" op " v50" tail(50) "\n\t" op " v52" tail(52) "\n\t" op " v54" tail(54) "\n\t"
+#define STR(x) #x
+#define T_MADACC(r) ", vcc, v38, v39, v[" STR(r) ":" "%=" "]"
+// (register pair text cannot be computed in the preprocessor: spell the eight out)
+#define MAD8 \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v38, v39, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[44:45], vcc, v38, v39, v[44:45]\n\tv_mad_u64_u32 v[46:47], vcc, v38, v39, v[46:47]\n\t" \
+    "v_mad_u64_u32 v[48:49], vcc, v38, v39, v[48:49]\n\tv_mad_u64_u32 v[50:51], vcc, v38, v39, v[50:51]\n\t" \
+    "v_mad_u64_u32 v[52:53], vcc, v38, v39, v[52:53]\n\tv_mad_u64_u32 v[54:55], vcc, v38, v39, v[54:55]\n\t"
+#define MADZ8 \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, 0\n\tv_mad_u64_u32 v[42:43], vcc, v38, v39, 0\n\t" \
+    "v_mad_u64_u32 v[44:45], vcc, v38, v39, 0\n\tv_mad_u64_u32 v[46:47], vcc, v38, v39, 0\n\t" \
+    "v_mad_u64_u32 v[48:49], vcc, v38, v39, 0\n\tv_mad_u64_u32 v[50:51], vcc, v38, v39, 0\n\t" \
+    "v_mad_u64_u32 v[52:53], vcc, v38, v39, 0\n\tv_mad_u64_u32 v[54:55], vcc, v38, v39, 0\n\t"
+// one dependent chain of eight: what a product column is
+#define MADDEP8 \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\t"
+#define MUL8 \
+    "v_mul_lo_u32 v40, v40, v38\n\tv_mul_lo_u32 v42, v42, v38\n\tv_mul_lo_u32 v44, v44, v38\n\tv_mul_lo_u32 v46, v46, v38\n\t" \
+    "v_mul_lo_u32 v48, v48, v38\n\tv_mul_lo_u32 v50, v50, v38\n\tv_mul_lo_u32 v52, v52, v38\n\tv_mul_lo_u32 v54, v54, v38\n\t"
+#define ADD8 \
+    "v_add_u32 v40, v40, v38\n\tv_add_u32 v42, v42, v38\n\tv_add_u32 v44, v44, v38\n\tv_add_u32 v46, v46, v38\n\t" \
+    "v_add_u32 v48, v48, v38\n\tv_add_u32 v50, v50, v38\n\tv_add_u32 v52, v52, v38\n\tv_add_u32 v54, v54, v38\n\t"
+#define ADDS8 /* VOP3 encoding: an SGPR second operand */ \
+    "v_add_u32 v40, v40, s21\n\tv_add_u32 v42, v42, s21\n\tv_add_u32 v44, v44, s21\n\tv_add_u32 v46, v46, s21\n\t" \
+    "v_add_u32 v48, v48, s21\n\tv_add_u32 v50, v50, s21\n\tv_add_u32 v52, v52, s21\n\tv_add_u32 v54, v54, s21\n\t"
+#define AND8 \
+    "v_and_b32 v40, v40, v38\n\tv_and_b32 v42, v42, v38\n\tv_and_b32 v44, v44, v38\n\tv_and_b32 v46, v46, v38\n\t" \
+    "v_and_b32 v48, v48, v38\n\tv_and_b32 v50, v50, v38\n\tv_and_b32 v52, v52, v38\n\tv_and_b32 v54, v54, v38\n\t"
+#define ANDL8 /* 32-bit literal operand: an 8-byte VOP2 */ \
+    "v_and_b32 v40, 0x3ffffff, v40\n\tv_and_b32 v42, 0x3ffffff, v42\n\tv_and_b32 v44, 0x3ffffff, v44\n\tv_and_b32 v46, 0x3ffffff, v46\n\t" \
+    "v_and_b32 v48, 0x3ffffff, v48\n\tv_and_b32 v50, 0x3ffffff, v50\n\tv_and_b32 v52, 0x3ffffff, v52\n\tv_and_b32 v54, 0x3ffffff, v54\n\t"
+#define SHR64_8 \
+    "v_lshrrev_b64 v[40:41], 1, v[40:41]\n\tv_lshrrev_b64 v[42:43], 1, v[42:43]\n\tv_lshrrev_b64 v[44:45], 1, v[44:45]\n\tv_lshrrev_b64 v[46:47], 1, v[46:47]\n\t" \
+    "v_lshrrev_b64 v[48:49], 1, v[48:49]\n\tv_lshrrev_b64 v[50:51], 1, v[50:51]\n\tv_lshrrev_b64 v[52:53], 1, v[52:53]\n\tv_lshrrev_b64 v[54:55], 1, v[54:55]\n\t"
+#define CNDE32_8 \
+    "v_cndmask_b32 v40, v40, v38, vcc\n\tv_cndmask_b32 v42, v42, v38, vcc\n\tv_cndmask_b32 v44, v44, v38, vcc\n\tv_cndmask_b32 v46, v46, v38, vcc\n\t" \
+    "v_cndmask_b32 v48, v48, v38, vcc\n\tv_cndmask_b32 v50, v50, v38, vcc\n\tv_cndmask_b32 v52, v52, v38, vcc\n\tv_cndmask_b32 v54, v54, v38, vcc\n\t"
+// the shipped multiplication's instruction stream: ten product columns one after the other, each 10 dependent MADs, the
+// limb mask and the 64-bit carry shift that feeds the next column (120 instructions); two of them per trip
+#define COL(l) \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\t" \
+    "v_and_b32 " l ", 0x3ffffff, v40\n\tv_lshrrev_b64 v[40:41], 26, v[40:41]\n\t"
+#define FIELD_MUL COL("v58") COL("v59") COL("v60") COL("v61") COL("v62") COL("v63") COL("v64") COL("v65") COL("v66") COL("v67")
+#define X2(B) B B
+#define X8(B) X2(X2(X2(B)))
+#define X16(B) X2(X8(B))
+#define X32(B) X2(X16(B))
+
+#define PAD0 ""
+#define PAD2 "s_nop 0\n\ts_nop 0\n\t"
+#define PAD6 PAD2 PAD2 PAD2
+#define PAD10 PAD6 PAD2 PAD2
+#define PAD14 PAD10 PAD2 PAD2
+
+#define LOOP(PADS, B) \
+    asm volatile( \
+        "v_mov_b32 v38, %1\n\tv_mov_b32 v39, %2\n\tv_mov_b32 v56, 1.0\n\tv_mov_b32 v57, 1.0\n\t" \
+        "v_mov_b32 v40, %1\n\tv_mov_b32 v41, 0\n\tv_mov_b32 v42, %2\n\tv_mov_b32 v43, 0\n\tv_mov_b32 v44, %1\n\tv_mov_b32 v45, 0\n\t" \
+        "v_mov_b32 v46, %2\n\tv_mov_b32 v47, 0\n\tv_mov_b32 v48, %1\n\tv_mov_b32 v49, 0\n\tv_mov_b32 v50, %2\n\tv_mov_b32 v51, 0\n\t" \
+        "v_mov_b32 v52, %1\n\tv_mov_b32 v53, 0\n\tv_mov_b32 v54, %2\n\tv_mov_b32 v55, 0\n\t" \
+        "v_mov_b32 v58, %1\n\tv_mov_b32 v59, 0\n\tv_mov_b32 v60, %2\n\tv_mov_b32 v61, 0\n\tv_mov_b32 v62, %1\n\tv_mov_b32 v63, 0\n\t" \
+        "v_mov_b32 v64, %2\n\tv_mov_b32 v65, 0\n\tv_mov_b32 v66, %1\n\tv_mov_b32 v67, 0\n\tv_mov_b32 v68, %2\n\tv_mov_b32 v69, 0\n\t" \
+        "v_mov_b32 v70, %1\n\tv_mov_b32 v71, 0\n\tv_mov_b32 v72, %2\n\tv_mov_b32 v73, 0\n\t" \
+        "s_mov_b32 s20, %3\n\ts_mov_b32 s21, 7\n\t" \
+        "s_branch 2f\n\t.p2align 6\n\t2:\n\t" PADS \
+        "1:\n\t" B \
+        "s_sub_u32 s20, s20, 1\n\ts_cmp_lg_u32 s20, 0\n\ts_cbranch_scc1 1b\n\t" \
+        "v_xor_b32 %0, v40, v42\n\tv_xor_b32 %0, %0, v44\n\tv_xor_b32 %0, %0, v46\n\tv_xor_b32 %0, %0, v48\n\t" \
+        "v_xor_b32 %0, %0, v50\n\tv_xor_b32 %0, %0, v52\n\tv_xor_b32 %0, %0, v54" \
+        : "=v"(r) : "v"(a), "v"(b), "s"(trips) \
+        : "vcc", "scc", "s20", "s21", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", \
+          "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
+          "v68", "v69", "v70", "v71", "v72", "v73")
+
+template <int ID>
+__global__ void __launch_bounds__(256) k_loop(unsigned* out, unsigned seed, int trips)
+{
+    unsigned a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u, r = 0;
+    if constexpr (ID == 0) LOOP(PAD0, X2(MAD8));
+    if constexpr (ID == 1) LOOP(PAD2, X2(MAD8));
+    if constexpr (ID == 2) LOOP(PAD6, X2(MAD8));
+    if constexpr (ID == 3) LOOP(PAD10, X2(MAD8));
+    if constexpr (ID == 4) LOOP(PAD14, X2(MAD8));
+    if constexpr (ID == 5) LOOP(PAD0, X8(MAD8));
+    if constexpr (ID == 6) LOOP(PAD0, X16(MAD8));
+    if constexpr (ID == 7) LOOP(PAD0, X32(MAD8));
+    if constexpr (ID == 8) LOOP(PAD0, X16(MADZ8));
+    if constexpr (ID == 9) LOOP(PAD0, X16(MADDEP8));
+    if constexpr (ID == 10) LOOP(PAD0, X16(MUL8));
+    if constexpr (ID == 11) LOOP(PAD0, X16(SHR64_8));
+    if constexpr (ID == 12) LOOP(PAD0, X16(ADD8));
+    if constexpr (ID == 13) LOOP(PAD0, X16(ADDS8));
+    if constexpr (ID == 14) LOOP(PAD0, X16(AND8));
+    if constexpr (ID == 15) LOOP(PAD0, X16(ANDL8));
+    if constexpr (ID == 16) LOOP(PAD0, X16(CNDE32_8));
+    if constexpr (ID == 18) LOOP(PAD0, X2(FIELD_MUL));
+    if (r == 0x12345678u) out[0] = r;
+}
+
+struct Row { int id; int per_trip; double scale; const char* key; const char* name; };
+static const Row rows[] = {
+    { 0, 16, 1, "mad_acc_16_aligned", "v_mad_u64_u32 acc,  16 per trip, loop top on a 64 B line" },
+    { 1, 16, 1, "mad_acc_16_off8", "v_mad_u64_u32 acc,  16 per trip, loop top + 8 B" },
+    { 2, 16, 1, "mad_acc_16_off24", "v_mad_u64_u32 acc,  16 per trip, loop top + 24 B" },
+    { 3, 16, 1, "mad_acc_16_off40", "v_mad_u64_u32 acc,  16 per trip, loop top + 40 B" },
+    { 4, 16, 1, "mad_acc_16_off56", "v_mad_u64_u32 acc,  16 per trip, loop top + 56 B" },
+    { 5, 64, 1, "mad_acc_64", "v_mad_u64_u32 acc,  64 per trip" },
+    { 6, 128, 1, "v_mad_u64_u32", "v_mad_u64_u32 acc, 128 per trip   <- roofline.valu peak" },
+    { 7, 256, 1, "mad_acc_256", "v_mad_u64_u32 acc, 256 per trip" },
+    { 8, 128, 1, "mad_zero_addend", "v_mad_u64_u32 zero addend, 128 per trip" },
+    { 9, 128, 1, "mad_one_chain", "v_mad_u64_u32 acc, ONE dependent chain, 128 per trip" },
+    { 10, 128, 1, "v_mul_lo_u32", "v_mul_lo_u32, 128 per trip" },
+    { 11, 128, 1, "v_lshrrev_b64", "v_lshrrev_b64, 128 per trip" },
+    { 12, 128, 1, "v_add_u32", "v_add_u32 (VOP2), 128 per trip" },
+    { 13, 128, 1, "v_add_u32_sgpr", "v_add_u32 with an SGPR operand (VOP3), 128 per trip" },
+    { 14, 128, 1, "v_and_b32", "v_and_b32 (VOP2), 128 per trip" },
+    { 15, 128, 1, "v_and_b32_literal", "v_and_b32 with a 32-bit literal (8-byte VOP2), 128 per trip" },
+    { 16, 128, 1, "v_cndmask_b32_vcc_run", "v_cndmask_b32 (VOP2, vcc), back to back, 128 per trip" },
+    { 18, 240, 1, "field_mul_stream", "the shipped field multiplication's stream (10 x [10 dependent MADs, mask, shift]), 240 per trip" },
+};
+
+template <int ID> static void launch(int blocks, unsigned* d, int trips, hipStream_t s) { k_loop<ID><<<blocks, 256, 0, s>>>(d, 1, trips); }
+static void dispatch(int id, int blocks, unsigned* d, int trips, hipStream_t s)
+{
+    switch (id) {
+#define C(k) case k: launch<k>(blocks, d, trips, s); break;
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(18)
+#undef C
+    }
+}
+
+int main(int argc, char** argv)
+{
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    unsigned* d; CHECK(hipMalloc(&d, 64));
+    hipStream_t s; CHECK(hipStreamCreate(&s));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    FILE* jf = argc > 1 ? fopen(argv[1], "w") : nullptr;
+    if (jf) fprintf(jf, "{\"device_cus\": %d, \"waves_per_simd\": 8, \"unit\": \"lane-op/s\", \"rates\": {\n", cus);
+    printf("device %s, %d CUs; 8 waves per SIMD, ~65536 instructions per wave, best of 5\n", prop.name, cus);
+    bool first = true;
+    for (const Row& r : rows) {
+        const int trips = 65536 / r.per_trip;
+        const int blocks = cus * 8;
+        float best = 1e30f;
+        for (int rep = 0; rep < 6; rep++) {
+            CHECK(hipEventRecord(e0, s));
+            dispatch(r.id, blocks, d, trips, s);
+            CHECK(hipEventRecord(e1, s));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep && ms < best) best = ms;
+        }
+        const double rate = r.scale * (double)blocks * 4 * (double)trips * r.per_trip * 64 / (best * 1e-3);
+        printf("%-78s %8.3f ms  %7.2f T lane-op/s\n", r.name, best, rate / 1e12);
+        if (jf) { fprintf(jf, "%s  \"%s\": %.4e", first ? "" : ",\n", r.key, rate); first = false; }
+    }
+    if (jf) { fprintf(jf, "\n}}\n"); fclose(jf); }
+    return 0;
+}

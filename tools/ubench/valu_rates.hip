@@ -11,8 +11,13 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-constexpr int ITERS = 4096;
-constexpr int UNROLL = 16;      // instructions of the tested kind per loop iteration
+// A loop trip issues INNER x UNROLL instructions of the tested kind.  The trip has to be LONG: with 16 per trip the loop
+// overhead (and where the loop top falls in a 64-byte fetch line: tools/ubench/mad_peak.hip) costs 10-25 % -- that is
+// how round 1 and the first half of round 2 came to quote 28-32 T lane-op/s for v_mad_u64_u32 and 57-67 T for the
+// full-rate class, when the instructions themselves run at 37.7 T (plain half rate) and ~75 T.
+constexpr int ITERS = 512;
+constexpr int INNER = 8;
+constexpr int UNROLL = 16;      // instructions of the tested kind per inner repetition
 
 // Each body issues UNROLL instructions on 8 independent dependency chains (2 per chain).
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
@@ -32,6 +37,8 @@ __global__ void __launch_bounds__(256) k_rate(unsigned* out, unsigned seed, unsi
     double dm = 1.0000001, da = 1e-9;
     float f0 = a, f1 = b, f2 = 1, f3 = 2, f4 = 3, f5 = 4, f6 = 5, f7 = 6, fm = 1.0001f, fa = 1e-5f;
     for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+      for (int u = 0; u < INNER; ++u) {
         if constexpr (KIND == 0) {          // v_mad_u64_u32, accumulate chain
 #define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q##i) : "v"(a), "v"(b) : "vcc");
             REP8(X) REP8(X)
@@ -277,6 +284,7 @@ __global__ void __launch_bounds__(256) k_rate(unsigned* out, unsigned seed, unsi
             REP8(X) REP8(X)
 #undef X
         }
+      }
     }
     unsigned acc = t0 ^ t1 ^ t2 ^ t3 ^ t4 ^ t5 ^ t6 ^ t7 ^ r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
     unsigned long long qa = q0 ^ q1 ^ q2 ^ q3 ^ q4 ^ q5 ^ q6 ^ q7;
@@ -356,11 +364,11 @@ int main(int argc, char** argv)
             CHECK(hipMemcpy(&ticks, g_ticks, 8, hipMemcpyDeviceToHost));
             const int per_iter = k.id == 36 ? 16 : UNROLL;                    // instructions per loop iteration
             const double scale = k.id == 39 ? 2.0 : 1.0;                      // packed: two lane-ops per lane
-            double insts = (double)blocks * 4 /*waves*/ * ITERS * per_iter;   // wave-instructions
+            double insts = (double)blocks * 4 /*waves*/ * ITERS * INNER * per_iter;   // wave-instructions
             double lane_ops_per_s = scale * insts * 64 / (best * 1e-3);
             // wave 0 is the oldest wave of its SIMD and keeps issue priority: `ticks` is how long ITS loop took,
             // i.e. the single-wave issue interval (meaningful at wps = 1, where ticks / time is also the clock)
-            double clk_per_inst = (double)ticks / ((double)ITERS * per_iter);
+            double clk_per_inst = (double)ticks / ((double)ITERS * INNER * per_iter);
             double eff_ghz = (double)ticks / (best * 1e-3) / 1e9;
             printf("wps=%d %-42s %8.3f ms  %8.2f Tlane-op/s  %6.2f cycles/instr for the oldest wave  (ticks/time %.2f GHz)\n", wps,
                    k.name, best, lane_ops_per_s / 1e12, clk_per_inst, eff_ghz);
