@@ -2,9 +2,11 @@
 symbol the headers in include/ declare, fail loudly (error code + message, never a CPU result) when
 asked to compute without a device, and the product package must not touch the oracle."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -107,3 +109,17 @@ def test_bench_self_launch_fails_only_for_lack_of_devices():
     else:
         assert p.returncode != 0
         assert "GPU(s)" in p.stderr and "launch with torch.distributed.run" not in p.stderr
+
+
+def test_roofline_denominator_is_the_half_rate_mad_peak():
+    """bench.py prices the kernels against the accumulating v_mad_u64_u32 rate of tools/ubench/mad_peak (whole-asm loop,
+    128 per trip) as committed under profiles/: plain half rate, 35-40 T lane-MAC/s on MI355X -- not the 28-32 T of a
+    16-per-trip loop that earlier rounds divided by.  Guards the denominator and its source."""
+    sys.path.insert(0, ROOT)
+    import bench
+    peak, src = bench.measured_mad_peak()
+    assert src and src.endswith("_mad_peak.json"), src
+    assert 35e12 < peak < 40e12, peak
+    rates = json.load(open(os.path.join(ROOT, "profiles", src)))["rates"]
+    assert rates["mad_acc_16_aligned"] < 0.85 * peak, "the short-loop artefact is part of the record"
+    assert abs(rates["v_mul_lo_u32"] / peak - 1) < 0.06, "MAD and the other half-rate instructions issue at the same rate"
