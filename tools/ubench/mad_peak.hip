@@ -80,7 +80,8 @@
 #define PAD10 PAD6 PAD2 PAD2
 #define PAD14 PAD10 PAD2 PAD2
 
-#define LOOP(PADS, B) \
+#define LOOP(PADS, B) LOOPI("", PADS, B)
+#define LOOPI(INIT, PADS, B) \
     asm volatile( \
         "v_mov_b32 v38, %1\n\tv_mov_b32 v39, %2\n\tv_mov_b32 v56, 1.0\n\tv_mov_b32 v57, 1.0\n\t" \
         "v_mov_b32 v40, %1\n\tv_mov_b32 v41, 0\n\tv_mov_b32 v42, %2\n\tv_mov_b32 v43, 0\n\tv_mov_b32 v44, %1\n\tv_mov_b32 v45, 0\n\t" \
@@ -89,7 +90,7 @@
         "v_mov_b32 v58, %1\n\tv_mov_b32 v59, 0\n\tv_mov_b32 v60, %2\n\tv_mov_b32 v61, 0\n\tv_mov_b32 v62, %1\n\tv_mov_b32 v63, 0\n\t" \
         "v_mov_b32 v64, %2\n\tv_mov_b32 v65, 0\n\tv_mov_b32 v66, %1\n\tv_mov_b32 v67, 0\n\tv_mov_b32 v68, %2\n\tv_mov_b32 v69, 0\n\t" \
         "v_mov_b32 v70, %1\n\tv_mov_b32 v71, 0\n\tv_mov_b32 v72, %2\n\tv_mov_b32 v73, 0\n\t" \
-        "s_mov_b32 s20, %3\n\ts_mov_b32 s21, 7\n\t" \
+        INIT "s_mov_b32 s20, %3\n\ts_mov_b32 s21, 7\n\t" \
         "s_branch 2f\n\t.p2align 6\n\t2:\n\t" PADS \
         "1:\n\t" B \
         "s_sub_u32 s20, s20, 1\n\ts_cmp_lg_u32 s20, 0\n\ts_cbranch_scc1 1b\n\t" \
