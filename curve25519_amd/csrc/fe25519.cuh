@@ -129,14 +129,15 @@ C25519_DEV void fe_mul_chained(fe& r, const fe& a, const fe& b)
             x[i] = odd2 ? a2[i] : a.v[i];
             y[i] = wrap ? b19[j] : b.v[j];
         }
-        acc = mad_chain10(acc, x, y);
+        acc = k == 0 ? mad_chain10_from_zero(x, y) : mad_chain10(acc, x, y);
         l[k] = (u32)acc & fe_mask(k);
         acc >>= fe_w(k);
     }
     fe_finish_chain(r, l, acc);
 }
 
-template <bool SCALE2, typename Extra>
+// PLAIN: extra(k) is zero for every k (a bare square), so column 0 starts from nothing
+template <bool SCALE2, bool PLAIN = false, typename Extra>
 C25519_DEV void fe_sqr_chained(fe& r, const fe& a, Extra extra)
 {
     u32 f2[10], f19[10], f38[10], l[10];
@@ -169,11 +170,12 @@ C25519_DEV void fe_sqr_chained(fe& r, const fe& a, Extra extra)
             }
             cnt++;
         }
+        const bool from_zero = SCALE2 || (PLAIN && k == 0);
         if (k & 1) {                                      // odd columns have 5 unordered pairs, even ones 6
             const u32 x5[5] = { x[0], x[1], x[2], x[3], x[4] }, y5[5] = { y[0], y[1], y[2], y[3], y[4] };
-            acc = mad_chain5(acc, x5, y5);
+            acc = from_zero ? mad_chain5_from_zero(x5, y5) : mad_chain5(acc, x5, y5);
         } else {
-            acc = mad_chain6(acc, x, y);
+            acc = from_zero ? mad_chain6_from_zero(x, y) : mad_chain6(acc, x, y);
         }
         if (SCALE2) acc = 2 * acc + carry + extra(k);
         l[k] = (u32)acc & fe_mask(k);
@@ -191,7 +193,7 @@ C25519_DEV void fe_mul(fe& r, const fe& a, const fe& b)
 // r = a^2.   beta_a <= 3.3; r may alias a.   (ecp_SqrReduce)
 C25519_DEV void fe_sqr(fe& r, const fe& a)
 {
-    fe_sqr_chained<false>(r, a, [](int) -> u64 { return 0; });
+    fe_sqr_chained<false, true>(r, a, [](int) -> u64 { return 0; });
 }
 
 // r = a^2 - m with the subtraction folded into the carry chain (result reduced).

@@ -50,6 +50,59 @@ C25519_DEV u64 mad_chain5(u64 acc, const u32 (&x)[5], const u32 (&y)[5])
     return acc;
 }
 
+// the same chains started from zero: the first MAD takes the inline constant 0 as its addend instead of an accumulator
+// that a v_mov_b64 had to clear (column 0 of every product)
+C25519_DEV u64 mad_chain5_from_zero(const u32 (&x)[5], const u32 (&y)[5])
+{
+    u64 acc, carry_out;
+    asm(
+        "v_mad_u64_u32 %0, %1, %2, %7, 0\n\t"
+        "v_mad_u64_u32 %0, %1, %3, %8, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %4, %9, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %5, %10, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %11, %0"
+        : "=&v"(acc), "=s"(carry_out)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]),
+          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]));
+    return acc;
+}
+
+C25519_DEV u64 mad_chain6_from_zero(const u32 (&x)[6], const u32 (&y)[6])
+{
+    u64 acc, carry_out;
+    asm(
+        "v_mad_u64_u32 %0, %1, %2, %8, 0\n\t"
+        "v_mad_u64_u32 %0, %1, %3, %9, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %4, %10, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %5, %11, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %12, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %7, %13, %0"
+        : "=&v"(acc), "=s"(carry_out)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
+          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]));
+    return acc;
+}
+
+C25519_DEV u64 mad_chain10_from_zero(const u32 (&x)[10], const u32 (&y)[10])
+{
+    u64 acc, carry_out;
+    asm(
+        "v_mad_u64_u32 %0, %1, %2, %12, 0\n\t"
+        "v_mad_u64_u32 %0, %1, %3, %13, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %4, %14, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %5, %15, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %16, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %7, %17, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %8, %18, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %9, %19, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %10, %20, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %11, %21, %0"
+        : "=&v"(acc), "=s"(carry_out)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]),
+          "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8]), "v"(y[9]));
+    return acc;
+}
+
 C25519_DEV u64 mad_chain6(u64 acc, const u32 (&x)[6], const u32 (&y)[6])
 {
     u64 carry_out;

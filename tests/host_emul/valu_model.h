@@ -57,6 +57,10 @@ inline u64 mad_chain6(u64 acc, const u32 (&x)[6], const u32 (&y)[6])
     for (int t = 0; t < 6; t++) acc = mad64(acc, x[t], y[t]);
     return acc;
 }
+inline u64 mad_chain5_from_zero(const u32 (&x)[5], const u32 (&y)[5]) { return mad_chain5(0, x, y); }
+inline u64 mad_chain6_from_zero(const u32 (&x)[6], const u32 (&y)[6]) { return mad_chain6(0, x, y); }
+inline u64 mad_chain10(u64 acc, const u32 (&x)[10], const u32 (&y)[10]);
+inline u64 mad_chain10_from_zero(const u32 (&x)[10], const u32 (&y)[10]) { return mad_chain10(0, x, y); }
 inline u64 mad_chain10(u64 acc, const u32 (&x)[10], const u32 (&y)[10])
 {
     for (int t = 0; t < 10; t++) acc = mad64(acc, x[t], y[t]);
