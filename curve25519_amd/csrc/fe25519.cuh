@@ -76,30 +76,6 @@ C25519_DEV void fe_select(fe& r, u32 mask, const fe& a, const fe& b)
     for (int i = 0; i < 10; i++) r.v[i] = (a.v[i] & mask) | (b.v[i] & ~mask);
 }
 
-// Sequential carry of ten 64-bit column sums into reduced limbs; the carry out of limb 9 re-enters
-// limb 0 times 19 (2^255 = 19 mod p).  Columns may be as large as 2^64-1.
-C25519_DEV void fe_carry64(fe& r, u64 (&h)[10])
-{
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        h[i + 1] += h[i] >> fe_w(i);
-        h[i] &= fe_mask(i);
-    }
-    u64 c = h[9] >> 25;
-    h[9] &= M25;
-    h[0] += c * 19;
-    h[1] += h[0] >> 26;
-    h[0] &= M26;
-#pragma unroll
-    for (int i = 0; i < 10; i++) r.v[i] = (u32)h[i];
-}
-
-// ---- chained-carry products --------------------------------------------------------------------------------
-// v_mad_u64_u32 adds a 64-bit value for free.  If the chain of MADs of column k+1 STARTS from the carry out of
-// column k, the carry propagation costs a 64-bit shift and a mask per limb and no separate 64-bit add (saves
-// 9 v_lshl_add_u64 per product).  mad_chain5/6/10 (valu_gfx950.cuh) are one asm statement per column because
-// the compiler's reassociation otherwise moves the carry back to the end of each chain.
-
 // limbs l[0..9] hold the masked columns, `carry` is what left column 9: fold it back times 19
 C25519_DEV void fe_finish_chain(fe& r, u32 (&l)[10], u64 carry)
 {
@@ -219,19 +195,38 @@ C25519_DEV void fe_sqr_n(fe& r, const fe& a, int n)
 // r = a + 121665 * b   (ecp_WordMulAddReduce with a24, curve25519_dh.c:53,:81); any beta, reduced out
 C25519_DEV void fe_mul121665_add(fe& r, const fe& a, const fe& b)
 {
-    u64 h[10];
+    // one MAD per limb with the previous limb's carry riding in its addend: b*121665 + a < 2^46 for beta < 8, so a
+    // carry is < 2^21 and a.v[i] + carry still fits 32 bits -- no 64-bit carry arithmetic (it was a 64-bit shift and a
+    // 64-bit add per limb)
+    u32 l[10], carry = 0;
 #pragma unroll
-    for (int i = 0; i < 10; i++) h[i] = (u64)b.v[i] * 121665u + a.v[i];
-    fe_carry64(r, h);
+    for (int i = 0; i < 10; i++) {
+        const u64 h = (u64)b.v[i] * 121665u + (u64)(a.v[i] + carry);
+        l[i] = (u32)h & fe_mask(i);
+        carry = (u32)(h >> fe_w(i));
+    }
+    const u32 t = l[0] + 19u * carry;                     // < 2^27
+    l[0] = t & M26;
+    l[1] += t >> 26;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = l[i];
 }
 
 // r = c * a for a small constant c < 2^16 (any beta_a <= 8); reduced out
 C25519_DEV void fe_mul_small(fe& r, const fe& a, u32 c)
 {
-    u64 h[10];
+    u32 l[10], carry = 0;                                 // a*c < 2^45: carries < 2^20, chained like above
 #pragma unroll
-    for (int i = 0; i < 10; i++) h[i] = (u64)a.v[i] * c;
-    fe_carry64(r, h);
+    for (int i = 0; i < 10; i++) {
+        const u64 h = (u64)a.v[i] * c + carry;
+        l[i] = (u32)h & fe_mask(i);
+        carry = (u32)(h >> fe_w(i));
+    }
+    const u32 t = l[0] + 19u * carry;
+    l[0] = t & M26;
+    l[1] += t >> 26;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = l[i];
 }
 
 // one carry pass over 32-bit limbs: brings any beta < 2^6 back to reduced

@@ -103,8 +103,27 @@ def sqr2_add_sub(a, p, m, where="sqr2_add_sub"):
     return carry64(h, where)
 
 
+def chained_small_mul(mulitplicand, c, addend, where):
+    """fe_mul121665_add / fe_mul_small: one MAD per limb, the previous limb's carry added to the 32-bit addend."""
+    l, carry = [0] * 10, 0
+    for i in range(10):
+        t = addend[i] + carry
+        need(t <= U32, f"{where}: addend + carry overflows 32 bits at limb {i}")
+        h = mulitplicand[i] * c + t
+        need(h <= U64, f"{where}: limb {i} overflows 64 bits")
+        carry = h >> W[i]
+        need(carry <= U32, f"{where}: carry out of limb {i} exceeds 32 bits")
+        l[i] = min(h, MASK[i])
+    t = l[0] + 19 * carry
+    need(19 * carry <= U32 and t <= U32, f"{where}: wrap overflows 32 bits")
+    l[1] += t >> 26
+    l[0] = min(t, M26)
+    need(all(x <= U32 for x in l), f"{where}: limb exceeds 32 bits")
+    return l
+
+
 def mul121665_add(a, b, where="mul121665_add"):
-    return carry64([b[i] * 121665 + a[i] for i in range(10)], where)
+    return chained_small_mul(b, 121665, a, where)
 
 
 def add(a, b, where="add"):
@@ -223,6 +242,8 @@ def main():
         nSX = sqr(C, "ladder x3")
         A = sqr(B, "ladder (A-B)^2")
         nSZ = mul(A, X1, "ladder z3")
+        nSZ9 = chained_small_mul(A, 9, [0] * 10, "ladder z3, base point u = 9 (fe_mul_small)")
+        need(all(nSZ9[i] <= R[i] for i in range(10)), "fe_mul_small output not reduced")
         A = sqr(P, "ladder AA")
         B = sqr(M, "ladder BB")
         nDX = mul(A, B, "ladder x4")
