@@ -1031,6 +1031,9 @@ int c25519_amd_device_count(void)
 int c25519_amd_host_register(void* p, size_t bytes)
 {
     if (!p || !bytes) return bad_arg("null pointer or empty range");
+    // page locking works on whole pages: a buffer that shares a page with another allocation would get that neighbour
+    // locked, and unlocked, with it (the runtime aborts on the second unregister) -- so only whole pages are accepted
+    if ((reinterpret_cast<uintptr_t>(p) & 4095u) || (bytes & 4095u)) return bad_arg("host_register: the buffer must start on a 4 KiB page and cover whole pages");
     C25519_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
     return 0;
 }

@@ -63,3 +63,24 @@ def corrupt_for_verify(sig: np.ndarray, msg: np.ndarray):
         else:
             msg[i, pos[i] % msg.shape[1]] ^= bit[i]
     return sig, msg, bad
+
+
+def page_aligned(shape, dtype=np.uint8, like=None) -> np.ndarray:
+    """A zeroed array in pages of its own (an anonymous mmap): what c25519_amd_host_register() wants -- page locking
+    works on whole pages, so the buffer must not share one with anything else.  `like`: initial contents."""
+    import mmap
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape))
+    size = max(1, count * dtype.itemsize)
+    size = (size + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE
+    buf = mmap.mmap(-1, size)
+    arr = np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+    if like is not None:
+        arr[...] = like
+    return arr
+
+
+def locked_bytes(arr: np.ndarray) -> int:
+    """Length to pass to c25519_amd_host_register for an array made by page_aligned(): its whole pages."""
+    import mmap
+    return (arr.nbytes + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE

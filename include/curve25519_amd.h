@@ -43,7 +43,10 @@ void c25519_amd_thread_release(void);
 /* Optional: page-lock a host array the caller is going to pass to *_batch functions again and again (hipHostRegister).
  * A *_batch call recognises page-locked arguments (registered here, or allocated with hipHostMalloc) and lets the DMA
  * engines read / write them directly instead of staging them through its own pinned buffers: no CPU copy at all.
- * Registration costs about a millisecond per 100 MB: worth it for buffers that are reused.  Unregister before free(). */
+ * Registration costs about a millisecond per 100 MB: worth it for buffers that are reused.  Unregister before free().
+ * Page locking works on whole pages, so p must be 4 KiB-aligned and bytes a multiple of 4 KiB (posix_memalign / mmap a
+ * buffer of its own: a heap object that shares a page with a neighbour would lock and unlock the neighbour with it);
+ * anything else is refused. */
 int c25519_amd_host_register(void *p, size_t bytes);
 int c25519_amd_host_unregister(void *p);
 

@@ -820,9 +820,9 @@ def test_host_pipeline_shapes_give_the_same_bytes(api, oracle, knobs):
 
 
 def test_page_locked_caller_arrays_are_used_in_place(api, oracle):
-    """*_batch recognises page-locked arguments (c25519_amd_host_register, or hipHostMalloc memory such as torch's
-    pinned tensors) and lets the copy engines work on them directly; any mix of locked and pageable arguments, the
-    IN/OUT secret-key array included, gives the bytes of the ordinary call."""
+    """*_batch recognises page-locked arguments (c25519_amd_host_register on page-aligned buffers, or hipHostMalloc
+    memory such as torch's pinned tensors) and lets the copy engines work on them directly; any mix of locked and
+    pageable arguments, the IN/OUT secret-key array included, gives the bytes of the ordinary call."""
     import torch
     from curve25519_amd import _lib
     L = _lib.load()
@@ -830,10 +830,10 @@ def test_page_locked_caller_arrays_are_used_in_place(api, oracle):
     P = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
     sk, pk = synth.x25519_inputs(n)
     want, want_sk = api.curve25519_dh_CreateSharedKey(pk, sk)
-    # every argument registered
-    r_sk, r_pk, r_out = sk.copy(), pk.copy(), np.zeros((n, 32), np.uint8)
+    # every argument registered (buffers in pages of their own: the call refuses anything else)
+    r_sk, r_pk, r_out = synth.page_aligned((n, 32), like=sk), synth.page_aligned((n, 32), like=pk), synth.page_aligned((n, 32))
     for a in (r_sk, r_pk, r_out):
-        assert L.c25519_amd_host_register(P(a), a.nbytes) == 0
+        assert L.c25519_amd_host_register(P(a), synth.locked_bytes(a)) == 0
     assert L.curve25519_dh_CreateSharedKey_batch(P(r_out), P(r_pk), P(r_sk), n) == 0
     assert np.array_equal(r_out, want) and np.array_equal(r_sk, want_sk), "clamped in place, in the caller's locked array"
     # only the output registered, inputs pageable; then only one input
@@ -849,11 +849,11 @@ def test_page_locked_caller_arrays_are_used_in_place(api, oracle):
     m = 70001
     out = np.zeros((m, 32), np.uint8)
     t_sk = r_sk[n - m:].copy()
+    assert L.c25519_amd_host_register(P(r_sk[1:]), 4096) != 0 and b"whole pages" in L.c25519_amd_last_error()
     assert L.curve25519_dh_CreateSharedKey_batch(P(out), P(r_pk[n - m:]), P(t_sk), m) == 0
     assert np.array_equal(out, want[n - m:])
     for a in (r_sk, r_pk, r_out):
         assert L.c25519_amd_host_unregister(P(a)) == 0
-    assert L.c25519_amd_host_unregister(P(out)) != 0 and b"hipHostUnregister" in L.c25519_amd_last_error()
     # torch's pinned tensors (hipHostMalloc) through sign + verify
     esk, msg = synth.ed25519_inputs(n)
     pub, priv = api.ed25519_CreateKeyPair(esk)

@@ -60,9 +60,10 @@ L = _lib.load()
 h32, h64, hok = np.zeros((n, 32), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32)
 P = lambda a: a.ctypes.data  # noqa: E731
 # the same arrays page-locked by the caller (c25519_amd_host_register): *_batch then skips its staging copies
-reg = {k: v.copy() for k, v in dict(h32=h32, h64=h64, hok=hok, pk=pk, sk=sk, priv=priv, msg=msg, sig=sig, pub=pub).items()}
+reg = {k: synth.page_aligned(v.shape, v.dtype, like=v)
+       for k, v in dict(h32=h32, h64=h64, hok=hok, pk=pk, sk=sk, priv=priv, msg=msg, sig=sig, pub=pub).items()}
 for v in reg.values():
-    assert L.c25519_amd_host_register(P(v), v.nbytes) == 0
+    assert L.c25519_amd_host_register(P(v), synth.locked_bytes(v)) == 0
 R = lambda k: reg[k].ctypes.data  # noqa: E731
 rows = {}
 for name, cfn, rfn, pfn, dfn, moved in (

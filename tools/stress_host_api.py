@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""tools/stress_host_api.py -- soak of the host-pointer (*_batch) pipeline: several host threads, each with its own
+streams / buffer sets / helper threads, hammer the three passes with batch sizes that exercise every shape of
+run_batch (single piece, exactly 8 pieces, more pieces than buffer sets via C25519_AMD_BATCH_PIECES, ragged tails),
+pageable and page-locked arguments mixed; every result is compared with the bytes the device-pointer path gave for the
+same inputs.   python tools/stress_host_api.py [--threads 4] [--iters 40]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import threading
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from curve25519_amd import _lib, api, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--threads", type=int, default=4)
+ap.add_argument("--iters", type=int, default=40)
+ap.add_argument("--n", type=int, default=(1 << 19) + 12345)
+args = ap.parse_args()
+L = _lib.load()
+N = args.n
+sk, pk = synth.x25519_inputs(N)
+esk, msg = synth.ed25519_inputs(N)
+shared, sk_clamped = api.curve25519_dh_CreateSharedKey(pk, sk)
+pub, priv = api.ed25519_CreateKeyPair(esk)
+sig = api.ed25519_SignMessage(priv, msg)
+bsig, bmsg, bad = synth.corrupt_for_verify(sig, msg)
+want_ok = (~bad).astype(np.int32)
+P = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+errors = []
+
+
+def worker(tid):
+    rng = np.random.default_rng(1000 + tid)
+    locked = []
+    try:
+        for it in range(args.iters):
+            n = int(rng.choice([1, 255, 4097, 1 << 17, (1 << 17) + 1, 200003, 1 << 18, N]))
+            lo = int(rng.integers(0, N - n + 1))
+            sl = slice(lo, lo + n)
+            op = it % 3
+            lock = bool(rng.integers(0, 2))
+            if op == 0:
+                out, s2, p2 = np.zeros((n, 32), np.uint8), sk[sl].copy(), np.ascontiguousarray(pk[sl])
+                if lock:
+                    out, s2 = synth.page_aligned((n, 32)), synth.page_aligned((n, 32), like=s2)
+                    for a in (out, s2):
+                        assert L.c25519_amd_host_register(P(a), synth.locked_bytes(a)) == 0
+                        locked.append(a)
+                assert L.curve25519_dh_CreateSharedKey_batch(P(out), P(p2), P(s2), n) == 0
+                good = np.array_equal(out, shared[sl]) and np.array_equal(s2, sk_clamped[sl])
+            elif op == 1:
+                out = np.zeros((n, 64), np.uint8)
+                pr, m = np.ascontiguousarray(priv[sl]), np.ascontiguousarray(msg[sl])
+                if lock:
+                    pr = synth.page_aligned(pr.shape, like=pr)
+                    assert L.c25519_amd_host_register(P(pr), synth.locked_bytes(pr)) == 0
+                    locked.append(pr)
+                assert L.ed25519_SignMessage_batch(P(out), P(pr), P(m), m.shape[1], n) == 0
+                good = np.array_equal(out, sig[sl])
+            else:
+                out = np.full(n, -7, np.int32)
+                s2, p2, m = np.ascontiguousarray(bsig[sl]), np.ascontiguousarray(pub[sl]), np.ascontiguousarray(bmsg[sl])
+                if lock:
+                    out = synth.page_aligned(n, np.int32, like=out)
+                    assert L.c25519_amd_host_register(P(out), synth.locked_bytes(out)) == 0
+                    locked.append(out)
+                assert L.ed25519_VerifySignature_batch(P(out), P(s2), P(p2), P(m), m.shape[1], n) == 0
+                good = np.array_equal(out, want_ok[sl])
+            while locked:
+                assert L.c25519_amd_host_unregister(P(locked.pop())) == 0
+            if not good:
+                errors.append((tid, it, op, n, lo, lock))
+                return
+        L.c25519_amd_thread_release()
+    except Exception as e:  # noqa: BLE001
+        errors.append((tid, repr(e), L.c25519_amd_last_error()))
+
+
+threads = [threading.Thread(target=worker, args=(t,)) for t in range(args.threads)]
+for t in threads:
+    t.start()
+for t in threads:
+    t.join()
+print("errors:", errors)
+print("stress ok" if not errors else "STRESS FAILED", f"({args.threads} threads x {args.iters} calls, pieces={os.environ.get('C25519_AMD_BATCH_PIECES', '8')})")
+sys.exit(1 if errors else 0)
