@@ -1018,7 +1018,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
 
 extern "C" {
 
-const char* c25519_amd_version(void) { return "curve25519_amd 0.5 (gfx950)"; }
+const char* c25519_amd_version(void) { return "curve25519_amd 0.6 (gfx950)"; }
 const char* c25519_amd_last_error(void) { return c25519_host::last_error().c_str(); }
 
 int c25519_amd_device_count(void)
