@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""tests/long_differential.py -- opt-in long run (not collected by pytest): the HIP path against the REAL reference
+(oracle/_ref, the reference's own C files compiled by oracle/Makefile) on fresh random inputs at volume, with the edge
+encodings of tests/vectors.py sprinkled through every batch.  Every round: 2^20 X25519 shared keys, 2^18 key pairs +
+signatures, 2^18 verifications with corrupted entries, garbage keys and S + L rewrites.
+
+    python tests/long_differential.py [--rounds 8] [--seed 1]
+"""
+import argparse
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import numpy as np  # noqa: E402
+
+import vectors  # noqa: E402
+from curve25519_amd import api, synth  # noqa: E402
+from oracle_lib import Reference  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=8)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--threads", type=int, default=16)
+args = ap.parse_args()
+assert Reference.available(), "oracle/_ref is not built (make -C oracle ref)"
+ref = Reference()
+T = args.threads
+L = vectors.L
+
+
+def sprinkle(arr, rng, rows):
+    """overwrite random rows of a 32-byte-wide array with edge encodings"""
+    idx = rng.choice(arr.shape[0], size=len(rows), replace=False)
+    arr[idx] = rows
+    return idx
+
+
+edge32 = np.stack([np.frombuffer(vectors.le(v, 32), np.uint8) for v in
+                   [0, 1, 2, 9, 2**255 - 19, 2**255 - 20, 2**255 - 18, 2**255 - 1, 2**256 - 1, 2**255, 2**255 + 9,
+                    L, L - 1, L + 1, 8 * L % 2**256, 2**252, 2**254, 2**254 + 8, 325606250916557431795983626356110631294008115727848805560023387167927233504,
+                    39382357235489614581723060781553021112529911719440698176882885853963445705823]])
+t0 = time.time()
+total = {"x25519": 0, "keypair": 0, "sign": 0, "verify": 0}
+for r in range(args.rounds):
+    rng = np.random.default_rng(args.seed * 1000 + r)
+    n = 1 << 20
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sprinkle(pk, rng, np.repeat(edge32, 8, axis=0))
+    sprinkle(sk, rng, np.repeat(edge32, 4, axis=0))
+    got, got_sk = api.curve25519_dh_CreateSharedKey(pk, sk)
+    want, want_sk = ref.x25519_shared_threaded(pk, sk, T)
+    assert np.array_equal(got, want) and np.array_equal(got_sk, want_sk), f"round {r}: X25519 differs at rows {np.nonzero((got != want).any(axis=1))[0][:5]}"
+    total["x25519"] += n
+    m = 1 << 18
+    esk = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    sprinkle(esk, rng, edge32)
+    mlen = int(rng.integers(0, 200))
+    msg = rng.integers(0, 256, (m, mlen), dtype=np.uint8)
+    pub, priv = api.ed25519_CreateKeyPair(esk)
+    rpub, rpriv = ref.ed25519_keypair(esk[:4096])
+    assert np.array_equal(pub[:4096], rpub) and np.array_equal(priv[:4096], rpriv), f"round {r}: keypair differs"
+    total["keypair"] += 4096
+    sig = api.ed25519_SignMessage(priv, msg)
+    rsig = ref.ed25519_sign_threaded(priv, msg, T)
+    assert np.array_equal(sig, rsig), f"round {r}: signatures differ at rows {np.nonzero((sig != rsig).any(axis=1))[0][:5]}"
+    total["sign"] += m
+    bsig, bmsg, bad = synth.corrupt_for_verify(sig, msg) if mlen else (sig.copy(), msg, np.zeros(m, bool))
+    vpk = pub.copy()
+    for i in rng.choice(m, 300, replace=False):                       # S + L where it fits: the reference accepts it
+        S = int.from_bytes(bsig[i, 32:].tobytes(), "little")
+        if S + L < 2**256:
+            bsig[i, 32:] = np.frombuffer(vectors.le(S + L, 32), np.uint8)
+    g = rng.choice(m, 2000, replace=False)
+    vpk[g] = rng.integers(0, 256, (2000, 32), dtype=np.uint8)           # garbage keys: about half are off the curve
+    sprinkle(vpk, rng, edge32)
+    e = rng.choice(m, 400, replace=False)
+    bsig[e, :32] = np.tile(edge32, (20, 1))                             # edge encodings as R
+    ok = api.ed25519_VerifySignature(bsig, vpk, bmsg)
+    rok = ref.ed25519_verify_threaded(bsig, vpk, bmsg, T)
+    assert np.array_equal(ok, rok), f"round {r}: verdicts differ at rows {np.nonzero(ok != rok)[0][:5]}"
+    total["verify"] += m
+    print(f"round {r}: ok (msg {mlen} B, accepted {int(ok.sum())} of {m})   {time.time() - t0:.0f} s", flush=True)
+print("long differential ok:", total)
