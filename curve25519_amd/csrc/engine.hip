@@ -815,12 +815,12 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     for (int a = 0; a < na; a++) row += arr[a].elem;
     static const size_t pieces = [] { const char* e = getenv("C25519_AMD_BATCH_PIECES"); int v = e ? atoi(e) : 0; return (size_t)(v >= 2 && v <= 64 ? v : 8); }();
     size_t chunk = n >= ((size_t)1 << 17) ? round_up((n + pieces - 1) / pieces, 256) : n;
-    const size_t cap = round_up(((size_t)256 << 20) / (row ? row : 1) + 1, 256);       // <= 256 MiB of staging per lane
+    const size_t cap = round_up(((size_t)256 << 20) / (row ? row : 1) + 1, 256);       // <= 256 MiB of staging per buffer set
     if (chunk > cap) chunk = cap;
     const size_t nchunks = (n + chunk - 1) / chunk;
     const int sets = nchunks < (size_t)ThreadState::SETS ? (int)nchunks : ThreadState::SETS;
     bool direct[ThreadState::SLOTS] = {};                  // the caller's array is pinned: no staging copy either way
-    for (int a = 0; a < na; a++) {
+    for (int a = 0; a < na && n >= 4096; a++) {            // (not worth two attribute queries per array on a tiny call)
         direct[a] = (!arr[a].in || host_pinned(arr[a].in, n * arr[a].elem)) && (!arr[a].out || host_pinned(arr[a].out, n * arr[a].elem));
         if (arr[a].in && arr[a].out && arr[a].in != arr[a].out) direct[a] = false;
     }
