@@ -453,20 +453,32 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fa
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
     lds_stage_base_table(lds_tbl, g_tbl + (BASE_NT - 1) * BASE_TBL_WORDS);
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    u32* lane_tables = fs.tables + i * FAST_TABLE_WORDS;
+    const bool valid = i < n;
+    u32* lane_tables = fs.tables + (valid ? i : 0) * FAST_TABLE_WORDS;
     if (fs.wg_slow[blockIdx.x]) {                              // uniform over the workgroup
+        if (!valid) return;
         u32 pkw[8];
         load32(pkw, pk, i);
         verdict[i] = verify_reference_order_lane(pkw, sig, i, msgs.ptr(i), msgs.len(i), lane_tables, lds_tbl);
         return;
     }
-    u32 sigma[8], rho[5], tau[5];
-    soa_load8(sigma, fs.sigma, n, i);
+    u32 sigma[8] = {}, rho[5] = {}, tau[5] = {};
+    int top = 0;
+    if (valid) {
+        soa_load8(sigma, fs.sigma, n, i);
 #pragma unroll
-    for (int w = 0; w < 5; w++) { rho[w] = fs.rho[(size_t)w * n + i]; tau[w] = fs.tau[(size_t)w * n + i]; }
+        for (int w = 0; w < 5; w++) { rho[w] = fs.rho[(size_t)w * n + i]; tau[w] = fs.tau[(size_t)w * n + i]; }
+        top = walk_top_digit(tau, rho);
+    }
+    // the wave walks from its longest element's first digit (the others' digits above their own are zero)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int other = __shfl_xor(top, o);
+        top = other > top ? other : top;
+    }
+    if (!valid) return;
     const QTableLimbs tq{ lane_tables }, tr{ lane_tables + WTABLE_WORDS };
-    const u32 neutral = ge_walk_is_neutral(sigma, tau, rho, tq, tr, lds_tbl);
+    const u32 neutral = ge_walk_is_neutral(sigma, tau, rho, tq, tr, lds_tbl, top < 8 ? 8 : top);
     verdict[i] = (neutral & fs.flags[i] & 1u) ? 1 : 0;
 }
 

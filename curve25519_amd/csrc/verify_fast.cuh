@@ -336,6 +336,20 @@ C25519_DEV u32 signed16_at(u32& negative, const u32 (&kb)[5], int i)
     return nib < 8u ? 8u - nib : nib - 8u;
 }
 
+// index of the most significant nonzero signed digit of either biased scalar (0 if there is none): nibbles that still
+// equal the bias' 8 are zero digits
+C25519_DEV int walk_top_digit(const u32 (&tau_b)[5], const u32 (&rho_b)[5])
+{
+    const u32 bias[5] = { 0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u, 0x00008888u };
+    int top = 0;
+#pragma unroll
+    for (int w = 0; w < 5; w++) {
+        const u32 v = (tau_b[w] ^ bias[w]) | (rho_b[w] ^ bias[w]);
+        top = v ? 8 * w + ((31 - __builtin_clz(v)) >> 2) : top;
+    }
+    return top < WALK_DIGITS ? top : WALK_DIGITS - 1;
+}
+
 // ---- per-lane window tables: rows 0..8 = 0, P, 2P, ..., 8P in PE form ---------------------------------------------------------
 constexpr int WTABLE_ROWS = 9;
 constexpr size_t WTABLE_WORDS = WTABLE_ROWS * PE_WORDS;   // 360 words = 1440 bytes per table
@@ -435,16 +449,20 @@ C25519_DEV u32 ge_decode_checked(ge_ext& P, const u32 (&w)[8], u32 parity_flip, 
 // ---- the walk ----------------------------------------------------------------------------------------------------------
 // W = sigma*B + tau*Q + rho*Rn from the two window tables (Q and Rn = -R already carry the signs of tau and of the
 // equation), the biased scalars and the LDS base table; returns all-ones iff W is the neutral element.
+// `top`: the walk starts at this digit; every digit above it must be zero in both scalars, and top >= 8 (sigma's columns
+// ride the last eight digits).  The kernels pass the maximum of walk_top_digit() over the wave: typical short vectors
+// have 127-131 bits, so a wave starts at digit 32 or 33 instead of 35 and saves two or three of the 36 rounds of four
+// doublings and two table additions; leading zero digits would have added the neutral row, so skipping them is exact.
 template <typename Tbl>
 C25519_DEV u32 ge_walk_is_neutral(u32 (&sigma)[8], const u32 (&tau_b)[5], const u32 (&rho_b)[5], const Tbl& tq, const Tbl& tr,
-                                  const u32* lds_tbl)
+                                  const u32* lds_tbl, int top = WALK_DIGITS - 1)
 {
     ge_ext S;
     ge_pa pa;
     {
         ge_pe pe;
         u32 neg;
-        const u32 m = signed16_at(neg, tau_b, WALK_DIGITS - 1);
+        const u32 m = signed16_at(neg, tau_b, top);
         tq.load(pe, m);
         pe_cond_neg(pe, neg);
         ge_from_pe(S, pe);
@@ -455,10 +473,10 @@ C25519_DEV u32 ge_walk_is_neutral(u32 (&sigma)[8], const u32 (&tau_b)[5], const 
         if (need_t) ge_add_pe_row<true>(S, t.base + (size_t)m * PE_WORDS, neg);
         else ge_add_pe_row<false>(S, t.base + (size_t)m * PE_WORDS, neg);
     };
-    add_row(tr, rho_b, WALK_DIGITS - 1, false);
+    add_row(tr, rho_b, top, false);
     // sigma's 8-fold columns ride on the last 32 doublings (the reference's own trick, ed25519_verify.c:266-279)
 #pragma unroll 1
-    for (int i = WALK_DIGITS - 2; i >= 0; i--) {
+    for (int i = top - 1; i >= 0; i--) {
         if (i >= 8) {
 #pragma unroll 1
             for (int j = 0; j < 3; j++) ge_double<false>(S);

@@ -232,7 +232,8 @@ void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char*
         const QTableLimbs tq{ q.data() }, tr{ q.data() + WTABLE_WORDS };
         const u32 lat_ok = ed_verify_fast_scalars(sigma, rho, tau, tau_neg, pkw, Rw, Sw, msg + len * i, len);
         const u32 pts = ed_verify_fast_points(tq, tr, pkw, Rw, tau_neg);
-        const u32 neutral = ge_walk_is_neutral(sigma, tau, rho, tq, tr, tbl);
+        const int top = walk_top_digit(tau, rho);                    // a "wave" of one lane: every start digit gets exercised
+        const u32 neutral = ge_walk_is_neutral(sigma, tau, rho, tq, tr, tbl, top < 8 ? 8 : top);
         verdict[i] = ((pts & 1u) && neutral) ? 1 : 0;
         need_slow[i] = (lat_ok && (pts & 2u)) ? 0 : 1;
     }
