@@ -38,9 +38,9 @@ BATCH = 1 << 20
 BYTES_PER_OP = {"x25519": 96, "sign": 160, "verify": 132}          # SURVEY.md 8(d), compulsory HBM bytes
 MACS_PER_OP = {"x25519": 184104, "sign": 52992, "verify": 245664}  # SURVEY.md 8(a), 32x32 MACs at 72/mul
 # what the device actually issues per operation (v_mad_u64_u32 count from the kernels' ISA): the
-# ladder does the reference's work in 100/55-MAD products; sign walks 7 doublings instead of 31; verification of
+# ladder does the reference's work in 100/55-MAD products; sign walks 3 doublings instead of 31; verification of
 # on-curve keys walks 140 doublings instead of 255
-EXECUTED_MACS_PER_OP = {"x25519": 191400, "sign": 27200, "verify": 187000}   # verify: 33.6 of 36 digit rounds on average
+EXECUTED_MACS_PER_OP = {"x25519": 191400, "sign": 25100, "verify": 187000}   # verify: 33.6 of 36 digit rounds on average
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md
 
 PASS_KERNELS = {

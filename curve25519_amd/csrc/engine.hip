@@ -151,31 +151,41 @@ __global__ void __launch_bounds__(XF_BLOCK, C25519_XF_WAVES) k_x25519_fused(void
 // ------------------------------------------------------------------------------------------------
 // 8-fold base table, generated on the device at first use
 // ------------------------------------------------------------------------------------------------
-// row k = sum over set bits i of k of 2^(32 i) * B, as canonical (Y+X, Y-X, 2dT): the content of the
-// reference's source/base_folding8.h, derived from B by doubling/adding (the recipe of
-// test/curve25519_selftest.c:498-551).  Written twice: limb-major limbs for LDS staging and 96-byte
-// canonical rows for inspection.
-// Thread group t (256 threads each) produces T_t = 2^((BASE_NT-1-t)*BASE_STEP) * T for the short walk of
-// ge_base_mult; the last group is the reference table T itself.
-__global__ void __launch_bounds__(256 * BASE_NT) k_gen_base_table(u32* tbl_limbs /*[BASE_NT][30][256]*/,
-                                                                  u32* tbl_bytes /*[256][24]*/)
+// Block 0, thread group t (128 threads each): the signed comb tables T_t = 2^((BASE_NT-1-t)*BASE_STEP) * Ts of
+// ge_base_mult (ge_signed_comb_row).  Block 1, 256 threads: row k = sum over set bits i of k of 2^(32 i) * B as canonical
+// (Y+X, Y-X, 2dT) -- the content of the reference's source/base_folding8.h, derived from B by doubling/adding (the recipe
+// of test/curve25519_selftest.c:498-551) -- written twice: limb-major limbs after the signed tables (REF_TBL_OFFSET:
+// verification's sigma columns) and 96-byte canonical rows for inspection.
+__global__ void __launch_bounds__(BASE_ROWS * BASE_NT) k_gen_base_table(u32* tbl_limbs /*[BASE_NT][30][128] + [30][256]*/,
+                                                                        u32* tbl_bytes /*[256][24]*/)
 {
-    const u32 k = threadIdx.x & 255u;
-    const int group = threadIdx.x >> 8;
-    const int extra = (BASE_NT - 1 - group) * BASE_STEP;   // trailing doublings
     u32 rows[3][8];
-    ge_base_table_row(rows, k, extra);
-    u32* limbs = tbl_limbs + group * BASE_TBL_WORDS;
+    if (blockIdx.x == 0) {
+        const u32 idx = threadIdx.x & (BASE_ROWS - 1);
+        const int group = threadIdx.x / BASE_ROWS;
+        ge_signed_comb_row(rows, idx, (BASE_NT - 1 - group) * BASE_STEP);
+        u32* limbs = tbl_limbs + group * BASE_TBL_WORDS;
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            fe c;
+            fe_from_words(c, rows[f]);            // canonical value back in limb form
+#pragma unroll
+            for (int l = 0; l < 10; l++) limbs[(10 * f + l) * BASE_ROWS + idx] = c.v[l];
+        }
+        return;
+    }
+    if (threadIdx.x >= 256) return;
+    const u32 k = threadIdx.x;
+    ge_base_table_row(rows, k, 0);
+    u32* limbs = tbl_limbs + REF_TBL_OFFSET;
 #pragma unroll
     for (int f = 0; f < 3; f++) {
         fe c;
-        fe_from_words(c, rows[f]);            // canonical value back in limb form
+        fe_from_words(c, rows[f]);
 #pragma unroll
         for (int l = 0; l < 10; l++) limbs[(10 * f + l) * 256 + k] = c.v[l];
-        if (extra == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) tbl_bytes[k * 24 + 8 * f + j] = rows[f][j];
-        }
+        for (int j = 0; j < 8; j++) tbl_bytes[k * 24 + 8 * f + j] = rows[f][j];
     }
 }
 
@@ -192,7 +202,7 @@ __global__ void __launch_bounds__(256 * BASE_NT) k_gen_base_table(u32* tbl_limbs
 #define C25519_VC_WAVES 2            // ... and Verify_Check (A/B: profiles/r02_ab_occupancy.txt)
 #endif
 constexpr int ED_BLOCK = C25519_ED_BLOCK;
-constexpr int BM_BLOCK = 1024;            // fixed-base kernels: one 120 KiB table set per 16 waves (4 per SIMD)
+constexpr int BM_BLOCK = 1024;            // fixed-base kernels: one 120 KiB set of signed comb tables per 16 waves (4 per SIMD)
 
 C25519_DEV void store_proj(const ProjScratch& scr, size_t n, size_t i, const ge_ext& S)
 {
@@ -223,7 +233,7 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_keypair_mult(ProjScratc
                                                                        const u32* __restrict__ blind_ctx)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
-    lds_stage_base_table(lds_tbl, g_tbl, BASE_NT);
+    lds_stage_words(lds_tbl, g_tbl, BASE_NT * BASE_TBL_WORDS);
     const size_t i = (size_t)blockIdx.x * BM_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 seed[8], a[8];
@@ -242,7 +252,7 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_x25519_public_fast_mult(ProjScr
                                                                           const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
-    lds_stage_base_table(lds_tbl, g_tbl, BASE_NT);
+    lds_stage_words(lds_tbl, g_tbl, BASE_NT * BASE_TBL_WORDS);
     const size_t i = (size_t)blockIdx.x * BM_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 k[8];
@@ -267,7 +277,7 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_sign_mult(ProjScratch s
                                                                     const u32* __restrict__ blind_ctx)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
-    lds_stage_base_table(lds_tbl, g_tbl, BASE_NT);
+    lds_stage_words(lds_tbl, g_tbl, BASE_NT * BASE_TBL_WORDS);
     const size_t i = (size_t)blockIdx.x * BM_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 seed[8], a[8], r[8];
@@ -307,7 +317,7 @@ __global__ void __launch_bounds__(256) k_ed25519_blinding_init(u32* ctx, const u
                                                                 const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
-    lds_stage_base_table(lds_tbl, g_tbl, BASE_NT);
+    lds_stage_words(lds_tbl, g_tbl, BASE_NT * BASE_TBL_WORDS);
     if (threadIdx.x == 0) ed_blinding_init_lane(ctx, seed, seed_len, lds_tbl);
 }
 
@@ -351,7 +361,7 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VC_WAVES) k_ed25519_verify_ch
                                                                        size_t stride_words)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
-    lds_stage_base_table(lds_tbl, g_tbl + (BASE_NT - 1) * BASE_TBL_WORDS);
+    lds_stage_words(lds_tbl, g_tbl + REF_TBL_OFFSET, REF_TBL_WORDS);
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 pkw[8];
@@ -451,7 +461,7 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fa
                                                                            const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
-    lds_stage_base_table(lds_tbl, g_tbl + (BASE_NT - 1) * BASE_TBL_WORDS);
+    lds_stage_words(lds_tbl, g_tbl + REF_TBL_OFFSET, REF_TBL_WORDS);
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     const bool valid = i < n;
     u32* lane_tables = fs.tables + (valid ? i : 0) * FAST_TABLE_WORDS;
@@ -516,7 +526,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(Pro
 #pragma unroll
         for (int l = 0; l < 10; l++) lds_q[(10 * f + l) * 16 + row] = v.v[l];
     }
-    lds_stage_base_table(lds_tbl, g_tbl + (BASE_NT - 1) * BASE_TBL_WORDS);   // ends with __syncthreads()
+    lds_stage_words(lds_tbl, g_tbl + REF_TBL_OFFSET, REF_TBL_WORDS);   // ends with __syncthreads()
     const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
     if (i >= n) return;
     u32 pkw[8];
@@ -682,16 +692,16 @@ constexpr int MAX_DEVICES = 64;
 struct DeviceTables {
     std::once_flag once;
     int rc = 0;
-    u32* limbs = nullptr;     // [BASE_NT][30][256]: 2^24 T, 2^16 T, 2^8 T, T
+    u32* limbs = nullptr;     // [BASE_NT][30][128] signed comb tables 2^28 Ts .. Ts, then [30][256]: the reference's table T
     u32* bytes = nullptr;     // [256][24]
 };
 DeviceTables g_tables[MAX_DEVICES];
 
 int init_tables(DeviceTables& t)
 {
-    C25519_TRY(hipMalloc(&t.limbs, BASE_NT * BASE_TBL_WORDS * sizeof(u32)));
+    C25519_TRY(hipMalloc(&t.limbs, (REF_TBL_OFFSET + REF_TBL_WORDS) * sizeof(u32)));
     C25519_TRY(hipMalloc(&t.bytes, 256 * 24 * sizeof(u32)));
-    k_gen_base_table<<<1, 256 * BASE_NT, 0, nullptr>>>(t.limbs, t.bytes);
+    k_gen_base_table<<<2, BASE_ROWS * BASE_NT, 0, nullptr>>>(t.limbs, t.bytes);
     C25519_TRY(hipGetLastError());
     C25519_TRY(hipStreamSynchronize(nullptr));
     return 0;
@@ -1030,7 +1040,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
 
 extern "C" {
 
-const char* c25519_amd_version(void) { return "curve25519_amd 0.6 (gfx950)"; }
+const char* c25519_amd_version(void) { return "curve25519_amd 0.7 (gfx950)"; }
 const char* c25519_amd_last_error(void) { return c25519_host::last_error().c_str(); }
 
 int c25519_amd_device_count(void)

@@ -185,12 +185,12 @@ C25519_DEV void lds_load_pa(ge_pa& q, const u32* tbl, u32 row)
     }
 }
 
-// cooperative copy of `tables` consecutive 256-row limb tables (device resident) into this workgroup's LDS
-C25519_DEV void lds_stage_base_table(u32* lds_tbl, const u32* __restrict__ g_tbl, int tables = 1)
+// cooperative copy of `words` table words (device resident, a multiple of 4) into this workgroup's LDS
+C25519_DEV void lds_stage_words(u32* lds_tbl, const u32* __restrict__ g_tbl, int words)
 {
     const uint4* src = reinterpret_cast<const uint4*>(g_tbl);
     uint4* dst = reinterpret_cast<uint4*>(lds_tbl);
-    for (int i = threadIdx.x; i < tables * PA_WORDS * 256 / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < words / 4; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
 }
 
@@ -204,22 +204,70 @@ C25519_DEV u32 fold8_at(const u32 (&k)[8], int n)
 }
 
 // S = k * B.  The reference's walk (edp_BasePointMult, ed25519_sign.c:215-244) is S = T[c0]; S = 2S + T[cn],
-// n = 1..31 over one 8-fold table.  With BASE_NT tables T_t = 2^((BASE_NT-1-t)*step) * T, step = 32/BASE_NT,
-// the same sum regroups as
-//     sum_n 2^(31-n) T[c_n]  =  sum_{m<step} 2^(step-1-m) * sum_{t<BASE_NT} T_t[c_(t*step+m)]
-// i.e. step-1 doublings and 31 additions instead of 31 doublings and 31 additions -- the same point, hence the
-// same canonical bytes after the inversion.  BASE_NT = 4: 7 doublings, 120 KiB of LDS (MI355X has 160 KiB per
-// CU), shared by a 1024-thread workgroup (BM_BLOCK).  lds_tbl holds T_0 .. T_(BASE_NT-1) (= T itself), limb-major each.
-constexpr int BASE_NT = 4;
+// n = 1..31 over one 8-fold table: 31 doublings, 31 additions.  Two regroupings of the same sum give the same point,
+// hence the same canonical bytes after the inversion:
+//  * BASE_NT tables T_t = 2^((BASE_NT-1-t)*step) * T, step = 32/BASE_NT:
+//        sum_n 2^(31-n) T[c_n]  =  sum_{m<step} 2^(step-1-m) * sum_{t<BASE_NT} T_t[c_(t*step+m)]
+//    i.e. step-1 doublings instead of 31;
+//  * signed digits: k is made odd (k + L when it is even: L*B = O) and written with ALL digits +-1,
+//    k' = sum_i s_i 2^i, s_i = 2 w_i - 1 with w = (k' >> 1) | 2^255.  A column of eight teeth is then +-(2^224 + sum of
+//    seven +-2^(32 j)) B: 128 rows and a sign instead of 256 rows, so EIGHT tables fit the 120 KiB of LDS that four
+//    unsigned ones took, and the walk needs 3 doublings instead of 7.  Rows are negated on the way out of LDS
+//    ((y+x, y-x, 2dxy) -> (y-x, y+x, -2dxy)).
+// lds_tbl holds T_0 .. T_(BASE_NT-1), limb-major each ([30][BASE_ROWS]); a 1024-thread workgroup (BM_BLOCK) shares it.
+// The reference-format table T itself (256 rows: verification's sigma columns, the table test hook) follows the signed
+// tables in device memory at REF_TBL_OFFSET.
+constexpr int BASE_NT = 8;
 constexpr int BASE_STEP = 32 / BASE_NT;
-constexpr int BASE_TBL_WORDS = PA_WORDS * 256;
+constexpr int BASE_ROWS = 128;
+constexpr int BASE_TBL_WORDS = PA_WORDS * BASE_ROWS;
+constexpr int REF_TBL_WORDS = PA_WORDS * 256;
+constexpr int REF_TBL_OFFSET = BASE_NT * BASE_TBL_WORDS;
+
+// w of the recoding above.  k < 2^255 + 2^254 (clamped scalars, scalars mod L).
+C25519_DEV void sc_signed_comb(u32 (&w)[8], const u32 (&k)[8])
+{
+    const u32 even = (k[0] & 1u) - 1u;                       // all-ones when k is even
+    u32 t[8];
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (u64)k[i] + (K_L[i] & even);
+        t[i] = (u32)c;
+        c >>= 32;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) w[i] = (t[i] >> 1) | (t[i + 1] << 31);
+    w[7] = (t[7] >> 1) | 0x80000000u;
+}
+
+// the row a column byte c selects: tooth 7 is the sign (w bit 0 = digit -1: the whole column is negated), teeth 0..6 the
+// index, complemented for a negative column
+C25519_DEV void lds_load_pa_signed(ge_pa& q, const u32* tbl, u32 c)
+{
+    const u32 neg = ((c >> 7) & 1u) - 1u;                     // all-ones: negative column
+    const u32 row = (c ^ neg) & 127u;
+    const u32* p_ypx = tbl + (neg ? 10 * BASE_ROWS : 0) + row;
+    const u32* p_ymx = tbl + (neg ? 0 : 10 * BASE_ROWS) + row;
+    fe t, n;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        q.ypx.v[i] = p_ypx[i * BASE_ROWS];
+        q.ymx.v[i] = p_ymx[i * BASE_ROWS];
+        t.v[i] = tbl[(20 + i) * BASE_ROWS + row];
+    }
+    fe_neg(n, t);                                            // 2p - 2dxy: beta 2, fine as the second factor of a product
+    fe_select(q.t2d, neg, n, t);
+}
 
 // FINAL_T: also produce T of the result (needed when another addition follows, i.e. the blinding point).
 template <bool FINAL_T = false>
 C25519_DEV void ge_base_mult(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl, const fe* zr = nullptr)
 {
+    u32 w[8];
+    sc_signed_comb(w, k);
     ge_pa q;
-    lds_load_pa(q, lds_tbl, fold8_at(k, 0));
+    lds_load_pa_signed(q, lds_tbl, fold8_at(w, 0));
     ge_from_pa(S, q, zr);
 #pragma unroll 1
     for (int m = 0; m < BASE_STEP; m++) {
@@ -228,11 +276,11 @@ C25519_DEV void ge_base_mult(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl, c
         // Kept as a loop: one copy of the addition in the instruction cache instead of BASE_NT.
 #pragma unroll 1
         for (int t = m ? 0 : 1; t < BASE_NT - 1; t++) {
-            lds_load_pa(q, lds_tbl + t * BASE_TBL_WORDS, fold8_at(k, t * BASE_STEP + m));
+            lds_load_pa_signed(q, lds_tbl + t * BASE_TBL_WORDS, fold8_at(w, t * BASE_STEP + m));
             ge_add_pa<true>(S, q);
         }
         // last table: a doubling or the affine conversion follows, neither reads T
-        lds_load_pa(q, lds_tbl + (BASE_NT - 1) * BASE_TBL_WORDS, fold8_at(k, (BASE_NT - 1) * BASE_STEP + m));
+        lds_load_pa_signed(q, lds_tbl + (BASE_NT - 1) * BASE_TBL_WORDS, fold8_at(w, (BASE_NT - 1) * BASE_STEP + m));
         if (FINAL_T && m == BASE_STEP - 1) ge_add_pa<true>(S, q);
         else ge_add_pa<false>(S, q);
     }

@@ -203,10 +203,49 @@ C25519_DEV void ge_base_table_row(u32 (&rows)[3][8], u32 k, int extra)
     for (int f = 0; f < 3; f++) fe_to_words(rows[f], row[f]);
 }
 
+// row idx (7 bits) of a signed comb table: 2^extra * (2^224 + sum over j < 7 of (bit j of idx ? + : -) 2^(32 j)) * B, as
+// canonical words of (Y+X, Y-X, 2dT) -- what ge_base_mult's recoding selects for a column whose top digit is +1
+C25519_DEV void ge_signed_comb_row(u32 (&rows)[3][8], u32 idx, int extra)
+{
+    ge_pa B, Bn;
+    B.ypx = fe_const(K_BY); B.ymx = fe_const(K_BY);
+    {
+        fe t;
+        fe_add(t, B.ypx, fe_const(K_BX)); fe_carry32(B.ypx, t);
+        fe_sub(t, B.ymx, fe_const(K_BX)); fe_carry32(B.ymx, t);
+    }
+    B.t2d = fe_const(K_BT2D);
+    Bn.ypx = B.ymx; Bn.ymx = B.ypx;                          // -B
+    { fe t; fe_neg(t, B.t2d); fe_carry32(Bn.t2d, t); }
+
+    ge_ext S;                                                // top tooth: + B
+    fe_set_u32(S.X, 0); fe_set_u32(S.Y, 1); fe_set_u32(S.Z, 1); fe_set_u32(S.T, 0);
+    ge_add_pa(S, B);
+#pragma unroll 1
+    for (int i = 6; i >= 0; i--) {                           // Horner over the seven signed teeth, 32 doublings apart
+#pragma unroll 1
+        for (int j = 0; j < 32; j++) ge_double(S);
+        if ((idx >> i) & 1) ge_add_pa(S, B);
+        else ge_add_pa(S, Bn);
+    }
+#pragma unroll 1
+    for (int j = 0; j < extra; j++) ge_double(S);
+    fe zi, x, y, t, row[3];
+    fe_invert(zi, S.Z);
+    fe_mul(x, S.X, zi);
+    fe_mul(y, S.Y, zi);
+    fe_add(row[0], y, x);
+    fe_sub(row[1], y, x);
+    fe_mul(t, x, y);
+    fe_mul(row[2], t, fe_const(K_2D));
+#pragma unroll
+    for (int f = 0; f < 3; f++) fe_to_words(rows[f], row[f]);
+}
+
 // ed25519_Blinding_Init (ed25519_sign.c:289-331) for one context: digest = SHA-512(domain || seed),
 // t = digest[0..31] mod L, bl = L - t, zr = digest[32..63], BP = PE(t*B) (affine, Z2 = 2).  The 32-byte domain string
 // "c25519_amd_blinding_cxv1--------" takes the place of the reference's compiled-in custom blinder (custom_blind.c),
-// which likewise only seeds the derivation.  lds_tbl: the BASE_NT staged tables.
+// which likewise only seeds the derivation.  lds_tbl: the BASE_NT staged signed comb tables.
 C25519_DEV void ed_blinding_init_lane(u32* ctx, const uint8_t* seed, size_t seed_len, const u32* lds_tbl)
 {
     const u32 domain[8] = { 0x35353263u, 0x615f3931u, 0x625f646du, 0x646e696cu, 0x5f676e69u, 0x31767863u, 0x2d2d2d2du, 0x2d2d2d2du };

@@ -16,26 +16,33 @@ namespace c25519 { unsigned long long emul_mad_overflows = 0; LatCounters emul_l
 
 namespace {
 
-std::vector<u32> g_tbl;                 // [BASE_NT][30][256] limb-major, as k_gen_base_table lays it out
+std::vector<u32> g_tbl;                 // [BASE_NT][30][128] signed comb tables, then [30][256] the reference's table:
+                                        // limb-major, as k_gen_base_table lays them out
 std::vector<u32> g_tbl_bytes;           // [256][24]
 std::once_flag g_tbl_once;
 
 void build_tables()
 {
-    g_tbl.assign((size_t)BASE_NT * BASE_TBL_WORDS, 0);
+    g_tbl.assign((size_t)REF_TBL_OFFSET + REF_TBL_WORDS, 0);
     g_tbl_bytes.assign(256 * 24, 0);
-    for (int group = 0; group < BASE_NT; group++) {
-        const int extra = (BASE_NT - 1 - group) * BASE_STEP;
-        for (u32 k = 0; k < 256; k++) {
+    for (int group = 0; group < BASE_NT; group++)
+        for (u32 idx = 0; idx < (u32)BASE_ROWS; idx++) {
             u32 rows[3][8];
-            ge_base_table_row(rows, k, extra);
+            ge_signed_comb_row(rows, idx, (BASE_NT - 1 - group) * BASE_STEP);
             for (int f = 0; f < 3; f++) {
                 fe c;
                 fe_from_words(c, rows[f]);
-                for (int l = 0; l < 10; l++) g_tbl[(size_t)group * BASE_TBL_WORDS + (10 * f + l) * 256 + k] = c.v[l];
-                if (extra == 0)
-                    for (int j = 0; j < 8; j++) g_tbl_bytes[k * 24 + 8 * f + j] = rows[f][j];
+                for (int l = 0; l < 10; l++) g_tbl[(size_t)group * BASE_TBL_WORDS + (10 * f + l) * BASE_ROWS + idx] = c.v[l];
             }
+        }
+    for (u32 k = 0; k < 256; k++) {
+        u32 rows[3][8];
+        ge_base_table_row(rows, k, 0);
+        for (int f = 0; f < 3; f++) {
+            fe c;
+            fe_from_words(c, rows[f]);
+            for (int l = 0; l < 10; l++) g_tbl[(size_t)REF_TBL_OFFSET + (10 * f + l) * 256 + k] = c.v[l];
+            for (int j = 0; j < 8; j++) g_tbl_bytes[k * 24 + 8 * f + j] = rows[f][j];
         }
     }
 }
@@ -194,7 +201,7 @@ void emul_ed25519_sign(unsigned char* sig, const unsigned char* priv, const unsi
 void emul_ed25519_verify(int* verdict, unsigned char* point /* may be NULL */, const unsigned char* sig,
                          const unsigned char* pk, const unsigned char* msg, size_t len, size_t n)
 {
-    const u32* tbl = tables() + (size_t)(BASE_NT - 1) * BASE_TBL_WORDS;
+    const u32* tbl = tables() + (size_t)REF_TBL_OFFSET;
     std::vector<u32> q(QTABLE_LIMB_WORDS);
     for (size_t i = 0; i < n; i++) {
         u32 pkw[8], Rw[8], Sw[8], h[8], enc[8];
@@ -222,7 +229,7 @@ void emul_ed25519_verify(int* verdict, unsigned char* point /* may be NULL */, c
 void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char* sig, const unsigned char* pk,
                               const unsigned char* msg, size_t len, size_t n)
 {
-    const u32* tbl = tables() + (size_t)(BASE_NT - 1) * BASE_TBL_WORDS;
+    const u32* tbl = tables() + (size_t)REF_TBL_OFFSET;
     std::vector<u32> q(2 * WTABLE_WORDS);
     for (size_t i = 0; i < n; i++) {
         u32 pkw[8], Rw[8], Sw[8], sigma[8], rho[5], tau[5], tau_neg;

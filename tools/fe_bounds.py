@@ -319,7 +319,12 @@ def main():
     for v in (mul(carry32(sub(R, R, "blind x")), FROM_WORDS, "blind X*zr"), mul(R, FROM_WORDS, "blind T*zr"),
               carry32(add(FROM_WORDS, FROM_WORDS))):
         need(all(v[i] <= R[i] for i in range(10)), "blinded start not reduced")
-    print("lattice verification walk and blinded base walk: ok")
+    # ---- ge25519.cuh signed comb (ge_base_mult): rows leave LDS negated when their column's top digit is -1 ----
+    for v in ge_add(R, R, R, R, R, R, t2d_neg, None):        # ge_add_pa with a conditionally negated affine row
+        need(all(v[i] <= R[i] for i in range(10)), "signed comb: add with a negated affine row: output not reduced")
+    mul(t2d_neg, CANON, "signed comb: ge_from_pa T of a negated first row")
+    carry32(neg(CANON, "signed comb table generation: -B's 2dxy"))
+    print("lattice verification walk, signed comb and blinded base walk: ok")
     print("all bounds hold")
 
 
