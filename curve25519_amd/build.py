@@ -36,7 +36,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: the gfx950 library cannot be built on this machine")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -pragma-unroll-threshold: k_batch_invert keeps 16 elements and their prefix products in registers, which needs its
+    # three 16-trip loops fully unrolled; the default threshold refuses the third one and the arrays land in scratch
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-pragma-unroll-threshold=131072",
            os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "multi_device.hip"), "-ldl", "-o", LIB + ".tmp"]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")

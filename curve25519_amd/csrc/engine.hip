@@ -11,7 +11,7 @@
 //     projective point in scratch, k_batch_invert (K elements per lane) writes the canonical bytes, and sign
 //     adds a finish kernel that hashes enc(R) || pk || m and computes S.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared engine.hip -o libcurve25519_amd.so
+// Build: curve25519_amd/build.py (hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -pragma-unroll-threshold=131072 ...)
 #include "capi_common.hpp"
 #include "lanes.cuh"
 #include "verify_fast.cuh"
@@ -594,49 +594,47 @@ struct FinishVerify {                        // verdict = (enc(T) == enc(R) byte
 constexpr int INV_BLOCK = 64;
 constexpr int INV_MAX_K = 16;
 
-template <typename Fin>
-__global__ void __launch_bounds__(INV_BLOCK) k_batch_invert(const u32* Z, u32* prefix, size_t n, size_t m, int K, Fin fin)
+// K is a compile-time constant and both loops are unrolled: a lane's K elements and their K prefix products live in
+// registers (a lone wave per SIMD has the whole register file: 64-thread workgroups, no occupancy to protect), so the
+// loads of all K elements are issued up front instead of one dependent round trip per element and per pass, and the
+// prefix products never go to memory.  (`prefix` stays in the signature for the scratch layout's sake.)
+template <typename Fin, int K>
+__global__ void __launch_bounds__(INV_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) k_batch_invert(const u32* Z, u32* prefix, size_t n, size_t m, Fin fin)
 {
+    (void)prefix;
     const size_t j = (size_t)blockIdx.x * INV_BLOCK + threadIdx.x;
     if (j >= m) return;
-    fe acc, z;
+    fe z[K], pre[K];
     u32 zero_mask = 0;
-    fe_set_u32(acc, 1);
-#pragma unroll 1
+#pragma unroll
     for (int t = 0; t < K; t++) {
         const size_t e = j + (size_t)t * m;
-        if (e >= n) break;
-        soa_load_fe(z, Z, n, e);
-        zero_mask |= (fe_zero_to_one(z) & 1u) << t;        // z == 0 (mod p) takes no part in the product
-        fe_mul(acc, acc, z);
-        soa_store_fe(prefix, n, e, acc);
+        if (e < n) soa_load_fe(z[t], Z, n, e);
+        else fe_set_u32(z[t], 1);                           // past the end: a factor of one
+    }
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+        zero_mask |= (fe_zero_to_one(z[t]) & 1u) << t;      // z == 0 (mod p) takes no part in the product
+        if (t == 0) pre[0] = z[0];
+        else fe_mul(pre[t], pre[t - 1], z[t]);
     }
     fe inv;
-    fe_invert(inv, acc);
-#pragma unroll 1
+    fe_invert(inv, pre[K - 1]);
+#pragma unroll
     for (int t = K - 1; t >= 0; t--) {
         const size_t e = j + (size_t)t * m;
-        if (e >= n) continue;
         fe zi;
         if (t > 0) {
-            fe p;
-            soa_load_fe(p, prefix, n, e - m);
-            fe_mul(zi, inv, p);
+            fe_mul(zi, inv, pre[t - 1]);
+            fe_mul(inv, inv, z[t]);
         } else {
             zi = inv;
         }
         const u32 was_zero = ((zero_mask >> t) & 1u) ? 0xffffffffu : 0u;
-        if (t > 0) {
-            soa_load_fe(z, Z, n, e);
-            fe one;
-            fe_set_u32(one, 1);
-            fe_select(z, was_zero, one, z);
-            fe_mul(inv, inv, z);
-        }
         fe zero;
         fe_set_u32(zero, 0);
         fe_select(zi, was_zero, zero, zi);
-        fin.emit(e, zi);
+        if (e < n) fin.emit(e, zi);
     }
 }
 
@@ -777,9 +775,17 @@ inline int inversion_k(size_t n)
 template <typename Fin>
 int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t stream)
 {
-    const int K = inversion_k(n);
+    int K = inversion_k(n);
+    K = K >= 16 ? 16 : K >= 8 ? 8 : K >= 4 ? 4 : K >= 2 ? 2 : 1;           // the instantiated group sizes
     const size_t m = (n + K - 1) / K;
-    k_batch_invert<Fin><<<grid_for(m, INV_BLOCK), INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, K, fin);
+    const unsigned grid = grid_for(m, INV_BLOCK);
+    switch (K) {
+        case 16: k_batch_invert<Fin, 16><<<grid, INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, fin); break;
+        case 8:  k_batch_invert<Fin, 8><<<grid, INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, fin); break;
+        case 4:  k_batch_invert<Fin, 4><<<grid, INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, fin); break;
+        case 2:  k_batch_invert<Fin, 2><<<grid, INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, fin); break;
+        default: k_batch_invert<Fin, 1><<<grid, INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, fin); break;
+    }
     C25519_TRY(hipGetLastError());
     return 0;
 }
