@@ -35,7 +35,17 @@ __device__ constexpr u64 SHA512_K[80] = {
     0x4cc5d4becb3e42b6ull, 0x597f299cfc657e2aull, 0x5fcb6fab3ad6faecull, 0x6c44198c4a475817ull,
 };
 
-C25519_DEV u64 rotr64(u64 x, int n) { return (x >> n) | (x << (64 - n)); }
+// 64-bit rotate right by a compile-time n (1..63) as two v_alignbit_b32 over the halves: the compiler expands the plain
+// shift-or form into a 64-bit right shift, a left shift and one or two ORs (four instructions per rotate, ten rotates
+// per round)
+C25519_DEV u64 rotr64(u64 x, int n)
+{
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    if (n == 32) return ((u64)lo << 32) | hi;
+    const u32 a = n < 32 ? lo : hi, b = n < 32 ? hi : lo;    // rotate (b:a) right by n mod 32
+    const int r = n & 31;
+    return ((u64)alignbit32(a, b, r) << 32) | alignbit32(b, a, r);
+}
 
 // big-endian 64-bit word from two little-endian 32-bit words as they sit in memory
 C25519_DEV u64 be64_from_le32(u32 lo_addr_word, u32 hi_addr_word)
