@@ -96,7 +96,7 @@ def measured_traffic(kernels):
         with open(path) as f:
             d = json.load(f)
         def rec(name):                      # rocprof prints template kernels as "void name<...>"
-            hits = [v for k, v in d.items() if name in k and "<true>" not in k]
+            hits = [v for k, v in d.items() if name.rstrip(">") in k and "<true>" not in k]   # "<FinishPack>" matches "<FinishPack, 16>"
             return hits[0]
         total = sum((2.0 * rec(k)["FETCH_SIZE"] + rec(k)["WRITE_SIZE"]) * 1024 for k in kernels)
         return int(total), os.path.basename(path)
