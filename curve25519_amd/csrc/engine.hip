@@ -370,63 +370,125 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VC_WAVES) k_ed25519_verify_ch
     verify_check_lane(scr, n, i, sig, pkw, msgs, tbl, lds_tbl);
 }
 
-// ---- the lattice fast path (verify_fast.cuh): three kernels over the same 256-element workgroups ------------------------
-// per-element hand-over between them, struct-of-arrays: sigma[8], rho[5], tau[5] (biased), flag word
+// ---- the lattice fast path (verify_fast.cuh) ---------------------------------------------------------------------------
+// Five kernels.  scalars -> decode -> tables -> walk decide every element whose key is on the curve (and whose short
+// vector fits the walk: a random one practically always does); the elements they cannot decide are collected in a list
+// and k_ed25519_verify_slow runs the reference's own operation order for exactly those.
+// Per-element hand-over, struct-of-arrays: sigma_cols[8] (the 32 column bytes of sigma), rho[5], tau[5] (biased),
+// the decoded points (affine limbs of +-Q and of -R), a flag word
 //   bit 0  R decodes canonically onto the curve      bit 1  the key is on the curve
 //   bit 2  the short vector fits the walk             bit 3  tau < 0
+//   bit 4  the element is on the slow list            bits 8..13  top nonzero digit of the element's scalars
 struct FastScratch {
     u32 *tables;            // per lane: window table of +-Q, then of -R (2 x WTABLE_WORDS, lane-contiguous)
     u32 *sigma, *rho, *tau, *flags;
-    u32 *wg_slow;           // per workgroup: some element needs the reference-order path
+    u32 *qx, *qy, *rx, *ry; // decoded points (the projective-result slots of the reference-order path, unused here)
+    u32 *slow_list;         // indices of the elements the reference-order kernel has to decide ...
+    u32 *slow_count;        // ... and how many
+    u32 *slow_report;       // a word that outlives the call's scratch: the count again, for c25519_amd_verify_last_slow_elements
 };
 constexpr size_t FAST_TABLE_WORDS = 2 * WTABLE_WORDS;
 constexpr int FS_BLOCK = 256;
+constexpr u32 FLAG_R_OK = 1u, FLAG_KEY_OK = 2u, FLAG_FITS = 4u, FLAG_TAU_NEG = 8u, FLAG_SLOW = 16u;
 #ifndef C25519_VW_WAVES
-#define C25519_VW_WAVES 2            // waves per SIMD the register allocator aims at: the walk ...
+#define C25519_VW_WAVES 3            // waves per SIMD the register allocator aims at: the walk ...
 #endif
-#ifndef C25519_VP_WAVES
-#define C25519_VP_WAVES 2            // ... and the point decoding / table kernel
+#ifndef C25519_VD_WAVES
+#define C25519_VD_WAVES 4            // ... the point decoding (two square roots per element) ...
+#endif
+#ifndef C25519_VT_WAVES
+#define C25519_VT_WAVES 2            // ... and the table kernel
 #endif
 
-// step 1: hash, short lattice vector, sigma -- integer work only (few registers, eight waves per SIMD)
+// step 1: hash, short lattice vector, sigma -- integer work only
 __global__ void __launch_bounds__(FS_BLOCK) k_ed25519_verify_fast_scalars(FastScratch fs, const void* sig, const void* pk,
                                                                           Msgs msgs, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (i == 0) *fs.slow_count = 0;
     if (i >= n) return;
-    u32 pkw[8], Rw[8], Sw[8], sigma[8], rho[5], tau[5], tau_neg;
+    u32 pkw[8], Rw[8], Sw[8], cols[8], rho[5], tau[5], tau_neg;
     load32(pkw, pk, i);
     load32(Rw, sig, 2 * i);
     load32(Sw, sig, 2 * i + 1);
-    const u32 lat_ok = ed_verify_fast_scalars(sigma, rho, tau, tau_neg, pkw, Rw, Sw, msgs.ptr(i), msgs.len(i));
-    soa_store8(fs.sigma, n, i, sigma);
+    const u32 lat_ok = ed_verify_fast_scalars(cols, rho, tau, tau_neg, pkw, Rw, Sw, msgs.ptr(i), msgs.len(i));
+    soa_store8(fs.sigma, n, i, cols);
 #pragma unroll
     for (int w = 0; w < 5; w++) { fs.rho[(size_t)w * n + i] = rho[w]; fs.tau[(size_t)w * n + i] = tau[w]; }
-    fs.flags[i] = (lat_ok & 4u) | (tau_neg & 8u);
+    const int top = lat_ok ? walk_top_digit(tau, rho) : 0;
+    fs.flags[i] = (lat_ok & FLAG_FITS) | (tau_neg & FLAG_TAU_NEG) | ((u32)top << 8);
 }
 
-// step 2: decode both points, build the two window tables; decides which workgroups the fast path keeps
-__global__ void __launch_bounds__(ED_BLOCK, C25519_VP_WAVES) k_ed25519_verify_fast_points(FastScratch fs, const void* sig, const void* pk,
-                                                                             size_t n)
+// step 2: the two square roots of an element, one per lane: lane j < n decodes key j, lane n + j decodes R of signature j
+// (2n lanes of pure field arithmetic: few registers, four waves per SIMD)
+__global__ void __launch_bounds__(ED_BLOCK, C25519_VD_WAVES) k_ed25519_verify_fast_decode(FastScratch fs, const void* sig, const void* pk,
+                                                                                          size_t n)
 {
-    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
-    u32 slow = 0;
-    if (i < n) {
-        u32 pkw[8], Rw[8];
-        load32(pkw, pk, i);
-        load32(Rw, sig, 2 * i);
-        const u32 f = fs.flags[i];
-        const QTableLimbs tq{ fs.tables + i * FAST_TABLE_WORDS }, tr{ fs.tables + i * FAST_TABLE_WORDS + WTABLE_WORDS };
-        const u32 pts = ed_verify_fast_points(tq, tr, pkw, Rw, (f & 8u) ? 0xffffffffu : 0u);
-        fs.flags[i] = f | pts;
-        slow = !((f & 4u) && (pts & 2u));
+    const size_t j = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    if (j >= 2 * n) return;
+    const bool is_r = j >= n;
+    const size_t e = is_r ? j - n : j;
+    u32 w[8];
+    if (is_r) load32(w, sig, 2 * e); else load32(w, pk, e);
+    const u32 tau_neg = (fs.flags[e] & FLAG_TAU_NEG) ? 0xffffffffu : 0u;
+    fe X, Y;
+    const u32 ok = ed_verify_fast_decode(X, Y, w, is_r ? 0xffffffffu : 0u, tau_neg);
+    soa_store_fe(is_r ? fs.rx : fs.qx, n, e, X);
+    soa_store_fe(is_r ? fs.ry : fs.qy, n, e, Y);
+    if (ok) atomicOr(&fs.flags[e], is_r ? FLAG_R_OK : FLAG_KEY_OK);
+}
+
+// step 3: the window tables, one per lane like the square roots (lane j < n: +-Q of element j, lane n + j: its -R);
+// elements the walk cannot decide get no tables and go on the slow list
+__global__ void __launch_bounds__(ED_BLOCK, C25519_VT_WAVES) k_ed25519_verify_fast_tables(FastScratch fs, size_t n)
+{
+    const size_t j = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    if (j >= 2 * n) return;
+    const bool is_r = j >= n;
+    const size_t e = is_r ? j - n : j;
+    const u32 f = fs.flags[e];
+    if (!((f & FLAG_FITS) && (f & FLAG_KEY_OK))) {
+        if (!is_r) {
+            atomicOr(&fs.flags[e], FLAG_SLOW);                        // (the R lane of this element may be reading the word)
+            fs.slow_list[atomicAdd(fs.slow_count, 1u)] = (u32)e;      // (the compiler aggregates this per wave)
+        }
+        return;
     }
-    const int any_slow = __syncthreads_or(slow != 0);
-    if (threadIdx.x == 0) fs.wg_slow[blockIdx.x] = any_slow ? 1u : 0u;
+    fe X, Y;
+    soa_load_fe(X, is_r ? fs.rx : fs.qx, n, e);
+    soa_load_fe(Y, is_r ? fs.ry : fs.qy, n, e);
+    const QTableLimbs tbl{ fs.tables + e * FAST_TABLE_WORDS + (is_r ? WTABLE_WORDS : 0) };
+    wtable_build(tbl, X, Y);
+}
+
+// step 4: the walk and the neutral-element test.  Nothing but the accumulator point lives in registers across a digit
+// round (the scalars are fetched a word at a time), which is what lets four waves share a SIMD like in the ladder.
+__global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fast_walk(FastScratch fs, int* verdict, size_t n,
+                                                                                        const u32* __restrict__ g_tbl)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
+    lds_stage_words(lds_tbl, g_tbl + REF_TBL_OFFSET, REF_TBL_WORDS);
+    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    const u32 f = i < n ? fs.flags[i] : FLAG_SLOW;
+    const bool walks = !(f & FLAG_SLOW);
+    // the wave walks from its longest element's first digit (the others' digits above their own are zero)
+    int top = walks ? (int)((f >> 8) & 63u) : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int other = __shfl_xor(top, o);
+        top = other > top ? other : top;
+    }
+    top = __builtin_amdgcn_readfirstlane(top);           // wave-uniform by construction: let the walk's loops be scalar ones
+    if (!walks) return;
+    const size_t base = i * FAST_TABLE_WORDS;
+    const QTableLimbs tq{ fs.tables + base }, tr{ fs.tables + base + WTABLE_WORDS };
+    const WalkScalars sc{ fs.sigma, fs.tau, fs.rho, n, i };
+    const u32 neutral = ge_walk_is_neutral(sc, tq, tr, lds_tbl, top < 8 ? 8 : top);
+    verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
 }
 
 // the reference-order path for one element, start to finish (own table, own inversion): what ed25519_VerifySignature does
-// (ed25519_verify.c:163-176 = Verify_Init + Verify_Check), used for the workgroups the fast path gives up
+// (ed25519_verify.c:163-176 = Verify_Init + Verify_Check)
 C25519_DEV int verify_reference_order_lane(const u32 (&pkw)[8], const void* sig, size_t i, const uint8_t* msg, size_t len,
                                            u32* lane_table, const u32* lds_tbl)
 {
@@ -451,45 +513,24 @@ C25519_DEV int verify_reference_order_lane(const u32 (&pkw)[8], const void* sig,
     return diff == 0 ? 1 : 0;
 }
 
-// step 3: the 140-doubling walk and the neutral-element test -- or, for a workgroup with an off-curve key or an
-// over-long vector among its 256 elements (about six workgroups per 2^20 valid signatures), the reference's own
-// operation order for all of them, in the same launch: behind the walk, in launches of their own, those few workgroups
-// run alone at single-wave issue speed and their latency (0.4 ms per kernel) is paid in full; here it hides under the
-// other workgroups' walks.
-__global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fast_walk(FastScratch fs, int* verdict, const void* sig,
-                                                                           const void* pk, Msgs msgs, size_t n,
-                                                                           const u32* __restrict__ g_tbl)
+// step 5: the elements on the slow list (off-curve keys -- the reference does not reject them, so neither may we -- and
+// the practically nonexistent over-long vectors), one per lane, in the reference's order.  Launched over the whole grid:
+// workgroups beyond the list's end leave at once.  It runs on the thread's side stream beside the walk, whose lanes
+// skip the listed elements, so a few garbage keys in a batch cost no time at all.
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_slow(FastScratch fs, int* verdict, const void* sig, const void* pk,
+                                                                     Msgs msgs, const u32* __restrict__ g_tbl)
 {
+    const u32 count = *fs.slow_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *fs.slow_report = count;
+    if ((size_t)blockIdx.x * ED_BLOCK >= count) return;
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
     lds_stage_words(lds_tbl, g_tbl + REF_TBL_OFFSET, REF_TBL_WORDS);
-    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
-    const bool valid = i < n;
-    u32* lane_tables = fs.tables + (valid ? i : 0) * FAST_TABLE_WORDS;
-    if (fs.wg_slow[blockIdx.x]) {                              // uniform over the workgroup
-        if (!valid) return;
-        u32 pkw[8];
-        load32(pkw, pk, i);
-        verdict[i] = verify_reference_order_lane(pkw, sig, i, msgs.ptr(i), msgs.len(i), lane_tables, lds_tbl);
-        return;
-    }
-    u32 sigma[8] = {}, rho[5] = {}, tau[5] = {};
-    int top = 0;
-    if (valid) {
-        soa_load8(sigma, fs.sigma, n, i);
-#pragma unroll
-        for (int w = 0; w < 5; w++) { rho[w] = fs.rho[(size_t)w * n + i]; tau[w] = fs.tau[(size_t)w * n + i]; }
-        top = walk_top_digit(tau, rho);
-    }
-    // the wave walks from its longest element's first digit (the others' digits above their own are zero)
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const int other = __shfl_xor(top, o);
-        top = other > top ? other : top;
-    }
-    if (!valid) return;
-    const QTableLimbs tq{ lane_tables }, tr{ lane_tables + WTABLE_WORDS };
-    const u32 neutral = ge_walk_is_neutral(sigma, tau, rho, tq, tr, lds_tbl, top < 8 ? 8 : top);
-    verdict[i] = (neutral & fs.flags[i] & 1u) ? 1 : 0;
+    const size_t k = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    if (k >= count) return;
+    const size_t i = fs.slow_list[k];
+    u32 pkw[8];
+    load32(pkw, pk, i);
+    verdict[i] = verify_reference_order_lane(pkw, sig, i, msgs.ptr(i), msgs.len(i), fs.tables + i * FAST_TABLE_WORDS, lds_tbl);
 }
 
 // Same check with ONE key for the whole batch (the reference's two-phase use: Verify_Init once, many
@@ -989,24 +1030,27 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
 }
 
 // scratch of one verification pass: per-lane tables (the larger of the two paths' formats: they never live at the same
-// time for one workgroup), projective results of the reference-order path, the fast path's scalars and flags
+// time for one element), projective results of the reference-order path (the fast path keeps its decoded points there),
+// the fast path's scalars, flags and slow list
 constexpr size_t VERIFY_TABLE_WORDS = FAST_TABLE_WORDS > QTABLE_LIMB_WORDS ? FAST_TABLE_WORDS : QTABLE_LIMB_WORDS;
-inline size_t verify_scalar_words(size_t n) { return round_up(8 * n, 4) + 2 * round_up(5 * n, 4) + round_up(n, 4) + round_up(grid_for(n, ED_BLOCK), 4); }
+inline size_t verify_scalar_words(size_t n) { return round_up(8 * n, 4) + 2 * round_up(5 * n, 4) + 2 * round_up(n, 4) + 4; }
 inline size_t verify_scratch_bytes(size_t n)
 {
     return (n * VERIFY_TABLE_WORDS + proj_words(n) + verify_scalar_words(n)) * sizeof(u32);
 }
 
-// fast = true: the lattice path (verify_fast.cuh) decides every workgroup whose keys are all on the curve and whose
-// short vectors fit; the others run the reference's order inside the same walk kernel.  fast = false: reference order
-// for everything in its own kernels, and Fin decides what leaves it: the verdict, or enc(T) for the test hook.
-// where the calling thread's last fast-path verification left its per-workgroup flags (c25519_amd_verify_last_slow_groups)
-struct LastVerify { const u32* wg_slow = nullptr; unsigned groups = 0; hipStream_t stream = nullptr; int device = -1; const ThreadState::WorkSlab* slab = nullptr; };
+// fast = true: the lattice path (verify_fast.cuh) decides every element whose key is on the curve and whose short vector
+// fits; the reference's order runs for the others in a kernel of its own, on the thread's side stream beside the walk
+// (C25519_AMD_VERIFY_NO_SIDE_STREAM=1: behind it on the caller's stream).  fast = false: reference order for everything,
+// and Fin decides what leaves it: the verdict, or enc(T) for the test hook.
+// what the calling thread's last fast-path verification left behind for c25519_amd_verify_last_slow_elements
+struct LastVerify { const u32* count = nullptr; hipStream_t stream = nullptr; int device = -1; };
 thread_local LastVerify tl_last_verify;
 
 template <typename MakeFin>
 int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t stream, int* verdict, bool fast, MakeFin make_fin)
 {
+    static const bool side_ok = getenv("C25519_AMD_VERIFY_NO_SIDE_STREAM") == nullptr;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
@@ -1015,22 +1059,42 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
     u32* tables = (u32*)w + proj_words(n);
     const unsigned grid = grid_for(n, ED_BLOCK);
     if (fast) {
+        ThreadState::Side* side = nullptr;
+        C25519_RC(tls().side_for_current_device(&side));
         FastScratch fs;
         fs.tables = tables;
         fs.sigma = tables + n * VERIFY_TABLE_WORDS;
         fs.rho = fs.sigma + round_up(8 * n, 4);
         fs.tau = fs.rho + round_up(5 * n, 4);
         fs.flags = fs.tau + round_up(5 * n, 4);
-        fs.wg_slow = fs.flags + round_up(n, 4);
+        fs.slow_list = fs.flags + round_up(n, 4);
+        fs.slow_count = fs.slow_list + round_up(n, 4);
+        fs.slow_report = side->counter;
+        fs.qx = scr.a; fs.qy = scr.b; fs.rx = scr.z; fs.ry = scr.prefix;
         k_ed25519_verify_fast_scalars<<<grid_for(n, FS_BLOCK), FS_BLOCK, 0, stream>>>(fs, sig, pk, msgs, n);
         C25519_TRY(hipGetLastError());
-        k_ed25519_verify_fast_points<<<grid, ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
+        k_ed25519_verify_fast_decode<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
         C25519_TRY(hipGetLastError());
-        k_ed25519_verify_fast_walk<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, n, tbl);
+        k_ed25519_verify_fast_tables<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, n);
         C25519_TRY(hipGetLastError());
-        tl_last_verify.wg_slow = fs.wg_slow; tl_last_verify.groups = grid; tl_last_verify.stream = stream;
+        const bool fork = side_ok && side->stream != stream;
+        if (fork) {                                   // the slow list's kernel beside the walk, joined behind it
+            C25519_TRY(hipEventRecord(side->fork, stream));
+            C25519_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
+            k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, side->stream>>>(fs, verdict, sig, pk, msgs, tbl);
+            C25519_TRY(hipGetLastError());
+            C25519_TRY(hipEventRecord(side->join, side->stream));
+        }
+        k_ed25519_verify_fast_walk<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
+        C25519_TRY(hipGetLastError());
+        if (fork) {
+            C25519_TRY(hipStreamWaitEvent(stream, side->join, 0));
+        } else {
+            k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
+            C25519_TRY(hipGetLastError());
+        }
+        tl_last_verify.count = side->counter; tl_last_verify.stream = stream;
         (void)hipGetDevice(&tl_last_verify.device);
-        tl_last_verify.slab = tls().slab_for(stream, tl_last_verify.device);
         return tls().release_work(stream);
     }
     tl_last_verify = LastVerify();
@@ -1237,23 +1301,17 @@ int c25519_amd_verify_point_dev(void* out, const void* sig, const void* pk, cons
                       [&](const ProjScratch& scr) { return FinishPack{ scr.a, scr.b, out, n, 1, 0, nullptr, 0, 0 }; });
 }
 
-// how many 256-element workgroups of the calling thread's last ed25519_VerifySignature_* call on this device went through
-// the reference-order kernels instead of the lattice path (-1: no fast-path verification to report).  Synchronises.
-long c25519_amd_verify_last_slow_groups(void)
+// how many elements of the calling thread's last ed25519_VerifySignature_* call on this device went through the
+// reference-order kernel instead of the lattice path (-1: no fast-path verification to report).  Synchronises.
+long c25519_amd_verify_last_slow_elements(void)
 {
     const LastVerify& lv = tl_last_verify;
     int dev = -1;
-    if (!lv.wg_slow || hipGetDevice(&dev) != hipSuccess || dev != lv.device) return -1;
-    {   // the flags live in one of the thread's work slabs: stale if that slab has been released or regrown since
-        const char* lo = lv.slab ? (const char*)lv.slab->ptr : nullptr;
-        if (!lo || (const char*)lv.wg_slow < lo || (const char*)(lv.wg_slow + lv.groups) > lo + lv.slab->cap) return -1;
-    }
+    if (!lv.count || hipGetDevice(&dev) != hipSuccess || dev != lv.device) return -1;
     if (hipStreamSynchronize(lv.stream) != hipSuccess) return -1;
-    std::vector<u32> flags(lv.groups);
-    if (hipMemcpy(flags.data(), lv.wg_slow, sizeof(u32) * lv.groups, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    long c = 0;
-    for (u32 f : flags) c += f != 0;
-    return c;
+    u32 c = 0;
+    if (hipMemcpy(&c, lv.count, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long)c;
 }
 
 int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, const void* msg, size_t msg_size,

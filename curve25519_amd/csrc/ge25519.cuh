@@ -136,19 +136,24 @@ C25519_DEV u32 ge_calc_x_checked(fe& X, const fe& Y, u32 parity)
     fe u, v, a, b, t;
     fe one;
     fe_set_u32(one, 1);
+    {
+        fe_sqr(u, Y);
+        fe_mul(v, u, fe_const(K_D));
+        fe_sub(t, u, one);  fe_carry32(u, t);            // u = y^2 - 1, reduced
+        v.v[0] += 1;                                     // v = d y^2 + 1
+        fe_sqr(b, v);
+        fe_mul(a, u, b);
+        fe_mul(a, a, v);                                 // a = u v^3
+        fe_sqr(b, b);                                    // v^4
+        fe_mul(b, a, b);                                 // u v^7
+    }
+    fe_pow2523(b, b);                                    // only y and a live across the 251 squarings: u and v are
+    fe_mul(X, b, a);                                     // rebuilt below (1 S + 1 M) instead of holding twenty registers
+
     fe_sqr(u, Y);
     fe_mul(v, u, fe_const(K_D));
-    fe_sub(t, u, one);  fe_carry32(u, t);            // u = y^2 - 1, reduced
-    v.v[0] += 1;                                     // v = d y^2 + 1
-
-    fe_sqr(b, v);
-    fe_mul(a, u, b);
-    fe_mul(a, a, v);                                 // a = u v^3
-    fe_sqr(b, b);                                    // v^4
-    fe_mul(b, a, b);                                 // u v^7
-    fe_pow2523(b, b);
-    fe_mul(X, b, a);
-
+    fe_sub(t, u, one);  fe_carry32(u, t);
+    v.v[0] += 1;
     fe_sqr(b, X);                                    // is v x^2 == u ?
     fe_mul(b, b, v);                                 // c = v x^2, reduced
     fe_add(a, b, u);                                 // c + u: zero iff x*sqrt(-1) is the root

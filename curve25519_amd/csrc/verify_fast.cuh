@@ -7,12 +7,12 @@
 // {(rho, tau): tau = rho*h mod 8L}.  E(F_p) has order 8L, so [rho*h]Q = [tau]Q for ANY curve point Q, torsion included,
 // and if rho is odd (and 0 < rho < L) then gcd(rho, 8L) = 1 and multiplication by rho is a bijection of the group:
 //         T == R   <=>   [rho](s*B + h*Q - R) == O   <=>   [rho*s mod L]B + [tau]Q + [rho](-R) == O
-// with rho, tau of ~128 bits: 140 doublings instead of 255.  When Q is on the curve the reference's own formulas are
+// with rho, tau of ~128 bits: ~134 doublings instead of 255.  When Q is on the curve the reference's own formulas are
 // the complete group law (a = -1 is a square, d is not), so its T is the group's T, and enc() is injective on curve
 // points: "R bytes decode canonically to a curve point R and the right-hand side holds" IS the reference's verdict,
 // for every s (S >= L included: B has order L) and every torsion component of A or R.  Everything else -- a key that
 // does not decompress onto the curve, a lattice vector longer than the walk's capacity -- is left to the
-// reference-order path (k_ed25519_verify_init / _check), selected per workgroup.
+// reference-order path (k_ed25519_verify_slow), selected per element.
 // Public data only: nothing here needs to be constant-time.
 #pragma once
 #include "ge25519.cuh"
@@ -32,7 +32,9 @@ namespace c25519 {
 //   * exact shift-subtract steps finish: until the smaller remainder is below 2^128, and then the other vector only
 //     until its remainder is below 2^129, which keeps its cofactor as short as the lattice allows.
 // Whatever comes out is checked (odd, short enough) before it is used.
-constexpr int LAT_CAP_BITS = 142;          // what the 36-digit signed walk can take (a random h exceeds it with p ~ 6e-6: measured, 6 of 2^20)
+constexpr int LAT_CAP_BITS = 158;          // what the 40-digit signed walk can take.  The typical vector has 127-131 bits; the tail halves per
+                                            // bit (142 bits, round 2's capacity, was exceeded by 6 random h in 2^20), so a random h practically
+                                            // never asks for the reference-order path; a wave walks from ITS longest vector's top digit anyway
 #ifndef C25519_LAT_COUNT
 #define C25519_LAT_COUNT(what)          // the host emulation counts loop trips here (tests/host_emul)
 #endif
@@ -311,67 +313,61 @@ C25519_DEV void sc_mul_short(u32 (&sigma)[8], const u32 (&rho)[5], const u32 (&s
 }
 
 // ---- signed radix-16 digits ----------------------------------------------------------------------------------------------
-constexpr int WALK_DIGITS = 36;             // 36 digits in [-8, 7] cover magnitudes below 2^142
-// k + 0x888...8 (36 nibbles): nibble i of the sum, minus 8, is the signed digit d_i in [-8, 7] with k = sum d_i 16^i,
-// so digits can be read most-significant first without a carry chain.  k < 2^142.
+constexpr int WALK_DIGITS = 40;             // 40 digits in [-8, 7] cover magnitudes below 2^158 (five 32-bit words of nibbles)
+// k + 0x888...8 (40 nibbles): nibble i of the sum, minus 8, is the signed digit d_i in [-8, 7] with k = sum d_i 16^i,
+// so digits can be read most-significant first without a carry chain.  k < 2^158: the sum stays below 2^160.
 C25519_DEV void bias_signed16(u32 (&kb)[5], const u32 (&k)[5])
 {
-    const u32 bias[5] = { 0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u, 0x00008888u };
     u64 c = 0;
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-        c += (u64)k[i] + bias[i];
+        c += (u64)k[i] + 0x88888888u;
         kb[i] = (u32)c;
         c >>= 32;
     }
 }
-// digit i of a biased scalar: |d_i| in 0..8 and all-ones if d_i < 0
-C25519_DEV u32 signed16_at(u32& negative, const u32 (&kb)[5], int i)
+// digit `nib` (0..7) of one word of a biased scalar: |d| in 0..8 and all-ones if d < 0
+C25519_DEV u32 signed16_of(u32& negative, u32 word, int nib)
 {
-    u32 w = kb[0];
-#pragma unroll
-    for (int t = 1; t < 5; t++) w = ((i >> 3) == t) ? kb[t] : w;
-    const u32 nib = (w >> (4 * (i & 7))) & 15u;
-    negative = nib < 8u ? 0xffffffffu : 0u;
-    return nib < 8u ? 8u - nib : nib - 8u;
+    const u32 v = (word >> (4 * nib)) & 15u;
+    negative = v < 8u ? 0xffffffffu : 0u;
+    return v < 8u ? 8u - v : v - 8u;
 }
 
 // index of the most significant nonzero signed digit of either biased scalar (0 if there is none): nibbles that still
 // equal the bias' 8 are zero digits
 C25519_DEV int walk_top_digit(const u32 (&tau_b)[5], const u32 (&rho_b)[5])
 {
-    const u32 bias[5] = { 0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u, 0x00008888u };
     int top = 0;
 #pragma unroll
     for (int w = 0; w < 5; w++) {
-        const u32 v = (tau_b[w] ^ bias[w]) | (rho_b[w] ^ bias[w]);
+        const u32 v = (tau_b[w] ^ 0x88888888u) | (rho_b[w] ^ 0x88888888u);
         top = v ? 8 * w + ((31 - __builtin_clz(v)) >> 2) : top;
     }
-    return top < WALK_DIGITS ? top : WALK_DIGITS - 1;
+    return top;
+}
+
+// the 32 8-fold columns of sigma, one byte each, in walk order: byte n (of word n >> 2) = bit (31 - n) of every word
+// (ecp_8Folds, curve25519_utils.c:144-153).  The walk reads one word per digit round instead of holding all of sigma.
+C25519_DEV void sc_fold8_columns(u32 (&cols)[8], const u32 (&k)[8])
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        u32 w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) w |= fold8_at(k, 4 * q + b) << (8 * b);
+        cols[q] = w;
+    }
 }
 
 // ---- per-lane window tables: rows 0..8 = 0, P, 2P, ..., 8P in PE form ---------------------------------------------------------
 constexpr int WTABLE_ROWS = 9;
 constexpr size_t WTABLE_WORDS = WTABLE_ROWS * PE_WORDS;   // 360 words = 1440 bytes per table
 
+// (x, y) affine.  P's own row is re-read from the table for the three "+ P" steps (ge_add_pe_row below), so only two
+// extended points live in registers: 2P, then 3P, 6P, 7P, then 4P, 5P, 8P.
 template <typename Tbl>
-C25519_DEV void wtable_build(const Tbl& tbl, const ge_ext& P)
-{
-    ge_pe pe, p1;
-    fe_set_u32(pe.ypx, 1); fe_set_u32(pe.ymx, 1); fe_set_u32(pe.t2d, 0); fe_set_u32(pe.z2, 2);
-    tbl.store(0, pe);
-    ge_to_pe(p1, P);
-    tbl.store(1, p1);
-    // order chosen to keep at most two extended points alive beside p1: 2P, (3P, 6P, 7P), then (4P, 5P, 8P)
-    ge_ext P2 = P, U, t;
-    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(2, pe);
-    ge_add_pe<true>(U, P2, p1);     ge_to_pe(pe, U);  tbl.store(3, pe);
-    ge_double<true>(U);             ge_to_pe(pe, U);  tbl.store(6, pe);
-    ge_add_pe<true>(t, U, p1);      ge_to_pe(pe, t);  tbl.store(7, pe);
-    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(4, pe);
-    ge_add_pe<true>(t, P2, p1);     ge_to_pe(pe, t);  tbl.store(5, pe);
-    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(8, pe);
-}
+C25519_DEV void wtable_build(const Tbl& tbl, const fe& x, const fe& y);
 
 // q <- -q when neg is all-ones: swap Y+X and Y-X, negate 2dT
 C25519_DEV void pe_cond_neg(ge_pe& q, u32 neg)
@@ -386,8 +382,9 @@ C25519_DEV void pe_cond_neg(ge_pe& q, u32 neg)
 
 // S += (neg ? -row : row), the row read from memory one field at a time, each right before the product that consumes it:
 // a whole row in registers (40) on top of the accumulator (40) and the addition's temporaries is what pushes the walk
-// over the register budget of three waves per SIMD.  Negation is free here: -q swaps Y+X and Y-X (two base offsets)
-// and negates 2dT (ten subtractions), instead of thirty selects on a loaded row.
+// over the register budget.  Negation is free here: -q swaps Y+X and Y-X (two base offsets) and negates 2dT (ten
+// subtractions), instead of thirty selects on a loaded row.  The sums B-A, B+A are formed as soon as A and B exist and
+// D-C, D+C as soon as C and D do, so at most four temporaries live beside the accumulator.
 C25519_DEV void load_fe_words(fe& f, const u32* p)
 {
 #pragma unroll
@@ -398,100 +395,134 @@ C25519_DEV void ge_add_pe_row(ge_ext& S, const u32* row, u32 neg)
 {
     const u32* p_ypx = row + (neg ? 10 : 0);        // field that multiplies Y+X
     const u32* p_ymx = row + (neg ? 0 : 10);        // field that multiplies Y-X
-    fe q, a, b, c, d, e, f, g, h;
+    fe q, a, b, e, f, g, h;
     fe_sub(a, S.Y, S.X);
     load_fe_words(q, p_ymx);
     fe_mul(a, a, q);
     fe_add(b, S.Y, S.X);
     load_fe_words(q, p_ypx);
     fe_mul(b, b, q);
-    load_fe_words(q, row + 20);
-    fe_neg(c, q);                                    // 2p - t2d: beta 2, fine as the second operand of a product
-    fe_select(q, neg, c, q);
-    fe_mul(c, S.T, q);
-    load_fe_words(q, row + 30);
-    fe_mul(d, S.Z, q);
     fe_sub(e, b, a);
     fe_add(h, b, a);
-    fe_sub(f, d, c);
-    fe_add(g, d, c);
+    load_fe_words(q, row + 20);
+    fe_neg(a, q);                                    // 2p - t2d: beta 2, fine as the second operand of a product
+    fe_select(q, neg, a, q);
+    fe_mul(a, S.T, q);                               // C
+    load_fe_words(q, row + 30);
+    fe_mul(b, S.Z, q);                               // D
+    fe_sub(f, b, a);
+    fe_add(g, b, a);
     fe_mul(S.X, e, f);
-    fe_mul(S.Y, g, h);
     if (NEED_T) fe_mul(S.T, e, h);
     fe_mul(S.Z, f, g);
+    fe_mul(S.Y, g, h);
 }
 
-// ---- decoding the two points ---------------------------------------------------------------------------------------------
-// y from 32 bytes with bit 255 stripped; x with the requested parity.  Returns all-ones iff (x, y) is on the curve.
-// want_canonical additionally requires y < p and a sign bit that an encoder would have produced (x = 0 has sign 0).
-C25519_DEV u32 ge_decode_checked(ge_ext& P, const u32 (&w)[8], u32 parity_flip, bool want_canonical)
+// S += row r of the limb-major LDS base table ([30][256] words), one field at a time like ge_add_pe_row.  need_t is a
+// run-time (wave-uniform) flag on purpose: ONE copy of the addition in the walk's loop keeps the register allocation
+// at 154 VGPRs (three waves per SIMD, no spills); the two template instances of ge_add_pa cost 182.
+C25519_DEV void ge_add_pa_lds(ge_ext& S, const u32* tbl, u32 r, bool need_t)
 {
-    u32 yw[8], cw[8];
+    fe q, a, b, e, f, g, h;
+    fe_sub(a, S.Y, S.X);
 #pragma unroll
-    for (int i = 0; i < 8; i++) yw[i] = w[i];
-    const u32 sign = yw[7] >> 31;
-    yw[7] &= 0x7fffffffu;
-    fe_from_words(P.Y, yw);
-    u32 ok = ge_calc_x_checked(P.X, P.Y, sign ^ parity_flip);
-    if (want_canonical) {
-        fe_to_words(cw, P.Y);
-        u32 diff = 0;
+    for (int i = 0; i < 10; i++) q.v[i] = tbl[(10 + i) * 256 + r];
+    fe_mul(a, a, q);
+    fe_add(b, S.Y, S.X);
 #pragma unroll
-        for (int i = 0; i < 8; i++) diff |= cw[i] ^ yw[i];
-        fe_to_words(cw, P.X);
-        ok &= (diff == 0 && ((cw[0] ^ sign ^ parity_flip) & 1u) == 0) ? 0xffffffffu : 0u;
-    }
-    fe_mul(P.T, P.X, P.Y);
-    fe_set_u32(P.Z, 1);
-    return ok;
+    for (int i = 0; i < 10; i++) q.v[i] = tbl[i * 256 + r];
+    fe_mul(b, b, q);
+    fe_sub(e, b, a);
+    fe_add(h, b, a);
+#pragma unroll
+    for (int i = 0; i < 10; i++) q.v[i] = tbl[(20 + i) * 256 + r];
+    fe_mul(a, S.T, q);                               // C
+    fe_add(b, S.Z, S.Z);                             // D
+    fe_sub(f, b, a);
+    fe_add(g, b, a);
+    fe_mul(S.X, f, e);
+    if (need_t) fe_mul(S.T, e, h);
+    fe_mul(S.Z, f, g);
+    fe_mul(S.Y, g, h);
+}
+
+template <typename Tbl>
+C25519_DEV void wtable_build(const Tbl& tbl, const fe& x, const fe& y)
+{
+    ge_pe pe;
+    ge_ext P2, U;
+    fe_set_u32(pe.ypx, 1); fe_set_u32(pe.ymx, 1); fe_set_u32(pe.t2d, 0); fe_set_u32(pe.z2, 2);
+    tbl.store(0, pe);
+    P2.X = x; P2.Y = y;
+    fe_mul(P2.T, x, y);
+    fe_set_u32(P2.Z, 1);
+    ge_to_pe(pe, P2);               tbl.store(1, pe);
+    const u32* row1 = tbl.base + PE_WORDS;
+    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(2, pe);
+    U = P2;
+    ge_add_pe_row<true>(U, row1, 0u);   ge_to_pe(pe, U);  tbl.store(3, pe);
+    ge_double<true>(U);             ge_to_pe(pe, U);  tbl.store(6, pe);
+    ge_add_pe_row<true>(U, row1, 0u);   ge_to_pe(pe, U);  tbl.store(7, pe);
+    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(4, pe);
+    U = P2;
+    ge_add_pe_row<true>(U, row1, 0u);   ge_to_pe(pe, U);  tbl.store(5, pe);
+    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(8, pe);
 }
 
 // ---- the walk ----------------------------------------------------------------------------------------------------------
+// Where a lane's scalars live while it walks: struct-of-arrays scratch written by the scalars kernel (word w of element i
+// at base[w * n + i]; the host emulation passes n = 1, i = 0).  The walk fetches ONE word of each per digit round -- the
+// round's nibble of tau and rho, the round's four column bytes of sigma -- instead of holding 18 words in registers.
+struct WalkScalars {
+    const u32 *sigma_cols, *tau, *rho;
+    size_t n, i;
+    C25519_DEV u32 tau_word(int w) const { return tau[(size_t)w * n + i]; }
+    C25519_DEV u32 rho_word(int w) const { return rho[(size_t)w * n + i]; }
+    C25519_DEV u32 sigma_word(int w) const { return sigma_cols[(size_t)w * n + i]; }
+};
+
 // W = sigma*B + tau*Q + rho*Rn from the two window tables (Q and Rn = -R already carry the signs of tau and of the
 // equation), the biased scalars and the LDS base table; returns all-ones iff W is the neutral element.
 // `top`: the walk starts at this digit; every digit above it must be zero in both scalars, and top >= 8 (sigma's columns
 // ride the last eight digits).  The kernels pass the maximum of walk_top_digit() over the wave: typical short vectors
-// have 127-131 bits, so a wave starts at digit 32 or 33 instead of 35 and saves two or three of the 36 rounds of four
-// doublings and two table additions; leading zero digits would have added the neutral row, so skipping them is exact.
+// have 127-131 bits, so a wave starts at digit 32 or 33 and walks 33-34 rounds of four doublings and two table
+// additions; leading zero digits would have added the neutral row, so skipping them is exact.
 template <typename Tbl>
-C25519_DEV u32 ge_walk_is_neutral(u32 (&sigma)[8], const u32 (&tau_b)[5], const u32 (&rho_b)[5], const Tbl& tq, const Tbl& tr,
-                                  const u32* lds_tbl, int top = WALK_DIGITS - 1)
+C25519_DEV u32 ge_walk_is_neutral(const WalkScalars& sc, const Tbl& tq, const Tbl& tr, const u32* lds_tbl, int top)
 {
     ge_ext S;
-    ge_pa pa;
     {
         ge_pe pe;
         u32 neg;
-        const u32 m = signed16_at(neg, tau_b, top);
+        const u32 m = signed16_of(neg, sc.tau_word(top >> 3), top & 7);
         tq.load(pe, m);
         pe_cond_neg(pe, neg);
         ge_from_pe(S, pe);
+        const u32 m2 = signed16_of(neg, sc.rho_word(top >> 3), top & 7);
+        ge_add_pe_row<false>(S, tr.base + (size_t)m2 * PE_WORDS, neg);
     }
-    auto add_row = [&](const Tbl& t, const u32 (&kb)[5], int i, bool need_t) {
-        u32 neg;
-        const u32 m = signed16_at(neg, kb, i);
-        if (need_t) ge_add_pe_row<true>(S, t.base + (size_t)m * PE_WORDS, neg);
-        else ge_add_pe_row<false>(S, t.base + (size_t)m * PE_WORDS, neg);
-    };
-    add_row(tr, rho_b, top, false);
     // sigma's 8-fold columns ride on the last 32 doublings (the reference's own trick, ed25519_verify.c:266-279)
 #pragma unroll 1
     for (int i = top - 1; i >= 0; i--) {
+        const u32 tw = sc.tau_word(i >> 3), rw = sc.rho_word(i >> 3);      // in flight under the doublings
         if (i >= 8) {
 #pragma unroll 1
             for (int j = 0; j < 3; j++) ge_double<false>(S);
             ge_double<true>(S);
         } else {
+            u32 cols = sc.sigma_word(7 - i);
 #pragma unroll 1
             for (int j = 0; j < 4; j++) {
                 ge_double<true>(S);
-                lds_load_pa(pa, lds_tbl, fold8_next(sigma));
-                if (j == 3) ge_add_pa<true>(S, pa);     // T feeds the key-table addition that follows
-                else ge_add_pa<false>(S, pa);           // a doubling follows: T is not read
+                ge_add_pa_lds(S, lds_tbl, cols & 255u, j == 3);      // T feeds the key-table addition that follows the last one
+                cols >>= 8;
             }
         }
-        add_row(tq, tau_b, i, true);
-        add_row(tr, rho_b, i, false);
+        u32 neg;
+        const u32 mq = signed16_of(neg, tw, i & 7);
+        ge_add_pe_row<true>(S, tq.base + (size_t)mq * PE_WORDS, neg);
+        const u32 mr = signed16_of(neg, rw, i & 7);
+        ge_add_pe_row<false>(S, tr.base + (size_t)mr * PE_WORDS, neg);
     }
     // neutral element: X == 0 and Y == Z (Z != 0 for on-curve inputs under the complete law)
     u32 xw[8], dw[8], acc = 0;
@@ -504,13 +535,14 @@ C25519_DEV u32 ge_walk_is_neutral(u32 (&sigma)[8], const u32 (&tau_b)[5], const 
     return acc == 0 ? 0xffffffffu : 0u;
 }
 
-// ---- one lane, in three steps (three kernels in engine.hip; the CPU tests chain them) ----------------------------------------
+// ---- one element, in four steps (four kernels in engine.hip; the CPU tests chain them) --------------------------------------
 // step 1, integers only: h = H(R || pk || m) mod L, the short vector, sigma = rho * s mod L.  rho and tau come back
-// BIASED (bias_signed16), ready for the walk.  Returns all-ones if the vector fits the walk.
-C25519_DEV u32 ed_verify_fast_scalars(u32 (&sigma)[8], u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative, const u32 (&pkw)[8],
+// BIASED (bias_signed16) and sigma as its 32 column bytes (sc_fold8_columns), ready for the walk.  Returns all-ones if
+// the vector fits the walk.
+C25519_DEV u32 ed_verify_fast_scalars(u32 (&sigma_cols)[8], u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative, const u32 (&pkw)[8],
                                       const u32 (&Rw)[8], const u32 (&Sw)[8], const uint8_t* msg, size_t len)
 {
-    u32 h[8];
+    u32 h[8], sigma[8];
     {
         u32 le[16];
         u64 pre[8], dg[8];
@@ -523,6 +555,7 @@ C25519_DEV u32 ed_verify_fast_scalars(u32 (&sigma)[8], u32 (&rho)[5], u32 (&tau)
     }
     const u32 lat_ok = sc_lattice_short(rho, tau, tau_negative, h);
     sc_mul_short(sigma, rho, Sw);
+    sc_fold8_columns(sigma_cols, sigma);
     u32 b[5];
     bias_signed16(b, rho);
 #pragma unroll
@@ -533,30 +566,39 @@ C25519_DEV u32 ed_verify_fast_scalars(u32 (&sigma)[8], u32 (&rho)[5], u32 (&tau)
     return lat_ok;
 }
 
-// step 2, field work: decode -A (as ed25519_Verify_Init does, :191-197) and R, build the two window tables (of +-Q by
-// the sign of tau, and of -R).  Returns bit 0: R's bytes are the canonical encoding of a curve point (otherwise the
-// reference's byte comparison cannot succeed for an on-curve key); bit 1: the key is on the curve.
-template <typename Tbl>
-C25519_DEV u32 ed_verify_fast_points(const Tbl& tq, const Tbl& tr, const u32 (&pkw)[8], const u32 (&Rw)[8], u32 tau_negative)
+// step 2, one point per call (the kernel gives the key and R of an element to two different lanes): y from the 32 bytes
+// with bit 255 stripped, x with the requested parity.
+//   is_r = 0:       the key A, decoded as -A exactly as ed25519_Verify_Init does (inverted parity, :191-197), and negated
+//                   again when tau < 0 (the walk then uses |tau| on -Q);
+//   is_r = all-ones: R, which must be the canonical encoding of a curve point (y < p and the sign bit an encoder would
+//                   have produced; otherwise the reference's byte comparison cannot succeed for an on-curve key),
+//                   negated: the walk adds rho * (-R).
+// Returns all-ones iff the point is on the curve (and, for R, canonically encoded).
+C25519_DEV u32 ed_verify_fast_decode(fe& X, fe& Y, const u32 (&w)[8], u32 is_r, u32 tau_negative)
 {
+    u32 yw[8], cw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) yw[i] = w[i];
+    const u32 sign = yw[7] >> 31;
+    yw[7] &= 0x7fffffffu;
+    fe_from_words(Y, yw);
+    const u32 parity = sign ^ (~is_r & 1u);
+    u32 ok = ge_calc_x_checked(X, Y, parity);
+    fe_to_words(cw, Y);
+    u32 diff = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) diff |= cw[i] ^ yw[i];
+    fe_to_words(cw, X);
+    const u32 canonical = (diff == 0 && ((cw[0] ^ parity) & 1u) == 0) ? 0xffffffffu : 0u;
+    ok &= ~is_r | canonical;
     fe t;
-    u32 q_ok, r_ok;
-    {
-        ge_ext Q;
-        q_ok = ge_decode_checked(Q, pkw, 1u, false);
-        fe_neg(t, Q.X); fe_carry32(t, t); fe_select(Q.X, tau_negative, t, Q.X);   // tau < 0: walk |tau| on -Q
-        fe_neg(t, Q.T); fe_carry32(t, t); fe_select(Q.T, tau_negative, t, Q.T);
-        wtable_build(tq, Q);
-    }
-    {
-        ge_ext Rn;
-        r_ok = ge_decode_checked(Rn, Rw, 0u, true);
-        fe_neg(t, Rn.X); fe_carry32(Rn.X, t);                       // Rn = -R
-        fe_neg(t, Rn.T); fe_carry32(Rn.T, t);
-        wtable_build(tr, Rn);
-    }
-    return (r_ok & 1u) | (q_ok & 2u);
+    fe_neg(t, X);
+    fe_carry32(t, t);
+    fe_select(X, is_r | tau_negative, t, X);
+    return ok;
 }
-// step 3: ge_walk_is_neutral above.
+
+// step 3: wtable_build above, once per point (the kernel gives the two tables of an element to two different lanes).
+// step 4: ge_walk_is_neutral above.
 
 }  // namespace c25519

@@ -109,13 +109,13 @@ int ed25519_VerifySignature_ragged_batch(int *verdict, const unsigned char *sig,
 int ed25519_VerifySignature_ragged_dev(void *verdict, const void *sig, const void *pk, const void *msgs,
                                        const uint64_t *offsets, size_t n, void *stream);
 
-/* ed25519_VerifySignature_* decide every 256-element workgroup whose keys all decompress onto the curve with an exact
- * lattice-shortened walk (csrc/verify_fast.cuh, 140 doublings instead of 255) and run the reference's own operation
+/* ed25519_VerifySignature_* decide every element whose key decompresses onto the curve with an exact
+ * lattice-shortened walk (csrc/verify_fast.cuh, ~134 doublings instead of 255) and run the reference's own operation
  * order only for the others (set C25519_AMD_VERIFY_REFERENCE_ORDER=1 to force it for everything).  This reports how many
- * workgroups of the calling thread's last verification on the current device took the reference-order kernels; -1 when
- * there is nothing to report (a *_batch call that was cut into pieces reports its last piece).  Synchronises with that
- * call's stream. */
-long c25519_amd_verify_last_slow_groups(void);
+ * elements of the calling thread's last verification on the current device took the reference-order kernel; -1 when
+ * there is nothing to report (a *_batch call that was cut into pieces reports one of its pieces).  Synchronises with
+ * that call's stream. */
+long c25519_amd_verify_last_slow_elements(void);
 
 /* bytes of device scratch ed25519_VerifySignature_dev needs for n elements (per-lane 4-fold tables);
  * the library allocates and caches it per host thread (about 3.1 KB per element). */

@@ -232,17 +232,25 @@ void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char*
     const u32* tbl = tables() + (size_t)REF_TBL_OFFSET;
     std::vector<u32> q(2 * WTABLE_WORDS);
     for (size_t i = 0; i < n; i++) {
-        u32 pkw[8], Rw[8], Sw[8], sigma[8], rho[5], tau[5], tau_neg;
+        u32 pkw[8], Rw[8], Sw[8], cols[8], rho[5], tau[5], tau_neg;
         rd32(pkw, pk, i);
         rd32(Rw, sig, 2 * i);
         rd32(Sw, sig, 2 * i + 1);
         const QTableLimbs tq{ q.data() }, tr{ q.data() + WTABLE_WORDS };
-        const u32 lat_ok = ed_verify_fast_scalars(sigma, rho, tau, tau_neg, pkw, Rw, Sw, msg + len * i, len);
-        const u32 pts = ed_verify_fast_points(tq, tr, pkw, Rw, tau_neg);
+        // the kernels' chain: scalars -> decode (key, then R) -> tables -> walk
+        const u32 lat_ok = ed_verify_fast_scalars(cols, rho, tau, tau_neg, pkw, Rw, Sw, msg + len * i, len);
+        fe QX, QY, RX, RY;
+        const u32 q_ok = ed_verify_fast_decode(QX, QY, pkw, 0u, tau_neg);
+        const u32 r_ok = ed_verify_fast_decode(RX, RY, Rw, 0xffffffffu, tau_neg);
+        need_slow[i] = (lat_ok && q_ok) ? 0 : 1;
+        verdict[i] = 0;
+        if (need_slow[i]) continue;                                   // the walk's lanes skip listed elements
+        wtable_build(tq, QX, QY);
+        wtable_build(tr, RX, RY);
         const int top = walk_top_digit(tau, rho);                    // a "wave" of one lane: every start digit gets exercised
-        const u32 neutral = ge_walk_is_neutral(sigma, tau, rho, tq, tr, tbl, top < 8 ? 8 : top);
-        verdict[i] = ((pts & 1u) && neutral) ? 1 : 0;
-        need_slow[i] = (lat_ok && (pts & 2u)) ? 0 : 1;
+        const WalkScalars sc{ cols, tau, rho, 1, 0 };
+        const u32 neutral = ge_walk_is_neutral(sc, tq, tr, tbl, top < 8 ? 8 : top);
+        verdict[i] = (r_ok && neutral) ? 1 : 0;
     }
 }
 

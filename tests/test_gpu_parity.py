@@ -743,13 +743,13 @@ def test_lattice_fast_path_and_reference_order_agree(api, oracle):
         if S + vectors.L < 2**256:
             bsig[i, 32:] = vectors.le(S + vectors.L, 32)
     ok = api.ed25519_VerifySignature(bsig, pub, bmsg)
-    assert L.c25519_amd_verify_last_slow_groups() == 0                  # all keys on the curve: the fast path took everything
+    assert L.c25519_amd_verify_last_slow_elements() == 0                  # all keys on the curve: the fast path took everything
     assert np.array_equal(ok, oracle.ed25519_verify(bsig, pub, bmsg, threads=THREADS)) and np.array_equal(ok == 0, bad)
     # torsion, small order, special R
     tsig, tpk, tmsg = vectors.torsion_signature_cases(count=40)
     ok = api.ed25519_VerifySignature(tsig, tpk, tmsg)
     exp = oracle.ed25519_verify(tsig, tpk, tmsg)
-    assert np.array_equal(ok, exp) and 0 < exp.sum() < len(exp) // 4 and L.c25519_amd_verify_last_slow_groups() == 0
+    assert np.array_equal(ok, exp) and 0 < exp.sum() < len(exp) // 4 and L.c25519_amd_verify_last_slow_elements() == 0
     lo = vectors.small_order_keys()
     gs, gm = synth.random_bytes((8, 64), 41), synth.random_bytes((8, 32), 42)
     assert np.array_equal(api.ed25519_VerifySignature(gs, lo, gm), oracle.ed25519_verify(gs, lo, gm))
@@ -763,7 +763,7 @@ def test_lattice_fast_path_and_reference_order_agree(api, oracle):
     off = next(k for k in gkey if vectors.ed_decode(int.from_bytes(k.tobytes(), "little") & (2**255 - 1), 0) is None)
     mixed[1000], mixed[9000] = off, off
     ok = api.ed25519_VerifySignature(bsig, mixed, bmsg)
-    assert L.c25519_amd_verify_last_slow_groups() == 2
+    assert L.c25519_amd_verify_last_slow_elements() == 2
     assert np.array_equal(ok, oracle.ed25519_verify(bsig, mixed, bmsg, threads=THREADS))
     # the same inputs with the fast path switched off give the same verdicts
     code = (
@@ -771,7 +771,7 @@ def test_lattice_fast_path_and_reference_order_agree(api, oracle):
         "from curve25519_amd import api, _lib\n"
         "d = np.load(sys.argv[1])\n"
         "ok = api.ed25519_VerifySignature(d['sig'], d['pk'], d['msg'])\n"
-        "assert _lib.load().c25519_amd_verify_last_slow_groups() == -1\n"
+        "assert _lib.load().c25519_amd_verify_last_slow_elements() == -1\n"
         "np.save(sys.argv[2], ok)\n") % ROOT
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:

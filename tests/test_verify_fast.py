@@ -54,7 +54,7 @@ def test_short_vector_properties(emul):
             continue
         r, t = int.from_bytes(rho[i].tobytes(), "little"), int.from_bytes(tau[i].tobytes(), "little")
         t = -t if neg[i] else t
-        assert r % 2 == 1 and 0 < r < 2**142 and abs(t) < 2**142, (x, r, t)
+        assert r % 2 == 1 and 0 < r < 2**158 and abs(t) < 2**158, (x, r, t)
         assert (r * x - t) % vectors.N8L == 0, (x, r, t)                 # tau = rho * h modulo 8L, not just L
     assert fits[12:6012].all(), "a random h practically always has a short vector that fits the walk"
     # h = L-1, L-2, (L-1)/2 are close to -1, -2, -1/2 modulo L but not modulo 8L: their only short vectors have an even

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Within-process interleaved A/B timing of engine builds (kernel variants compiled to different .so files).
 
-    python tools/ab_bench.py build_a.so build_b.so ...   [--ops x25519,sign,verify,keypair] [--rounds 5]
+    python tools/ab_bench.py build_a.so build_b.so lib.so@KEY=VAL,KEY2=VAL2 ...   [--ops x25519,sign,verify,keypair] [--rounds 5]
+
+`lib.so@KEY=VAL` times a library under run-time knobs the engine reads per call (C25519_AMD_INV_K, ...): the
+environment is switched right before that variant's launches.
 
 Each library is dlopen'ed privately; every round runs each (library, op) once at N = 2^20 with inputs
 resident in HBM and reports min / median kernel time from HIP events on torch's current stream."""
@@ -26,13 +29,25 @@ n = args.n
 dev = torch.device("cuda", 0)
 vp, sz = C.c_void_p, C.c_size_t
 libs = []
-for p in args.libs:
+envs = {}
+for spec in args.libs:
+    p, _, knobs = spec.partition("@")
     L = C.CDLL(os.path.abspath(p))
     L.curve25519_dh_CreateSharedKey_dev.argtypes = [vp, vp, vp, sz, vp]
     L.ed25519_CreateKeyPair_dev.argtypes = [vp, vp, vp, sz, vp]
     L.ed25519_SignMessage_dev.argtypes = [vp, vp, vp, sz, sz, vp]
     L.ed25519_VerifySignature_dev.argtypes = [vp, vp, vp, vp, sz, sz, vp]
-    libs.append((os.path.basename(p), L))
+    name = os.path.basename(p) + ("@" + knobs if knobs else "")
+    envs[name] = dict(kv.split("=", 1) for kv in knobs.split(",")) if knobs else {}
+    libs.append((name, L))
+KNOBS = sorted({k for e in envs.values() for k in e})
+
+
+def set_env(name):
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(envs[name])
+
 
 sk_np, pk_np = synth.x25519_inputs(n)
 esk_np, msg_np = synth.ed25519_inputs(n)
@@ -70,6 +85,7 @@ for r in range(args.rounds + 1):
     for op in ops:
         for name, L in libs:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            set_env(name)
             run(L, op)                                  # warm-up launch keeps the clocks up (DVFS)
             a.record()
             for _ in range(BURST):
@@ -83,6 +99,6 @@ for r in range(args.rounds + 1):
 for op in ops:
     for name, _ in libs:
         t = times[(name, op)]
-        print(f"{op:8s} {name:32s} min {min(t):8.3f} ms  median {statistics.median(t):8.3f} ms  -> {n / min(t) / 1e3:9.1f} Mops/s")
+        print(f"{op:8s} {name:44s} min {min(t):8.3f} ms  median {statistics.median(t):8.3f} ms  -> {n / min(t) / 1e3:9.1f} Mops/s")
 if "verify" in ops:
     print("verify all ok:", bool(ok.all().item()))

@@ -1,10 +1,10 @@
 #!/bin/bash
 # tools/gpu_round.sh -- one gpurun call's worth of work: the GPU test suite, bench lines, the instruction-rate
-# microbenchmark, the host-API rates and the rocprofv3 passes.  Everything lands under gpurun_out/r02/.
+# microbenchmark, the host-API rates and the rocprofv3 passes.  Everything lands under gpurun_out/$ROUND/ (default r03).
 #   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tests|bench|ubench|prof|all ...]'
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/r02
+OUT=$REPO/gpurun_out/${ROUND:-r03}
 mkdir -p $OUT
 cd $REPO
 WHAT=${*:-all}
@@ -29,8 +29,16 @@ if has ubench; then
   [ -x tools/ubench/field_ab ] && { timeout 300 tools/ubench/field_ab > $OUT/field_ab.txt 2>&1; echo "field_ab rc=$?"; cat $OUT/field_ab.txt; }
 fi
 if has ab && ls build_ab/*.so >/dev/null 2>&1; then
-  timeout 600 python tools/ab_bench.py curve25519_amd/libcurve25519_amd.so build_ab/*.so --ops x25519,sign,verify,keypair --rounds 4 > $OUT/ab_bench.txt 2>&1
+  timeout 900 python tools/ab_bench.py curve25519_amd/libcurve25519_amd.so build_ab/*.so ${AB_EXTRA:-} --ops ${AB_OPS:-x25519,sign,verify,keypair} --rounds ${AB_ROUNDS:-4} > $OUT/ab_bench.txt 2>&1
   echo "ab rc=$?"; cat $OUT/ab_bench.txt
+fi
+if has stats && ! has prof; then                       # the kernel-trace pass alone (per-kernel times of the bench)
+  cd /tmp && export TMPDIR=/tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o stats -- python $REPO/bench.py --steps 30 --warmup 4 --no-cpu > $OUT/prof_stats.log 2>&1
+  cd $REPO
+  S=$(find $OUT/prof_stats -name '*.db' | head -1)
+  [ -n "$S" ] && python tools/rocpd_summary.py stats $S > $OUT/kernel_stats.txt && cat $OUT/kernel_stats.txt
+  find $OUT -name '*.db' -size +8M -delete
 fi
 if has prof; then
   cd /tmp && export TMPDIR=/tmp

@@ -16,7 +16,8 @@ FULL = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xo
 
 
 def kernel_body(text, sym):
-    m = re.search(r"^(\S*%s\S*):.*?\n(.*?)\n\s*s_endpgm" % re.escape(sym), text, re.S | re.M)
+    # up to the function's end marker (a kernel may hold several s_endpgm: early exits)
+    m = re.search(r"^(\S*%s\S*):.*?\n(.*?)\n\.Lfunc_end\d+:" % re.escape(sym), text, re.S | re.M)
     if not m:
         raise SystemExit(f"kernel matching {sym!r} not found")
     return m.group(1), m.group(2).split("\n")
@@ -40,7 +41,7 @@ def main():
     print(f"{name}: {len(insts)} instructions")
     loops = []
     for i, ins in enumerate(insts):
-        m = re.match(r"s_cbranch_\w+\s+(\.LBB\w+)", ins)
+        m = re.match(r"s_c?branch\w*\s+(\.LBB\w+)", ins)     # big loops close with s_cbranch out + s_branch back
         if m and m.group(1) in labels and labels[m.group(1)] <= i:
             loops.append((labels[m.group(1)], i))
     for lo, hi in loops:

@@ -15,14 +15,18 @@ def short(name):
 def stats(path):
     db = sqlite3.connect(path)
     print(f"# rocprofv3 --kernel-trace --stats   ({path})")
-    print(f"{'kernel':<28}{'calls':>6}{'total_ms':>12}{'avg_ms':>12}{'min_ms':>12}{'max_ms':>12}{'pct':>8}  grid x wg  vgpr agpr sgpr lds")
+    # rocprofv3 (ROCm 7.2) decodes the kernel descriptor's granulated register count with a granule of 4; gfx950
+    # allocates in granules of 8 (MI355X_MICROARCH.md, register files), so the trace's vgpr_count / accum_vgpr_count are
+    # HALF the allocation: 60 / 116 / 256 for kernels the compiler reports at 118 / 228 / 512.  Printed doubled =
+    # registers allocated per lane, to be read next to profiles/rNN_resource_usage.txt (the compiler's own figures).
+    print(f"{'kernel':<28}{'calls':>6}{'total_ms':>12}{'avg_ms':>12}{'min_ms':>12}{'max_ms':>12}{'pct':>8}  grid x wg  vgpr_alloc agpr_alloc sgpr lds")
     rows = db.execute(
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(grid_x), max(workgroup_x),"
         " max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size) from kernels group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows)
     for r in rows:
         print(f"{short(r[0]):<28}{r[1]:>6}{r[2]/1e6:>12.3f}{r[3]/1e6:>12.4f}{r[4]/1e6:>12.4f}{r[5]/1e6:>12.4f}{100*r[2]/total:>8.2f}"
-              f"  {r[6]} x {r[7]}  {r[8]} {r[9]} {r[10]} {r[11]}")
+              f"  {r[6]} x {r[7]}  {2 * (r[8] or 0)} {2 * (r[9] or 0)} {r[10]} {r[11]}")
 
 
 def pmc(paths):

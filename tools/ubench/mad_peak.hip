@@ -69,6 +69,55 @@
     "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\t" \
     "v_and_b32 " l ", 0x3ffffff, v40\n\tv_lshrrev_b64 v[40:41], 26, v[40:41]\n\t"
 #define FIELD_MUL COL("v58") COL("v59") COL("v60") COL("v61") COL("v62") COL("v63") COL("v64") COL("v65") COL("v66") COL("v67")
+// two independent products column by column, their MAD chains interleaved (what a dual-product primitive would issue):
+// the same 240 instructions per trip as two FIELD_MULs, but no MAD waits for the one right before it
+#define COL2(l, m) \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_and_b32 " l ", 0x3ffffff, v40\n\tv_lshrrev_b64 v[40:41], 26, v[40:41]\n\t" \
+    "v_and_b32 " m ", 0x3ffffff, v42\n\tv_lshrrev_b64 v[42:43], 26, v[42:43]\n\t"
+#define FIELD_MUL2 COL2("v58", "v68") COL2("v59", "v69") COL2("v60", "v70") COL2("v61", "v71") COL2("v62", "v72") \
+                   COL2("v63", "v73") COL2("v64", "v58") COL2("v65", "v59") COL2("v66", "v60") COL2("v67", "v61")
+// ONE product, columns in pairs: the even column continues from the carry, the odd one starts from zero beside it and
+// takes the even column's carry in one 64-bit add afterwards (125 instructions per product, two per trip)
+#define COLPAIR(l, m) \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, 0\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v39, v38, v[42:43]\n\t" \
+    "v_and_b32 " l ", 0x3ffffff, v40\n\tv_lshrrev_b64 v[40:41], 26, v[40:41]\n\t" \
+    "v_lshl_add_u64 v[42:43], v[40:41], 0, v[42:43]\n\t" \
+    "v_and_b32 " m ", 0x1ffffff, v42\n\tv_lshrrev_b64 v[40:41], 25, v[42:43]\n\t"
+#define FIELD_MULC COLPAIR("v58", "v59") COLPAIR("v60", "v61") COLPAIR("v62", "v63") COLPAIR("v64", "v65") COLPAIR("v66", "v67")
+// one product with a full-rate instruction of the same product (a mask) between every two dependent MADs: does an
+// independent VALU instruction in between hide the dependent-issue penalty?  (10 x [10 x (MAD, and), shift]: 210)
+#define COLI(l) \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_and_b32 v68, 0x3ffffff, v58\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\tv_and_b32 v69, 0x3ffffff, v59\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_and_b32 v70, 0x3ffffff, v60\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\tv_and_b32 v71, 0x3ffffff, v61\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_and_b32 v72, 0x3ffffff, v62\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\tv_and_b32 v73, 0x3ffffff, v63\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_and_b32 v68, 0x3ffffff, v64\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\tv_and_b32 v69, 0x3ffffff, v65\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v38, v39, v[40:41]\n\tv_and_b32 v70, 0x3ffffff, v66\n\t" \
+    "v_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\tv_and_b32 " l ", 0x3ffffff, v40\n\t" \
+    "v_lshrrev_b64 v[40:41], 26, v[40:41]\n\t"
+#define FIELD_MULI COLI("v58") COLI("v59") COLI("v60") COLI("v61") COLI("v62") COLI("v63") COLI("v64") COLI("v65") COLI("v66") COLI("v67")
 #define X2(B) B B
 #define X8(B) X2(X2(X2(B)))
 #define X16(B) X2(X8(B))
@@ -123,6 +172,9 @@ __global__ void __launch_bounds__(256) k_loop(unsigned* out, unsigned seed, int 
     if constexpr (ID == 15) LOOP(PAD0, X16(ANDL8));
     if constexpr (ID == 16) LOOP(PAD0, X16(CNDE32_8));
     if constexpr (ID == 18) LOOP(PAD0, X2(FIELD_MUL));
+    if constexpr (ID == 19) LOOP(PAD0, FIELD_MUL2);
+    if constexpr (ID == 20) LOOP(PAD0, X2(FIELD_MULC));
+    if constexpr (ID == 21) LOOP(PAD0, FIELD_MULI);
     if (r == 0x12345678u) out[0] = r;
 }
 
@@ -146,14 +198,19 @@ static const Row rows[] = {
     { 15, 128, 1, "v_and_b32_literal", "v_and_b32 with a 32-bit literal (8-byte VOP2), 128 per trip" },
     { 16, 128, 1, "v_cndmask_b32_vcc_run", "v_cndmask_b32 (VOP2, vcc), back to back, 128 per trip" },
     { 18, 240, 1, "field_mul_stream", "the shipped field multiplication's stream (10 x [10 dependent MADs, mask, shift]), 240 per trip" },
+    { 19, 240, 1, "field_mul_two_products", "two products interleaved MAD by MAD (same 240 instructions per trip)" },
+    { 20, 250, 1, "field_mul_column_pairs", "one product, columns in pairs + one 64-bit add per pair (2 x 125 per trip)" },
+    { 21, 210, 1, "field_mul_mad_and", "one product, a full-rate mask between dependent MADs (210 per trip, 100 MADs)" },
 };
+// the field streams again at lower occupancy: what the dependent-MAD penalty costs with 4 / 2 / 1 waves per SIMD
+static const int occupancy_rows[] = { 6, 9, 18, 19, 20, 21 };
 
 template <int ID> static void launch(int blocks, unsigned* d, int trips, hipStream_t s) { k_loop<ID><<<blocks, 256, 0, s>>>(d, 1, trips); }
 static void dispatch(int id, int blocks, unsigned* d, int trips, hipStream_t s)
 {
     switch (id) {
 #define C(k) case k: launch<k>(blocks, d, trips, s); break;
-        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(18)
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(18) C(19) C(20) C(21)
 #undef C
     }
 }
@@ -184,6 +241,29 @@ int main(int argc, char** argv)
         const double rate = r.scale * (double)blocks * 4 * (double)trips * r.per_trip * 64 / (best * 1e-3);
         printf("%-78s %8.3f ms  %7.2f T lane-op/s\n", r.name, best, rate / 1e12);
         if (jf) { fprintf(jf, "%s  \"%s\": %.4e", first ? "" : ",\n", r.key, rate); first = false; }
+    }
+    if (jf) fprintf(jf, "\n},\n\"by_occupancy\": {\n");
+    first = true;
+    for (int waves : { 4, 2, 1 }) {
+        printf("-- %d wave(s) per SIMD\n", waves);
+        for (int id : occupancy_rows) {
+            const Row* r = nullptr;
+            for (const Row& q : rows) if (q.id == id) r = &q;
+            const int trips = 65536 / r->per_trip;
+            const int blocks = cus * waves;
+            float best = 1e30f;
+            for (int rep = 0; rep < 6; rep++) {
+                CHECK(hipEventRecord(e0, s));
+                dispatch(r->id, blocks, d, trips, s);
+                CHECK(hipEventRecord(e1, s));
+                CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms < best) best = ms;
+            }
+            const double rate = (double)blocks * 4 * (double)trips * r->per_trip * 64 / (best * 1e-3);
+            printf("%-78s %8.3f ms  %7.2f T lane-op/s\n", r->name, best, rate / 1e12);
+            if (jf) { fprintf(jf, "%s  \"%s@%d\": %.4e", first ? "" : ",\n", r->key, waves, rate); first = false; }
+        }
     }
     if (jf) { fprintf(jf, "\n}}\n"); fclose(jf); }
     return 0;

@@ -46,7 +46,7 @@ def timed(pk_np, label):
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 5
     print(f"{label:46s} {ms:8.3f} ms per 2^{n.bit_length() - 1}  = {n / ms / 1e3:7.1f} M verifies/s   "
-          f"accepted {int(ok.sum())}  reference-order workgroups {L.c25519_amd_verify_last_slow_groups()} of {(n + 255) // 256}")
+          f"accepted {int(ok.sum())}  reference-order workgroups {L.c25519_amd_verify_last_slow_elements()} of {(n + 255) // 256}")
     return ms
 
 
