@@ -147,7 +147,11 @@ struct ThreadState {
     int reserve_dev(int lane /* = buffer set */, int slot, size_t bytes)
     {
         if (bytes <= dcap[lane][slot]) return 0;
-        if (dbuf[lane][slot]) { C25519_TRY(hipFree(dbuf[lane][slot])); dbuf[lane][slot] = nullptr; dcap[lane][slot] = 0; }
+        if (dbuf[lane][slot]) {                           // held staged secrets: zeroed before it goes back to the allocator
+            C25519_TRY(hipMemset(dbuf[lane][slot], 0, dcap[lane][slot]));
+            C25519_TRY(hipFree(dbuf[lane][slot]));
+            dbuf[lane][slot] = nullptr; dcap[lane][slot] = 0;
+        }
         const size_t want = bytes < 4096 ? 4096 : bytes;
         C25519_TRY(hipMalloc(&dbuf[lane][slot], want));
         dcap[lane][slot] = want;
@@ -156,7 +160,11 @@ struct ThreadState {
     int reserve_host(int lane, int slot, size_t bytes)
     {
         if (bytes <= hcap[lane][slot]) return 0;
-        if (hbuf[lane][slot]) { C25519_TRY(hipHostFree(hbuf[lane][slot])); hbuf[lane][slot] = nullptr; hcap[lane][slot] = 0; }
+        if (hbuf[lane][slot]) {
+            memset(hbuf[lane][slot], 0, hcap[lane][slot]);
+            C25519_TRY(hipHostFree(hbuf[lane][slot]));
+            hbuf[lane][slot] = nullptr; hcap[lane][slot] = 0;
+        }
         const size_t want = bytes < 4096 ? 4096 : bytes;
         C25519_TRY(hipHostMalloc(&hbuf[lane][slot], want, hipHostMallocDefault));
         hcap[lane][slot] = want;
@@ -171,6 +179,7 @@ struct ThreadState {
         WorkSlab& w = *slab_for(s, dev);
         if (w.ptr && bytes > w.cap) {
             C25519_TRY(hipDeviceSynchronize());
+            C25519_TRY(hipMemset(w.ptr, 0, w.cap));
             C25519_TRY(hipFree(w.ptr));
             w.ptr = nullptr; w.cap = 0; w.used = false;
         }

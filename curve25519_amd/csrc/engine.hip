@@ -13,6 +13,7 @@
 //
 // Build: curve25519_amd/build.py (hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -pragma-unroll-threshold=131072 ...)
 #include "capi_common.hpp"
+#include "host_pipeline.hpp"
 #include "lanes.cuh"
 #include "verify_fast.cuh"
 
@@ -371,18 +372,16 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VC_WAVES) k_ed25519_verify_ch
 }
 
 // ---- the lattice fast path (verify_fast.cuh) ---------------------------------------------------------------------------
-// Five kernels.  scalars -> decode -> tables -> walk decide every element whose key is on the curve (and whose short
+// Four kernels.  scalars -> points -> walk decide every element whose key is on the curve (and whose short
 // vector fits the walk: a random one practically always does); the elements they cannot decide are collected in a list
 // and k_ed25519_verify_slow runs the reference's own operation order for exactly those.
-// Per-element hand-over, struct-of-arrays: sigma_cols[8] (the 32 column bytes of sigma), rho[5], tau[5] (biased),
-// the decoded points (affine limbs of +-Q and of -R), a flag word
+// Per-element hand-over, struct-of-arrays: sigma_cols[8] (the 32 column bytes of sigma), rho[5], tau[5] (biased), a flag word
 //   bit 0  R decodes canonically onto the curve      bit 1  the key is on the curve
 //   bit 2  the short vector fits the walk             bit 3  tau < 0
 //   bit 4  the element is on the slow list            bits 8..13  top nonzero digit of the element's scalars
 struct FastScratch {
     u32 *tables;            // per lane: window table of +-Q, then of -R (2 x WTABLE_WORDS, lane-contiguous)
     u32 *sigma, *rho, *tau, *flags;
-    u32 *qx, *qy, *rx, *ry; // decoded points (the projective-result slots of the reference-order path, unused here)
     u32 *slow_list;         // indices of the elements the reference-order kernel has to decide ...
     u32 *slow_count;        // ... and how many
     u32 *slow_report;       // a word that outlives the call's scratch: the count again, for c25519_amd_verify_last_slow_elements
@@ -391,13 +390,10 @@ constexpr size_t FAST_TABLE_WORDS = 2 * WTABLE_WORDS;
 constexpr int FS_BLOCK = 256;
 constexpr u32 FLAG_R_OK = 1u, FLAG_KEY_OK = 2u, FLAG_FITS = 4u, FLAG_TAU_NEG = 8u, FLAG_SLOW = 16u;
 #ifndef C25519_VW_WAVES
-#define C25519_VW_WAVES 3            // waves per SIMD the register allocator aims at: the walk ...
+#define C25519_VW_WAVES 3            // waves per SIMD the register allocator aims at: the walk kernel ...
 #endif
 #ifndef C25519_VD_WAVES
-#define C25519_VD_WAVES 4            // ... the point decoding (two square roots per element) ...
-#endif
-#ifndef C25519_VT_WAVES
-#define C25519_VT_WAVES 2            // ... and the table kernel
+#define C25519_VD_WAVES 3            // ... and the point decoding + table kernel
 #endif
 
 // step 1: hash, short lattice vector, sigma -- integer work only
@@ -419,9 +415,9 @@ __global__ void __launch_bounds__(FS_BLOCK) k_ed25519_verify_fast_scalars(FastSc
     fs.flags[i] = (lat_ok & FLAG_FITS) | (tau_neg & FLAG_TAU_NEG) | ((u32)top << 8);
 }
 
-// step 2: the two square roots of an element, one per lane: lane j < n decodes key j, lane n + j decodes R of signature j
-// (2n lanes of pure field arithmetic: few registers, four waves per SIMD)
-__global__ void __launch_bounds__(ED_BLOCK, C25519_VD_WAVES) k_ed25519_verify_fast_decode(FastScratch fs, const void* sig, const void* pk,
+// step 2: the two points of an element, one per lane: lane j < n decodes key j, lane n + j decodes R of signature j (a
+// square root each), then builds that point's window table.  2n lanes, 168 registers: three waves per SIMD, no spills.
+__global__ void __launch_bounds__(ED_BLOCK, C25519_VD_WAVES) k_ed25519_verify_fast_points(FastScratch fs, const void* sig, const void* pk,
                                                                                           size_t n)
 {
     const size_t j = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
@@ -430,39 +426,30 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VD_WAVES) k_ed25519_verify_fa
     const size_t e = is_r ? j - n : j;
     u32 w[8];
     if (is_r) load32(w, sig, 2 * e); else load32(w, pk, e);
-    const u32 tau_neg = (fs.flags[e] & FLAG_TAU_NEG) ? 0xffffffffu : 0u;
+    const u32 f = fs.flags[e];
+    const u32 tau_neg = (f & FLAG_TAU_NEG) ? 0xffffffffu : 0u;
     fe X, Y;
     const u32 ok = ed_verify_fast_decode(X, Y, w, is_r ? 0xffffffffu : 0u, tau_neg);
-    soa_store_fe(is_r ? fs.rx : fs.qx, n, e, X);
-    soa_store_fe(is_r ? fs.ry : fs.qy, n, e, Y);
-    if (ok) atomicOr(&fs.flags[e], is_r ? FLAG_R_OK : FLAG_KEY_OK);
-}
-
-// step 3: the window tables, one per lane like the square roots (lane j < n: +-Q of element j, lane n + j: its -R);
-// elements the walk cannot decide get no tables and go on the slow list
-__global__ void __launch_bounds__(ED_BLOCK, C25519_VT_WAVES) k_ed25519_verify_fast_tables(FastScratch fs, size_t n)
-{
-    const size_t j = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
-    if (j >= 2 * n) return;
-    const bool is_r = j >= n;
-    const size_t e = is_r ? j - n : j;
-    const u32 f = fs.flags[e];
-    if (!((f & FLAG_FITS) && (f & FLAG_KEY_OK))) {
-        if (!is_r) {
-            atomicOr(&fs.flags[e], FLAG_SLOW);                        // (the R lane of this element may be reading the word)
-            fs.slow_list[atomicAdd(fs.slow_count, 1u)] = (u32)e;      // (the compiler aggregates this per wave)
-        }
-        return;
+    if (is_r) {
+        if (ok) atomicOr(&fs.flags[e], FLAG_R_OK);
+    } else if (ok && (f & FLAG_FITS)) {
+        atomicOr(&fs.flags[e], FLAG_KEY_OK);
+    } else {                                                      // an element the walk cannot decide: on the slow list
+        atomicOr(&fs.flags[e], ok ? FLAG_KEY_OK | FLAG_SLOW : FLAG_SLOW);
+        fs.slow_list[atomicAdd(fs.slow_count, 1u)] = (u32)e;      // (the compiler aggregates this per wave)
     }
-    fe X, Y;
-    soa_load_fe(X, is_r ? fs.rx : fs.qx, n, e);
-    soa_load_fe(Y, is_r ? fs.ry : fs.qy, n, e);
+    // the point's window table, right here: a table is 1440 bytes of 16-byte stores scattered over as many cache lines, and
+    // they hide under the other waves' square roots (in a kernel of their own: 1.3 ms with the SIMDs idle half the time; in
+    // front of the walk, inside its kernel: 1.0 ms; here 0.6 ms -- profiles/r03_ab_verify_structure.txt).
+    // (An element that turns out to be on the slow list gets tables nobody reads: the key lane cannot tell the R lane in time.)
     const QTableLimbs tbl{ fs.tables + e * FAST_TABLE_WORDS + (is_r ? WTABLE_WORDS : 0) };
     wtable_build(tbl, X, Y);
 }
 
-// step 4: the walk and the neutral-element test.  Nothing but the accumulator point lives in registers across a digit
-// round (the scalars are fetched a word at a time), which is what lets four waves share a SIMD like in the ladder.
+// step 3: the walk and the neutral-element test.  Across a digit round nothing but the accumulator point lives in
+// registers (the scalars are fetched a word at a time, table rows and LDS rows a field at a time): 154 registers, three
+// waves per SIMD, no spills.  The kernel is VALU-bound -- every SIMD issues ~100 % of the time (SQ_ACTIVE_INST_ANY against
+// SQ_BUSY_CYCLES, profiles/r03_pmc.txt), and it measured the same at two, three and four waves per SIMD.
 __global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fast_walk(FastScratch fs, int* verdict, size_t n,
                                                                                         const u32* __restrict__ g_tbl)
 {
@@ -514,10 +501,13 @@ C25519_DEV int verify_reference_order_lane(const u32 (&pkw)[8], const void* sig,
 }
 
 // step 5: the elements on the slow list (off-curve keys -- the reference does not reject them, so neither may we -- and
-// the practically nonexistent over-long vectors), one per lane, in the reference's order.  Launched over the whole grid:
-// workgroups beyond the list's end leave at once.  It runs on the thread's side stream beside the walk, whose lanes
-// skip the listed elements, so a few garbage keys in a batch cost no time at all.
-__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_slow(FastScratch fs, int* verdict, const void* sig, const void* pk,
+// the practically nonexistent over-long vectors), one per lane, in the reference's order.  A fixed small grid strides
+// over the list (SLOW_GRID workgroups fill the chip at this kernel's two waves per SIMD; a full-size grid of workgroups
+// that only look at the counter and leave still has to be dispatched beside the walk, 232 registers and 30 KiB of LDS
+// each, and was measured to hold the walk back).  It runs on the thread's side stream beside the walk, whose lanes skip
+// the listed elements, so a few garbage keys in a batch cost no time at all.
+constexpr unsigned SLOW_GRID = 512;
+__global__ void __launch_bounds__(ED_BLOCK, 1) k_ed25519_verify_slow(FastScratch fs, int* verdict, const void* sig, const void* pk,
                                                                      Msgs msgs, const u32* __restrict__ g_tbl)
 {
     const u32 count = *fs.slow_count;
@@ -525,12 +515,12 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_slow(FastScratch
     if ((size_t)blockIdx.x * ED_BLOCK >= count) return;
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
     lds_stage_words(lds_tbl, g_tbl + REF_TBL_OFFSET, REF_TBL_WORDS);
-    const size_t k = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
-    if (k >= count) return;
-    const size_t i = fs.slow_list[k];
-    u32 pkw[8];
-    load32(pkw, pk, i);
-    verdict[i] = verify_reference_order_lane(pkw, sig, i, msgs.ptr(i), msgs.len(i), fs.tables + i * FAST_TABLE_WORDS, lds_tbl);
+    for (size_t k = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x; k < count; k += (size_t)gridDim.x * ED_BLOCK) {
+        const size_t i = fs.slow_list[k];
+        u32 pkw[8];
+        load32(pkw, pk, i);
+        verdict[i] = verify_reference_order_lane(pkw, sig, i, msgs.ptr(i), msgs.len(i), fs.tables + i * FAST_TABLE_WORDS, lds_tbl);
+    }
 }
 
 // Same check with ONE key for the whole batch (the reference's two-phase use: Verify_Init once, many
@@ -722,8 +712,11 @@ __global__ void __launch_bounds__(64) k_fold_selftest(uint8_t* out /* n x 128 */
 // ================================================================================================
 namespace {
 
+using c25519_host::Arr;
 using c25519_host::ThreadState;
 using c25519_host::aligned16;
+using c25519_host::round_up;
+using c25519_host::run_batch;
 using c25519_host::bad_arg;
 using c25519_host::tls;
 
@@ -788,7 +781,6 @@ int check_dev_args(size_t n, std::initializer_list<const void*> ptrs)
     return 0;
 }
 
-inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // words of the projective-result part of the scratch for n elements (a, b, z, prefix; 16-byte aligned parts)
 inline size_t proj_words(size_t n) { return 4 * round_up(SCR_FE * n, 4); }
@@ -829,204 +821,6 @@ int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t 
     }
     C25519_TRY(hipGetLastError());
     return 0;
-}
-
-// ---- host-pointer pipeline used by the *_batch entry points -------------------------------------------------------
-// A call is cut into pieces; piece c uses buffer set c % SETS (pinned host + device staging), and these roles work on
-// different pieces at the same time:
-//     stage-in  : helper threads (4, or 2 on a small host; C25519_AMD_STAGERS) copy the caller's pageable arrays into a set's pinned buffers
-//     submit    : the calling thread enqueues the piece: upload on the upload stream, the *_dev kernels on one of two
-//                 kernel streams, download on the download stream, chained by events (pinned memory: hipMemcpyAsync is
-//                 a real DMA).  With copies and kernels on the same stream, piece c+4's upload queued behind piece c's
-//                 kernels and the device idled between rounds of four.
-//     stage-out : helper threads (2, or 1; C25519_AMD_DRAINERS) wait for the set's event and copies the results out
-// so both CPU copies and both PCIe directions ride under the kernels of the neighbouring pieces.  Pieces are n/8 for
-// big batches: two of them (2^18 lanes) fill every kernel's occupancy, and a piece cannot finish faster than one
-// ladder's latency (~1.2 ms), so fewer, larger pieces in flight beat many small ones.  Eight buffer sets let a 2^20
-// call stage every piece in without waiting for an earlier one to leave; four streams because the runtime drives four
-// hardware queues (timelines and the rejected shapes: profiles/r02_hostapi_trace.txt, rates: profiles/r02_hostapi.txt).
-struct Arr {
-    const void* in;      // caller's source (nullptr: output only)
-    void* out;           // caller's destination (nullptr: input only); in and out may both be set (IN/OUT array)
-    size_t elem;         // bytes per element
-};
-
-constexpr int MAX_STAGERS = 8, MAX_DRAINERS = 4;
-inline int env_count(const char* name, int dflt, int max)
-{
-    const char* e = getenv(name);
-    const int v = e ? atoi(e) : 0;
-    return v >= 1 && v <= max ? v : dflt;
-}
-
-// is [p, p + bytes) page-locked host memory the device can DMA from (hipHostMalloc / hipHostRegister /
-// c25519_amd_host_register)?  Such arrays skip the staging copies: the H2D / D2H copies run on the caller's memory.
-inline bool host_pinned(const void* p, size_t bytes)
-{
-    if (!p || !bytes) return false;
-    for (const char* q : { (const char*)p, (const char*)p + bytes - 1 }) {
-        hipPointerAttribute_t a{};
-        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }   // pageable
-        if (a.type != hipMemoryTypeHost) return false;
-    }
-    return true;
-}
-
-template <typename Launch>
-int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
-{
-    ThreadState& t = tls();
-    C25519_RC(t.ensure());
-    const Arr* arr = arrays.begin();
-    const int na = (int)arrays.size();
-    if (na > ThreadState::SLOTS) return bad_arg("internal: too many arrays");
-    size_t row = 0;
-    for (int a = 0; a < na; a++) row += arr[a].elem;
-    static const size_t pieces = [] { const char* e = getenv("C25519_AMD_BATCH_PIECES"); int v = e ? atoi(e) : 0; return (size_t)(v >= 2 && v <= 64 ? v : 8); }();
-    size_t chunk = n >= ((size_t)1 << 17) ? round_up((n + pieces - 1) / pieces, 256) : n;
-    const size_t cap = round_up(((size_t)256 << 20) / (row ? row : 1) + 1, 256);       // <= 256 MiB of staging per buffer set
-    if (chunk > cap) chunk = cap;
-    const size_t nchunks = (n + chunk - 1) / chunk;
-    const int sets = nchunks < (size_t)ThreadState::SETS ? (int)nchunks : ThreadState::SETS;
-    bool direct[ThreadState::SLOTS] = {};                  // the caller's array is pinned: no staging copy either way
-    for (int a = 0; a < na && n >= 4096; a++) {            // (not worth two attribute queries per array on a tiny call)
-        direct[a] = (!arr[a].in || host_pinned(arr[a].in, n * arr[a].elem)) && (!arr[a].out || host_pinned(arr[a].out, n * arr[a].elem));
-        if (arr[a].in && arr[a].out && arr[a].in != arr[a].out) direct[a] = false;
-    }
-    for (int l = 0; l < sets; l++)
-        for (int a = 0; a < na; a++) {
-            C25519_RC(t.reserve_dev(l, a, arr[a].elem * chunk));
-            if (!direct[a]) C25519_RC(t.reserve_host(l, a, arr[a].elem * chunk));
-        }
-    auto span = [&](size_t c, size_t& lo, size_t& cnt) { lo = c * chunk; cnt = (n - lo < chunk) ? n - lo : chunk; };
-    auto stage_in = [&](size_t c, int part, int parts) {   // rows [part, part+1) / parts of piece c
-        size_t lo, cnt;
-        span(c, lo, cnt);
-        const size_t r0 = cnt * part / parts, r1 = cnt * (part + 1) / parts;
-        const int l = (int)(c % sets);
-        for (int a = 0; a < na; a++)
-            if (arr[a].in && !direct[a] && (r1 - r0) * arr[a].elem)
-                memcpy((char*)t.hbuf[l][a] + r0 * arr[a].elem, (const char*)arr[a].in + (lo + r0) * arr[a].elem, (r1 - r0) * arr[a].elem);
-    };
-    // one piece: upload on the upload stream, kernels on one of the two kernel streams, download on the download
-    // stream, chained by events -- so the upload of a later piece never queues behind an earlier piece's kernels, and
-    // two pieces' kernels (2^18 lanes: full occupancy for every pass) are in flight while others move over PCIe
-    auto submit = [&](size_t c, bool one_stream) -> int {
-        size_t lo, cnt;
-        span(c, lo, cnt);
-        const int l = (int)(c % sets);
-        hipStream_t kern = t.stream[c & 1];
-        hipStream_t up = one_stream ? kern : t.stream[2], down = one_stream ? kern : t.stream[3];
-        void* dptr[ThreadState::SLOTS] = {};
-        for (int a = 0; a < na; a++) {
-            dptr[a] = t.dbuf[l][a];
-            if (arr[a].in && cnt * arr[a].elem)
-                C25519_TRY(hipMemcpyAsync(dptr[a], direct[a] ? (const char*)arr[a].in + lo * arr[a].elem : (const char*)t.hbuf[l][a],
-                                          cnt * arr[a].elem, hipMemcpyHostToDevice, up));
-        }
-        if (!one_stream) {
-            C25519_TRY(hipEventRecord(t.uploaded[l], up));
-            C25519_TRY(hipStreamWaitEvent(kern, t.uploaded[l], 0));
-        }
-        C25519_RC(launch(dptr, cnt, lo, kern));
-        if (!one_stream) {
-            C25519_TRY(hipEventRecord(t.computed[l], kern));
-            C25519_TRY(hipStreamWaitEvent(down, t.computed[l], 0));
-        }
-        for (int a = 0; a < na; a++)
-            if (arr[a].out && cnt * arr[a].elem)
-                C25519_TRY(hipMemcpyAsync(direct[a] ? (char*)arr[a].out + lo * arr[a].elem : (char*)t.hbuf[l][a], dptr[a],
-                                          cnt * arr[a].elem, hipMemcpyDeviceToHost, down));
-        C25519_TRY(hipEventRecord(t.done[l], down));
-        return 0;
-    };
-    auto drain = [&](size_t c) -> int {
-        size_t lo, cnt;
-        span(c, lo, cnt);
-        const int l = (int)(c % sets);
-        C25519_TRY(hipEventSynchronize(t.done[l]));
-        for (int a = 0; a < na; a++)
-            if (arr[a].out && !direct[a] && cnt * arr[a].elem) memcpy((char*)arr[a].out + lo * arr[a].elem, t.hbuf[l][a], cnt * arr[a].elem);
-        return 0;
-    };
-
-    auto sequential = [&]() -> int {                      // no helper threads: one piece after the other
-        for (size_t c = 0; c < nchunks; c++) {
-            stage_in(c, 0, 1);
-            C25519_RC(submit(c, true));
-            C25519_RC(drain(c));
-        }
-        return 0;
-    };
-    if (nchunks == 1) return sequential();
-
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<char> staged(nchunks, 0), drained(nchunks, 0);
-    size_t submitted = 0;
-    int failed = 0;                                       // first error of any role; everybody stops
-    // helper threads: 4 + 2 on a machine with cores to spare (sign moves 160 B per 1.8 ns of kernel time: one copier
-    // per direction cannot keep up), 2 + 1 on a small one
-    static const bool roomy = std::thread::hardware_concurrency() >= 16;
-    static const int STAGERS = env_count("C25519_AMD_STAGERS", roomy ? 4 : 2, MAX_STAGERS);
-    static const int DRAINERS = env_count("C25519_AMD_DRAINERS", roomy ? 2 : 1, MAX_DRAINERS);
-    std::thread helpers[MAX_STAGERS + MAX_DRAINERS];
-    int started = 0;
-    try {
-    for (int sidx = 0; sidx < STAGERS; sidx++, started++)
-        helpers[started] = std::thread([&, sidx] {
-            for (size_t c = 0; c < nchunks; c++) {        // every stager copies its share of every piece: pieces
-                                                          // become ready in order, each in 1/STAGERS of the time
-                {   // the previous piece in this buffer set must have left its pinned buffers
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return failed || c < (size_t)sets || drained[c - sets]; });
-                    if (failed) return;
-                }
-                stage_in(c, sidx, STAGERS);
-                { std::lock_guard<std::mutex> lk(mu); staged[c]++; }
-                cv.notify_all();
-            }
-        });
-    for (int didx = 0; didx < DRAINERS; didx++, started++)
-        helpers[started] = std::thread([&, didx] {
-            for (size_t c = didx; c < nchunks; c += DRAINERS) {
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return failed || submitted > c; });
-                    if (failed) return;
-                }
-                const int rc = drain(c);
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    if (rc && !failed) failed = rc;
-                    drained[c] = 1;
-                }
-                cv.notify_all();
-            }
-        });
-    } catch (const std::system_error&) {                  // the process cannot have more threads: do without them
-        { std::lock_guard<std::mutex> lk(mu); failed = -1; }
-        cv.notify_all();
-        for (int i = 0; i < started; i++) helpers[i].join();
-        return sequential();
-    }
-    for (size_t c = 0; c < nchunks; c++) {
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return failed || staged[c] == STAGERS; });
-            if (failed) break;
-        }
-        const int rc = submit(c, false);
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            if (rc && !failed) failed = rc;
-            submitted = c + 1;
-        }
-        cv.notify_all();
-        if (rc) break;
-    }
-    for (int i = 0; i < started; i++) helpers[i].join();
-    return failed;
 }
 
 // scratch of one verification pass: per-lane tables (the larger of the two paths' formats: they never live at the same
@@ -1070,18 +864,16 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
         fs.slow_list = fs.flags + round_up(n, 4);
         fs.slow_count = fs.slow_list + round_up(n, 4);
         fs.slow_report = side->counter;
-        fs.qx = scr.a; fs.qy = scr.b; fs.rx = scr.z; fs.ry = scr.prefix;
         k_ed25519_verify_fast_scalars<<<grid_for(n, FS_BLOCK), FS_BLOCK, 0, stream>>>(fs, sig, pk, msgs, n);
         C25519_TRY(hipGetLastError());
-        k_ed25519_verify_fast_decode<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
+        k_ed25519_verify_fast_points<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
         C25519_TRY(hipGetLastError());
-        k_ed25519_verify_fast_tables<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, n);
-        C25519_TRY(hipGetLastError());
+        const unsigned slow_grid = grid < SLOW_GRID ? grid : SLOW_GRID;
         const bool fork = side_ok && side->stream != stream;
         if (fork) {                                   // the slow list's kernel beside the walk, joined behind it
             C25519_TRY(hipEventRecord(side->fork, stream));
             C25519_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-            k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, side->stream>>>(fs, verdict, sig, pk, msgs, tbl);
+            k_ed25519_verify_slow<<<slow_grid, ED_BLOCK, 0, side->stream>>>(fs, verdict, sig, pk, msgs, tbl);
             C25519_TRY(hipGetLastError());
             C25519_TRY(hipEventRecord(side->join, side->stream));
         }
@@ -1090,7 +882,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
         if (fork) {
             C25519_TRY(hipStreamWaitEvent(stream, side->join, 0));
         } else {
-            k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
+            k_ed25519_verify_slow<<<slow_grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
             C25519_TRY(hipGetLastError());
         }
         tl_last_verify.count = side->counter; tl_last_verify.stream = stream;

@@ -1,0 +1,235 @@
+// curve25519_amd/csrc/host_pipeline.hpp -- the host-pointer pipeline behind the *_batch entry points (engine.hip) and the
+// per-device workers of the *_multi entry points (multi_device.hip): pageable caller arrays <-> pinned staging <-> device,
+// in pieces, on the calling thread's streams (ThreadState, capi_common.hpp).  No arithmetic here: `launch` enqueues kernels.
+#pragma once
+#include "capi_common.hpp"
+
+#include <condition_variable>
+#include <initializer_list>
+#include <mutex>
+#include <system_error>
+#include <thread>
+#include <vector>
+
+namespace c25519_host {
+
+inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- host-pointer pipeline used by the *_batch entry points -------------------------------------------------------
+// A call is cut into pieces; piece c uses buffer set c % SETS (pinned host + device staging), and these roles work on
+// different pieces at the same time:
+//     stage-in  : helper threads (4, or 2 on a small host; C25519_AMD_STAGERS) copy the caller's pageable arrays into a set's pinned buffers
+//     submit    : the calling thread enqueues the piece: upload on the upload stream, the *_dev kernels on one of two
+//                 kernel streams, download on the download stream, chained by events (pinned memory: hipMemcpyAsync is
+//                 a real DMA).  With copies and kernels on the same stream, piece c+4's upload queued behind piece c's
+//                 kernels and the device idled between rounds of four.
+//     stage-out : helper threads (2, or 1; C25519_AMD_DRAINERS) wait for the set's event and copies the results out
+// so both CPU copies and both PCIe directions ride under the kernels of the neighbouring pieces.  Pieces are n/8 for
+// big batches: two of them (2^18 lanes) fill every kernel's occupancy, and a piece cannot finish faster than one
+// ladder's latency (~1.2 ms), so fewer, larger pieces in flight beat many small ones.  Eight buffer sets let a 2^20
+// call stage every piece in without waiting for an earlier one to leave; four streams because the runtime drives four
+// hardware queues (timelines and the rejected shapes: profiles/r02_hostapi_trace.txt, rates: profiles/r02_hostapi.txt).
+struct Arr {
+    const void* in;      // caller's source (nullptr: output only)
+    void* out;           // caller's destination (nullptr: input only); in and out may both be set (IN/OUT array)
+    size_t elem;         // bytes per element
+    void* dev = nullptr; // a device-resident array of the current device instead of staging: a piece works on
+                         // dev + lo * elem in place (no upload; downloaded to `out` if that is set).  The multi-GPU
+                         // entry points keep a shard's results on its device this way, for the RCCL gather.
+};
+
+constexpr int MAX_STAGERS = 8, MAX_DRAINERS = 4;
+inline int env_count(const char* name, int dflt, int max)
+{
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= max ? v : dflt;
+}
+
+// is [p, p + bytes) page-locked host memory the device can DMA from (hipHostMalloc / hipHostRegister /
+// c25519_amd_host_register)?  Such arrays skip the staging copies: the H2D / D2H copies run on the caller's memory.
+inline bool host_pinned(const void* p, size_t bytes)
+{
+    if (!p || !bytes) return false;
+    for (const char* q : { (const char*)p, (const char*)p + bytes - 1 }) {
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }   // pageable
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+template <typename Launch>
+int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
+{
+    ThreadState& t = tls();
+    C25519_RC(t.ensure());
+    const Arr* arr = arrays.begin();
+    const int na = (int)arrays.size();
+    if (na > ThreadState::SLOTS) return bad_arg("internal: too many arrays");
+    size_t row = 0;
+    for (int a = 0; a < na; a++) row += arr[a].elem;
+    static const size_t pieces = [] { const char* e = getenv("C25519_AMD_BATCH_PIECES"); int v = e ? atoi(e) : 0; return (size_t)(v >= 2 && v <= 64 ? v : 8); }();
+    size_t chunk = n >= ((size_t)1 << 17) ? round_up((n + pieces - 1) / pieces, 256) : n;
+    const size_t cap = round_up(((size_t)256 << 20) / (row ? row : 1) + 1, 256);       // <= 256 MiB of staging per buffer set
+    if (chunk > cap) chunk = cap;
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    const int sets = nchunks < (size_t)ThreadState::SETS ? (int)nchunks : ThreadState::SETS;
+    bool direct[ThreadState::SLOTS] = {};                  // the caller's array is pinned: no staging copy either way
+    for (int a = 0; a < na && n >= 4096; a++) {            // (not worth two attribute queries per array on a tiny call)
+        direct[a] = (!arr[a].in || host_pinned(arr[a].in, n * arr[a].elem)) && (!arr[a].out || host_pinned(arr[a].out, n * arr[a].elem));
+        if (arr[a].in && arr[a].out && arr[a].in != arr[a].out) direct[a] = false;
+    }
+    bool resident_result = false;                          // a device-resident array nobody downloads: synchronise at the end
+    for (int a = 0; a < na; a++)
+        if (arr[a].dev) {
+            if (arr[a].in) return bad_arg("internal: a device-resident array has no host source");
+            resident_result = resident_result || !arr[a].out;
+        }
+    for (int l = 0; l < sets; l++)
+        for (int a = 0; a < na; a++) {
+            if (!arr[a].dev) C25519_RC(t.reserve_dev(l, a, arr[a].elem * chunk));
+            if (!direct[a]) C25519_RC(t.reserve_host(l, a, arr[a].elem * chunk));
+        }
+    auto span = [&](size_t c, size_t& lo, size_t& cnt) { lo = c * chunk; cnt = (n - lo < chunk) ? n - lo : chunk; };
+    auto stage_in = [&](size_t c, int part, int parts) {   // rows [part, part+1) / parts of piece c
+        size_t lo, cnt;
+        span(c, lo, cnt);
+        const size_t r0 = cnt * part / parts, r1 = cnt * (part + 1) / parts;
+        const int l = (int)(c % sets);
+        for (int a = 0; a < na; a++)
+            if (arr[a].in && !direct[a] && (r1 - r0) * arr[a].elem)
+                memcpy((char*)t.hbuf[l][a] + r0 * arr[a].elem, (const char*)arr[a].in + (lo + r0) * arr[a].elem, (r1 - r0) * arr[a].elem);
+    };
+    // one piece: upload on the upload stream, kernels on one of the two kernel streams, download on the download
+    // stream, chained by events -- so the upload of a later piece never queues behind an earlier piece's kernels, and
+    // two pieces' kernels (2^18 lanes: full occupancy for every pass) are in flight while others move over PCIe
+    auto submit = [&](size_t c, bool one_stream) -> int {
+        size_t lo, cnt;
+        span(c, lo, cnt);
+        const int l = (int)(c % sets);
+        hipStream_t kern = t.stream[c & 1];
+        hipStream_t up = one_stream ? kern : t.stream[2], down = one_stream ? kern : t.stream[3];
+        void* dptr[ThreadState::SLOTS] = {};
+        for (int a = 0; a < na; a++) {
+            dptr[a] = arr[a].dev ? (void*)((char*)arr[a].dev + lo * arr[a].elem) : t.dbuf[l][a];
+            if (arr[a].in && cnt * arr[a].elem)
+                C25519_TRY(hipMemcpyAsync(dptr[a], direct[a] ? (const char*)arr[a].in + lo * arr[a].elem : (const char*)t.hbuf[l][a],
+                                          cnt * arr[a].elem, hipMemcpyHostToDevice, up));
+        }
+        if (!one_stream) {
+            C25519_TRY(hipEventRecord(t.uploaded[l], up));
+            C25519_TRY(hipStreamWaitEvent(kern, t.uploaded[l], 0));
+        }
+        C25519_RC(launch(dptr, cnt, lo, kern));
+        if (!one_stream) {
+            C25519_TRY(hipEventRecord(t.computed[l], kern));
+            C25519_TRY(hipStreamWaitEvent(down, t.computed[l], 0));
+        }
+        for (int a = 0; a < na; a++)
+            if (arr[a].out && cnt * arr[a].elem)
+                C25519_TRY(hipMemcpyAsync(direct[a] ? (char*)arr[a].out + lo * arr[a].elem : (char*)t.hbuf[l][a], dptr[a],
+                                          cnt * arr[a].elem, hipMemcpyDeviceToHost, down));
+        C25519_TRY(hipEventRecord(t.done[l], down));
+        return 0;
+    };
+    auto drain = [&](size_t c) -> int {
+        size_t lo, cnt;
+        span(c, lo, cnt);
+        const int l = (int)(c % sets);
+        C25519_TRY(hipEventSynchronize(t.done[l]));
+        for (int a = 0; a < na; a++)
+            if (arr[a].out && !direct[a] && cnt * arr[a].elem) memcpy((char*)arr[a].out + lo * arr[a].elem, t.hbuf[l][a], cnt * arr[a].elem);
+        return 0;
+    };
+
+    // every stream of the thread idle again: after an error (copies may still be writing the caller's pinned arrays or the
+    // staging buffers), and when a result stays on the device with no download to wait for
+    auto quiesce = [&]() {
+        for (int l = 0; l < ThreadState::LANES; l++)
+            if (t.stream[l]) (void)hipStreamSynchronize(t.stream[l]);
+        (void)hipGetLastError();
+    };
+    auto sequential = [&]() -> int {                      // no helper threads: one piece after the other
+        for (size_t c = 0; c < nchunks; c++) {
+            stage_in(c, 0, 1);
+            int rc = submit(c, true);
+            if (!rc) rc = drain(c);
+            if (rc) { quiesce(); return rc; }
+        }
+        if (resident_result) quiesce();
+        return 0;
+    };
+    if (nchunks == 1) return sequential();
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> staged(nchunks, 0), drained(nchunks, 0);
+    size_t submitted = 0;
+    int failed = 0;                                       // first error of any role; everybody stops
+    // helper threads: 4 + 2 on a machine with cores to spare (sign moves 160 B per 1.8 ns of kernel time: one copier
+    // per direction cannot keep up), 2 + 1 on a small one
+    static const bool roomy = std::thread::hardware_concurrency() >= 16;
+    static const int STAGERS = env_count("C25519_AMD_STAGERS", roomy ? 4 : 2, MAX_STAGERS);
+    static const int DRAINERS = env_count("C25519_AMD_DRAINERS", roomy ? 2 : 1, MAX_DRAINERS);
+    std::thread helpers[MAX_STAGERS + MAX_DRAINERS];
+    int started = 0;
+    try {
+    for (int sidx = 0; sidx < STAGERS; sidx++, started++)
+        helpers[started] = std::thread([&, sidx] {
+            for (size_t c = 0; c < nchunks; c++) {        // every stager copies its share of every piece: pieces
+                                                          // become ready in order, each in 1/STAGERS of the time
+                {   // the previous piece in this buffer set must have left its pinned buffers
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return failed || c < (size_t)sets || drained[c - sets]; });
+                    if (failed) return;
+                }
+                stage_in(c, sidx, STAGERS);
+                { std::lock_guard<std::mutex> lk(mu); staged[c]++; }
+                cv.notify_all();
+            }
+        });
+    for (int didx = 0; didx < DRAINERS; didx++, started++)
+        helpers[started] = std::thread([&, didx] {
+            for (size_t c = didx; c < nchunks; c += DRAINERS) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return failed || submitted > c; });
+                    if (failed) return;
+                }
+                const int rc = drain(c);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (rc && !failed) failed = rc;
+                    drained[c] = 1;
+                }
+                cv.notify_all();
+            }
+        });
+    } catch (const std::system_error&) {                  // the process cannot have more threads: do without them
+        { std::lock_guard<std::mutex> lk(mu); failed = -1; }
+        cv.notify_all();
+        for (int i = 0; i < started; i++) helpers[i].join();
+        return sequential();
+    }
+    for (size_t c = 0; c < nchunks; c++) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return failed || staged[c] == STAGERS; });
+            if (failed) break;
+        }
+        const int rc = submit(c, false);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc && !failed) failed = rc;
+            submitted = c + 1;
+        }
+        cv.notify_all();
+        if (rc) break;
+    }
+    for (int i = 0; i < started; i++) helpers[i].join();
+    if (failed || resident_result) quiesce();
+    return failed;
+}
+
+}  // namespace c25519_host

@@ -364,8 +364,9 @@ C25519_DEV void sc_fold8_columns(u32 (&cols)[8], const u32 (&k)[8])
 constexpr int WTABLE_ROWS = 9;
 constexpr size_t WTABLE_WORDS = WTABLE_ROWS * PE_WORDS;   // 360 words = 1440 bytes per table
 
-// (x, y) affine.  P's own row is re-read from the table for the three "+ P" steps (ge_add_pe_row below), so only two
-// extended points live in registers: 2P, then 3P, 6P, 7P, then 4P, 5P, 8P.
+// (x, y) affine.  ONE extended point lives in registers: P's own row is re-read from the table for the three "+ P"
+// steps (ge_add_pe_row below), 2P and 4P for the doublings that restart from them (a product and two carry passes each):
+// P, 2P, 3P, 6P, 7P, then (2P ->) 4P, 5P, then (4P ->) 8P.  Built this way the tables fit the walk kernel's registers.
 template <typename Tbl>
 C25519_DEV void wtable_build(const Tbl& tbl, const fe& x, const fe& y);
 
@@ -410,11 +411,13 @@ C25519_DEV void ge_add_pe_row(ge_ext& S, const u32* row, u32 neg)
     fe_mul(a, S.T, q);                               // C
     load_fe_words(q, row + 30);
     fe_mul(b, S.Z, q);                               // D
-    fe_sub(f, b, a);
+    fe_sub(f, b, a);                                 // beta 3: still a legal second operand
     fe_add(g, b, a);
+    // second operands f, h, f, h: their 19-multiples (nine v_mul_lo_u32 each) are formed twice, not four times, and the
+    // doubled odd limbs of the first operands e, e, g, g likewise
     fe_mul(S.X, e, f);
     if (NEED_T) fe_mul(S.T, e, h);
-    fe_mul(S.Z, f, g);
+    fe_mul(S.Z, g, f);
     fe_mul(S.Y, g, h);
 }
 
@@ -446,27 +449,56 @@ C25519_DEV void ge_add_pa_lds(ge_ext& S, const u32* tbl, u32 r, bool need_t)
     fe_mul(S.Y, g, h);
 }
 
+// row <- PE form of S (ge_to_pe), written two fields at a time so that twenty words, not forty, wait in registers for
+// their stores (rows are 16-byte aligned: five 16-byte stores per half)
+C25519_DEV void store_two_fields(u32* p, const fe& a, const fe& b)
+{
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+    q[2] = make_uint4(a.v[8], a.v[9], b.v[0], b.v[1]);
+    q[3] = make_uint4(b.v[2], b.v[3], b.v[4], b.v[5]);
+    q[4] = make_uint4(b.v[6], b.v[7], b.v[8], b.v[9]);
+}
+C25519_DEV void ge_store_pe_row(u32* row, const ge_ext& S)
+{
+    fe t, a, b;
+    fe_add(t, S.Y, S.X);  fe_carry32(a, t);
+    fe_sub(t, S.Y, S.X);  fe_carry32(b, t);
+    store_two_fields(row, a, b);
+    fe_mul(a, S.T, fe_const(K_2D));
+    fe_add(t, S.Z, S.Z);  fe_carry32(b, t);
+    store_two_fields(row + 20, a, b);
+}
+
 template <typename Tbl>
 C25519_DEV void wtable_build(const Tbl& tbl, const fe& x, const fe& y)
 {
-    ge_pe pe;
-    ge_ext P2, U;
-    fe_set_u32(pe.ypx, 1); fe_set_u32(pe.ymx, 1); fe_set_u32(pe.t2d, 0); fe_set_u32(pe.z2, 2);
-    tbl.store(0, pe);
-    P2.X = x; P2.Y = y;
-    fe_mul(P2.T, x, y);
-    fe_set_u32(P2.Z, 1);
-    ge_to_pe(pe, P2);               tbl.store(1, pe);
-    const u32* row1 = tbl.base + PE_WORDS;
-    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(2, pe);
-    U = P2;
-    ge_add_pe_row<true>(U, row1, 0u);   ge_to_pe(pe, U);  tbl.store(3, pe);
-    ge_double<true>(U);             ge_to_pe(pe, U);  tbl.store(6, pe);
-    ge_add_pe_row<true>(U, row1, 0u);   ge_to_pe(pe, U);  tbl.store(7, pe);
-    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(4, pe);
-    U = P2;
-    ge_add_pe_row<true>(U, row1, 0u);   ge_to_pe(pe, U);  tbl.store(5, pe);
-    ge_double<true>(P2);            ge_to_pe(pe, P2); tbl.store(8, pe);
+    ge_ext S;
+    {
+        ge_pe pe;
+        fe_set_u32(pe.ypx, 1); fe_set_u32(pe.ymx, 1); fe_set_u32(pe.t2d, 0); fe_set_u32(pe.z2, 2);
+        tbl.store(0, pe);
+    }
+    S.X = x; S.Y = y;
+    fe_mul(S.T, x, y);
+    fe_set_u32(S.Z, 1);
+    u32* const rows = tbl.base;
+    ge_store_pe_row(rows + PE_WORDS, S);
+    // seven steps, alternately a doubling and "+ P", as a loop (one copy of each operation, and the scheduler cannot
+    // stretch live ranges across steps: the straight-line version took 207 registers, this one fits the 168 of three
+    // waves per SIMD): rows 2, 3, 6, 7, then from 2P: 4, 5, then from 4P: 8
+#pragma unroll 1
+    for (int step = 0; step < 7; step++) {
+        if (step == 4 || step == 6) {
+            ge_pe pe;
+            tbl.load(pe, step == 4 ? 2u : 4u);
+            ge_from_pe(S, pe);
+        }
+        if (step & 1) ge_add_pe_row<true>(S, rows + PE_WORDS, 0u);
+        else ge_double<true>(S);
+        ge_store_pe_row(rows + ((0x8547632u >> (4 * step)) & 15u) * PE_WORDS, S);
+    }
 }
 
 // ---- the walk ----------------------------------------------------------------------------------------------------------

@@ -311,6 +311,25 @@ def main():
     t2d_neg = select(neg(R, "pe_cond_neg t2d"), R)           # beta 2 where the row was negated
     for v in ge_add(R, R, R, R, R, R, t2d_neg, R):           # ge_add_pe with a conditionally negated row
         need(all(v[i] <= R[i] for i in range(10)), "add with a negated row: output not reduced")
+
+    def ge_add_pe_row(X, Y, Z, T, ypx, ymx, t2d, z2):        # verify_fast.cuh: the streamed addition's operand order
+        a = mul(sub(Y, X, "row add Y-X"), ymx, "row add a")
+        b = mul(add(Y, X), ypx, "row add b")
+        e, h = sub(b, a, "row add e"), add(b, a)
+        c, d = mul(T, t2d, "row add c"), mul(Z, z2, "row add d")
+        f, g = sub(d, c, "row add f"), add(d, c)
+        return mul(e, f, "row add X"), mul(e, h, "row add T"), mul(g, f, "row add Z"), mul(g, h, "row add Y")
+
+    def ge_add_pa_lds(X, Y, Z, T, ypx, ymx, t2d):            # ... and the streamed affine addition from the LDS table
+        a = mul(sub(Y, X, "lds add Y-X"), ymx, "lds add a")
+        b = mul(add(Y, X), ypx, "lds add b")
+        e, h = sub(b, a, "lds add e"), add(b, a)
+        c, d = mul(T, t2d, "lds add c"), add(Z, Z)
+        f, g = sub(d, c, "lds add f"), add(d, c)
+        return mul(f, e, "lds add X"), mul(e, h, "lds add T"), mul(f, g, "lds add Z"), mul(g, h, "lds add Y")
+
+    for v in ge_add_pe_row(R, R, R, R, R, R, t2d_neg, R) + ge_add_pa_lds(R, R, R, R, CANON, CANON, CANON):
+        need(all(v[i] <= R[i] for i in range(10)), "streamed addition: output not reduced")
     mul(t2d_neg, CANON, "from_pe T of a negated row")        # ge_from_pe: t2d is the FIRST operand (beta <= 5)
     to_words(add(mul(sqr(R, "check x^2"), add(R, ONE), "check v x^2"), R), "calc check c + u")      # ge_calc_x_checked
     to_words(sub(R, R, "neutral Y - Z"), "neutral test to_words")
