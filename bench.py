@@ -105,6 +105,25 @@ def measured_traffic(kernels):
         return None, None
 
 
+def measured_valu_busy(kernels):
+    """Fraction of SIMD cycles in which a VALU instruction was executing, over the pass's kernels, from the committed PMC
+    pass: sum(SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs) / sum(GRBM_GUI_ACTIVE / 8 XCDs) -- the gfx9 VALUBusy formula, the two
+    counters taken in the same rocprofv3 pass.  Near 1.0 means the pass is bound by VALU issue at the clock the chip
+    sustained under it, whatever share of those instructions are multiplies."""
+    try:
+        path = latest_profile("r[0-9][0-9]_pmc.json")
+        with open(path) as f:
+            d = json.load(f)
+        def rec(name):
+            hits = [v for k, v in d.items() if name.rstrip(">") in k and "<true>" not in k]
+            return hits[0]
+        act = sum(rec(k)["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024 for k in kernels)
+        gui = sum(rec(k)["GRBM_GUI_ACTIVE_same_pass"] / 8.0 for k in kernels)
+        return round(act / gui, 4), os.path.basename(path)
+    except Exception:
+        return None, None
+
+
 def roofline_for(wl, n, kernel_ms):
     """The contract's roofline object for one pass of workload `wl` (n operations, mean kernel time kernel_ms)."""
     kernel_s = kernel_ms * 1e-3
@@ -112,6 +131,7 @@ def roofline_for(wl, n, kernel_ms):
     peak_mac, peak_src = measured_mad_peak()
     traffic, traffic_src = measured_traffic(PASS_KERNELS[wl])
     achieved_mac = MACS_PER_OP[wl] * n / kernel_s
+    valu_busy, busy_src = measured_valu_busy(PASS_KERNELS[wl])
     return {
         "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
@@ -125,7 +145,10 @@ def roofline_for(wl, n, kernel_ms):
                  "algorithmic_macs_per_op": MACS_PER_OP[wl],
                  "executed_macs_per_op": EXECUTED_MACS_PER_OP[wl],
                  "frac_executed": round(EXECUTED_MACS_PER_OP[wl] * n / kernel_s / peak_mac, 4) if peak_mac else None,
-                 "peak_source": f"profiles/{peak_src}" if peak_src else None},
+                 "peak_source": f"profiles/{peak_src}" if peak_src else None,
+                 "valu_busy": valu_busy,
+                 "valu_busy_source": f"profiles/{busy_src}: SQ_ACTIVE_INST_VALU*4/1024 over GRBM_GUI_ACTIVE/8, same PMC pass"
+                                     if busy_src else None},
     }
 
 
@@ -347,19 +370,41 @@ def main():
         finish()                             # every gather of the timed steps has completed inside the timed region
         barrier()
         elapsed = time.perf_counter() - t0
+        kms = [sum(events[k][j][0].elapsed_time(events[k][j][1]) for k in range(args.steps)) / max(1, args.steps)
+               for j in range(len(passes))]
+        attribution = None
         if use_dist:
+            local_ms = elapsed / max(1, args.steps) * 1e3
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        kms = [sum(events[k][j][0].elapsed_time(events[k][j][1]) for k in range(args.steps)) / max(1, args.steps)
-               for j in range(len(passes))]
-        return elapsed, kms, outs
+            # what a sub-linear N-GPU result would be made of: every rank's own kernel time and step time, and the
+            # gathers timed ALONE afterwards (K steps of gathers with nothing to hide under; in the timed region above
+            # they ran underneath the next batch's kernels)
+            barrier()
+            g0 = time.perf_counter()
+            for _ in range(args.steps):
+                for og in ogs:
+                    og.next_buffer()
+                    og.submit()
+            finish()
+            barrier()
+            gather_ms = (time.perf_counter() - g0) / max(1, args.steps) * 1e3
+            mine = {"rank": rank, "kernel_ms": [round(k, 4) for k in kms], "step_ms": round(local_ms, 4),
+                    "gather_ms_alone": round(gather_ms, 4)}
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+            attribution = everyone
+        return elapsed, kms, outs, attribution
 
-    def summarize(p, elapsed, kernel_ms, out):
+    def summarize(p, elapsed, kernel_ms, out, attribution=None, j=0):
         r = {"value": round(world * p["n"] * args.steps / elapsed, 1), "unit": "ops/s",
              "ms_per_step": round(elapsed / args.steps * 1e3, 4), "steps": args.steps, "warmup": args.warmup,
              "n_gpus": world, "batch_per_gpu": p["n"], "workload": WORKLOAD_NAME[p["wl"]],
              "roofline": roofline_for(p["wl"], p["n"], kernel_ms)}
+        if attribution:
+            r["per_rank"] = [{"rank": a["rank"], "kernel_ms": a["kernel_ms"][j], "step_ms": a["step_ms"],
+                              "gather_ms_alone": a["gather_ms_alone"]} for a in attribution]
         if p["wl"] == "verify":
             rejected = (out.view(-1) == 0).cpu().numpy()
             r["rejected"] = int(rejected.sum())
@@ -371,8 +416,8 @@ def main():
     if wl == "mixed":
         (x0, x1), (s0, s1), (v0, v1) = mixed_thirds(n)
         passes = [make_x25519(x1 - x0, x0), make_sign(s1 - s0, s0), make_verify(v1 - v0, v0)]
-        elapsed, kms, outs = run_timed(passes)
-        parts = [summarize(p, elapsed, k, o) for p, k, o in zip(passes, kms, outs)]
+        elapsed, kms, outs, attr = run_timed(passes)
+        parts = [summarize(p, elapsed, k, o, attr, j) for j, (p, k, o) in enumerate(zip(passes, kms, outs))]
         kernel_ms = sum(kms)
         bytes_per_launch = sum(BYTES_PER_OP[p["wl"]] * p["n"] for p in passes)
         macs = sum(MACS_PER_OP[p["wl"]] * p["n"] for p in passes)
@@ -392,14 +437,14 @@ def main():
     else:
         make = {"x25519": make_x25519, "sign": make_sign, "verify": make_verify}[wl]
         p = make(n)
-        elapsed, kms, outs = run_timed([p])
-        primary = summarize(p, elapsed, kms[0], outs[0])
+        elapsed, kms, outs, attr = run_timed([p])
+        primary = summarize(p, elapsed, kms[0], outs[0], attr)
         if wl == "x25519" and not args.no_side:
             # the second half of BASELINE.json's metric, and config 3, with the same protocol
             for name, mk in (("verify", make_verify), ("sign", make_sign)):
                 q = mk(n)
-                e2, k2, o2 = run_timed([q])
-                side[name] = summarize(q, e2, k2[0], o2[0])
+                e2, k2, o2, a2 = run_timed([q])
+                side[name] = summarize(q, e2, k2[0], o2[0], a2)
 
     result = None
     if rank == 0:
@@ -423,6 +468,10 @@ def main():
                                                           if use_dist else "")},
             "roofline": roof,
         }
+        if primary.get("per_rank"):
+            result["per_rank"] = primary["per_rank"]
+        if wl == "mixed" and parts[0].get("per_rank"):
+            result["per_rank"] = {q["wl"]: r.get("per_rank") for q, r in zip(passes, parts)}
         result.update(side)
 
     # ---- extra measurements outside the protocol above (rank 0, single GPU, default workload only) ----

@@ -152,18 +152,18 @@ __global__ void __launch_bounds__(XF_BLOCK, C25519_XF_WAVES) k_x25519_fused(void
 // ------------------------------------------------------------------------------------------------
 // 8-fold base table, generated on the device at first use
 // ------------------------------------------------------------------------------------------------
-// Block 0, thread group t (128 threads each): the signed comb tables T_t = 2^((BASE_NT-1-t)*BASE_STEP) * Ts of
-// ge_base_mult (ge_signed_comb_row).  Block 1, 256 threads: row k = sum over set bits i of k of 2^(32 i) * B as canonical
+// Workgroup t < BASE_NT (128 threads each): the signed comb table T_t = 2^((BASE_NT-1-t)*BASE_STEP) * Ts of
+// ge_base_mult (ge_signed_comb_row).  Two more workgroups: row k = sum over set bits i of k of 2^(32 i) * B as canonical
 // (Y+X, Y-X, 2dT) -- the content of the reference's source/base_folding8.h, derived from B by doubling/adding (the recipe
 // of test/curve25519_selftest.c:498-551) -- written twice: limb-major limbs after the signed tables (REF_TBL_OFFSET:
 // verification's sigma columns) and 96-byte canonical rows for inspection.
-__global__ void __launch_bounds__(BASE_ROWS * BASE_NT) k_gen_base_table(u32* tbl_limbs /*[BASE_NT][30][128] + [30][256]*/,
-                                                                        u32* tbl_bytes /*[256][24]*/)
+__global__ void __launch_bounds__(BASE_ROWS) k_gen_base_table(u32* tbl_limbs /*[BASE_NT][30][128] + [30][256]*/,
+                                                              u32* tbl_bytes /*[256][24]*/)
 {
     u32 rows[3][8];
-    if (blockIdx.x == 0) {
-        const u32 idx = threadIdx.x & (BASE_ROWS - 1);
-        const int group = threadIdx.x / BASE_ROWS;
+    if (blockIdx.x < BASE_NT) {                               // workgroup g: signed comb table g, one row per thread
+        const u32 idx = threadIdx.x;
+        const int group = blockIdx.x;
         ge_signed_comb_row(rows, idx, (BASE_NT - 1 - group) * BASE_STEP);
         u32* limbs = tbl_limbs + group * BASE_TBL_WORDS;
 #pragma unroll
@@ -175,8 +175,7 @@ __global__ void __launch_bounds__(BASE_ROWS * BASE_NT) k_gen_base_table(u32* tbl
         }
         return;
     }
-    if (threadIdx.x >= 256) return;
-    const u32 k = threadIdx.x;
+    const u32 k = (blockIdx.x - BASE_NT) * BASE_ROWS + threadIdx.x;   // two more workgroups: the reference table's 256 rows
     ge_base_table_row(rows, k, 0);
     u32* limbs = tbl_limbs + REF_TBL_OFFSET;
 #pragma unroll
@@ -218,9 +217,7 @@ template <bool BLIND>
 C25519_DEV void base_mult_maybe_blinded(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl, const u32* blind_ctx)
 {
     if (BLIND) {
-        ge_blinding b;
-        blinding_from_words(b, blind_ctx);
-        ge_base_mult_blinded(S, k, b, lds_tbl);
+        ge_base_mult_blinded(S, k, blind_ctx, lds_tbl);
     } else {
         ge_base_mult(S, k, lds_tbl);
     }
@@ -733,7 +730,7 @@ int init_tables(DeviceTables& t)
 {
     C25519_TRY(hipMalloc(&t.limbs, (REF_TBL_OFFSET + REF_TBL_WORDS) * sizeof(u32)));
     C25519_TRY(hipMalloc(&t.bytes, 256 * 24 * sizeof(u32)));
-    k_gen_base_table<<<2, BASE_ROWS * BASE_NT, 0, nullptr>>>(t.limbs, t.bytes);
+    k_gen_base_table<<<BASE_NT + 256 / BASE_ROWS, BASE_ROWS, 0, nullptr>>>(t.limbs, t.bytes);
     C25519_TRY(hipGetLastError());
     C25519_TRY(hipStreamSynchronize(nullptr));
     return 0;
@@ -809,11 +806,13 @@ template <typename Fin>
 int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t stream)
 {
     int K = inversion_k(n);
-    K = K >= 16 ? 16 : K >= 8 ? 8 : K >= 4 ? 4 : K >= 2 ? 2 : 1;           // the instantiated group sizes
+    K = K >= 16 ? 16 : K >= 14 ? 14 : K >= 12 ? 12 : K >= 8 ? 8 : K >= 4 ? 4 : K >= 2 ? 2 : 1;           // the instantiated group sizes
     const size_t m = (n + K - 1) / K;
     const unsigned grid = grid_for(m, INV_BLOCK);
     switch (K) {
         case 16: k_batch_invert<Fin, 16><<<grid, INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, fin); break;
+        case 14: k_batch_invert<Fin, 14><<<grid, INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, fin); break;
+        case 12: k_batch_invert<Fin, 12><<<grid, INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, fin); break;
         case 8:  k_batch_invert<Fin, 8><<<grid, INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, fin); break;
         case 4:  k_batch_invert<Fin, 4><<<grid, INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, fin); break;
         case 2:  k_batch_invert<Fin, 2><<<grid, INV_BLOCK, 0, stream>>>(scr.z, scr.prefix, n, m, fin); break;

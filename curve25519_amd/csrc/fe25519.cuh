@@ -79,8 +79,8 @@ C25519_DEV void fe_select(fe& r, u32 mask, const fe& a, const fe& b)
 // limbs l[0..9] hold the masked columns, `carry` is what left column 9: fold it back times 19
 C25519_DEV void fe_finish_chain(fe& r, u32 (&l)[10], u64 carry)
 {
-#ifdef C25519_FENCE_FIELD
-    __builtin_amdgcn_sched_barrier(0);
+#ifdef C25519_FENCE_FIELD                 // A/B knob (profiles/r03_ab_fence.txt): a fence behind every product
+    C25519_SCHED_FENCE();
 #endif
     const u64 t = carry * 19 + l[0];
     l[0] = (u32)t & M26;

@@ -68,6 +68,27 @@ C25519_DEV void ge_add_pa(ge_ext& p, const ge_pa& q)
     fe_mul(p.Z, f, g);
 }
 
+// the same addition with T produced on a run-time (wave-uniform) request: ONE copy of the addition where the template
+// would put two into a loop (ge_base_mult's last table: T only before the blinding point is added)
+C25519_DEV void ge_add_pa_rt(ge_ext& p, const ge_pa& q, bool need_t)
+{
+    fe a, b, c, d, e, f, g, h;
+    fe_sub(a, p.Y, p.X);
+    fe_mul(a, a, q.ymx);
+    fe_add(b, p.Y, p.X);
+    fe_mul(b, b, q.ypx);
+    fe_mul(c, p.T, q.t2d);
+    fe_add(d, p.Z, p.Z);
+    fe_sub(e, b, a);
+    fe_add(h, b, a);
+    fe_sub(f, d, c);
+    fe_add(g, d, c);
+    fe_mul(p.X, f, e);
+    fe_mul(p.Y, g, h);
+    if (need_t) fe_mul(p.T, e, h);
+    fe_mul(p.Z, f, g);
+}
+
 // r = p + q, q projective precomputed with reduced limbs.  8M.   (edp_AddPoint)
 template <bool NEED_T = true>
 C25519_DEV void ge_add_pe(ge_ext& r, const ge_ext& p, const ge_pe& q)
@@ -282,11 +303,13 @@ C25519_DEV void ge_base_mult(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl, c
 #pragma unroll 1
         for (int t = m ? 0 : 1; t < BASE_NT - 1; t++) {
             lds_load_pa_signed(q, lds_tbl + t * BASE_TBL_WORDS, fold8_at(w, t * BASE_STEP + m));
-            ge_add_pa<true>(S, q);
+            C25519_SCHED_FENCE();          // the row is complete before the addition starts: without it the 1024-thread
+            ge_add_pa<true>(S, q);         // kernels (128 registers) spilled two to four registers
         }
         // last table: a doubling or the affine conversion follows, neither reads T
         lds_load_pa_signed(q, lds_tbl + (BASE_NT - 1) * BASE_TBL_WORDS, fold8_at(w, (BASE_NT - 1) * BASE_STEP + m));
-        if (FINAL_T && m == BASE_STEP - 1) ge_add_pa<true>(S, q);
+        C25519_SCHED_FENCE();
+        if (FINAL_T) ge_add_pa_rt(S, q, m == BASE_STEP - 1);
         else ge_add_pa<false>(S, q);
     }
 }

@@ -135,36 +135,48 @@ C25519_DEV void ed_decode_neg_key(ge_ext& Q, const u32 (&pkw)[8])
 // so that (k + bl)*B + BP = k*B: the table lookups and the walk see a scalar that changes with every context.
 constexpr int BLIND_WORDS = 48;
 
-struct ge_blinding {
-    u32 bl[8];
-    fe zr;
-    ge_pe BP;
-};
-
-C25519_DEV void blinding_from_words(ge_blinding& b, const u32* ctx)
+// S = k*B computed as (k + bl)*B + BP with the starting point's Z randomised   (edp_BasePointMultiply, blinding != 0).
+// ctx: the 48 context words (wave-uniform).  Only bl and zr are read before the walk; the four fields of BP are fetched
+// one at a time for the final addition (held across the walk they cost 40 registers the 1024-thread kernels do not have).
+// k + bl is reduced mod L before the recoding: sc_signed_comb adds L to an even scalar in 256 bits, so it needs its input
+// below 2^256 - L; contexts from ed25519_Blinding_Init have bl <= L, but a context is caller-supplied bytes.
+C25519_DEV void ge_base_mult_blinded(ge_ext& S, const u32 (&k)[8], const u32* ctx, const u32* lds_tbl)
 {
-    u32 w[8];
+    u32 t[8], w[8];
+    {
+        u32 bl[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) b.bl[i] = ctx[i];
+        for (int i = 0; i < 8; i++) bl[i] = ctx[i];
+        sc_add(t, k, bl);                     // 256 bits, congruent to k + bl mod L (eco_AddReduce :255)
+        sc_mod(t);
+    }
+    {
+        fe zr;
 #pragma unroll
-    for (int i = 0; i < 8; i++) w[i] = ctx[8 + i];
-    fe_from_words(b.zr, w);
-    fe* f[4] = { &b.BP.ypx, &b.BP.ymx, &b.BP.t2d, &b.BP.z2 };
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
+        for (int i = 0; i < 8; i++) w[i] = ctx[8 + i];
+        fe_from_words(zr, w);
+        ge_base_mult<true>(S, t, lds_tbl, &zr);  // T of the result feeds the addition below
+    }
+    // S += BP (:257); the affine conversion that follows never reads T.  ge_add_pe with the fields streamed in.
+    fe q, a, b, e, f, g, h;
+    auto field = [&](int j) {
 #pragma unroll
         for (int i = 0; i < 8; i++) w[i] = ctx[16 + 8 * j + i];
-        fe_from_words(*f[j], w);
-    }
-}
-
-// S = k*B computed as (k + bl)*B + BP with the starting point's Z randomised   (edp_BasePointMultiply, blinding != 0)
-C25519_DEV void ge_base_mult_blinded(ge_ext& S, const u32 (&k)[8], const ge_blinding& b, const u32* lds_tbl)
-{
-    u32 t[8];
-    sc_add(t, k, b.bl);                       // 256 bits, congruent to k + bl mod L (eco_AddReduce :255)
-    ge_base_mult<true>(S, t, lds_tbl, &b.zr);  // T of the result feeds the addition below
-    ge_add_pe<false>(S, S, b.BP);             // :257; the affine conversion that follows never reads T
+        fe_from_words(q, w);
+    };
+    fe_sub(a, S.Y, S.X);
+    field(1);  fe_mul(a, a, q);               // (Y - X) * YmX
+    fe_add(b, S.Y, S.X);
+    field(0);  fe_mul(b, b, q);               // (Y + X) * YpX
+    fe_sub(e, b, a);
+    fe_add(h, b, a);
+    field(2);  fe_mul(a, S.T, q);             // C = T * T2d
+    field(3);  fe_mul(b, S.Z, q);             // D = Z * Z2
+    fe_sub(f, b, a);
+    fe_add(g, b, a);
+    fe_mul(S.X, e, f);
+    fe_mul(S.Z, g, f);
+    fe_mul(S.Y, g, h);
 }
 
 // ---- 8-fold base table rows ----------------------------------------------------------------------------------

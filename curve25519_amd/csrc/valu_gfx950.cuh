@@ -19,6 +19,9 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #define C25519_DEV __device__ __forceinline__
+// nothing is scheduled across this point: keeps the live ranges of two neighbouring field operations apart where the
+// scheduler's interleaving would cost registers the kernel does not have (a no-op in the CPU model)
+#define C25519_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // 2x as v_add_u32 x, x: v_add_u32 is full-rate, while v_lshlrev_b32 -- what the compiler picks for x*2 or x+x --
 // is in the half-rate class.

@@ -155,9 +155,7 @@ static void base_mult_any(ge_ext& S, const u32 (&k)[8], const unsigned char* bli
     if (blinding) {
         u32 w[BLIND_WORDS];
         memcpy(w, blinding, sizeof w);
-        ge_blinding b;
-        blinding_from_words(b, w);
-        ge_base_mult_blinded(S, k, b, tables());
+        ge_base_mult_blinded(S, k, w, tables());
     } else {
         ge_base_mult(S, k, tables());
     }

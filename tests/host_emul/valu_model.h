@@ -14,6 +14,7 @@
 #define __forceinline__ inline
 #define __restrict__
 #define C25519_DEV inline
+#define C25519_SCHED_FENCE() ((void)0)
 
 struct uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{ x, y, z, w }; }

@@ -637,9 +637,10 @@ def test_bench_mixed_and_self_launch_run():
 
 
 def test_c_abi_multi_device_entry_points(api):
-    """The C-level multi-GPU entry points (shards per device, one grouped ncclGather per output to devices[0]) with the
-    devices this box has -- one here, so RCCL runs a communicator of one rank; the shard / gather / read-back
-    bookkeeping is the same code for any count.  Results are the fixture's (the reference's) bytes."""
+    """The C-level multi-GPU entry points (one worker thread and pinned pipeline per device, one grouped ncclGather per
+    output to devices[0]) with EVERY device this box has: on a multi-GPU node that is a real RCCL communicator over xGMI,
+    on a one-GPU box a communicator of one rank -- the shard / worker / gather / slab-download code is the same for any
+    count.  Results are the fixture's (the reference's) bytes; sizes that do not divide by the device count included."""
     from curve25519_amd import _lib
     L = _lib.load()
     ndev = min(api.device_count(), 8)
@@ -649,7 +650,7 @@ def test_c_abi_multi_device_entry_points(api):
     try:
         assert L.c25519_amd_multi_device_count(h) == ndev
         g = {k: np.ascontiguousarray(R1024[k]) for k in R1024.files}     # materialise once: ctypes gets raw pointers
-        for n in (1024, 1000, 1):
+        for n in (1024, 1000, 1023, ndev, 1):
             sk, pk = g["x_sk"][:n].copy(), g["x_pk"][:n].copy()
             shared = np.empty((n, 32), np.uint8)
             _lib.check(L.curve25519_dh_CreateSharedKey_multi(h, shared.ctypes.data, pk.ctypes.data, sk.ctypes.data, n), "x25519 multi")
@@ -663,6 +664,15 @@ def test_c_abi_multi_device_entry_points(api):
             _lib.check(L.ed25519_VerifySignature_multi(h, ok.ctypes.data, vs.ctypes.data, pub.ctypes.data, vm.ctypes.data, 32, n), "verify multi")
             assert np.array_equal(ok, g["v_ok"][:n])
         assert L.curve25519_dh_CreateSharedKey_multi(h, shared.ctypes.data, g["x_pk"].ctypes.data, sk.ctypes.data, 0) == 0
+        # a batch big enough for every device's pipeline to run in pieces (2^17 per device and more), against the
+        # single-GPU host-pointer path on the same arrays
+        n = (1 << 17) * ndev + 1000
+        sk, pk = synth.x25519_inputs(n)
+        sk2 = sk.copy()
+        a, b = np.empty((n, 32), np.uint8), np.empty((n, 32), np.uint8)
+        _lib.check(L.curve25519_dh_CreateSharedKey_multi(h, a.ctypes.data, pk.ctypes.data, sk.ctypes.data, n), "x25519 multi (big)")
+        _lib.check(L.curve25519_dh_CreateSharedKey_batch(b.ctypes.data, pk.ctypes.data, sk2.ctypes.data, n), "x25519 batch (big)")
+        assert np.array_equal(a, b) and np.array_equal(sk, sk2)
     finally:
         L.c25519_amd_multi_destroy(h)
     bad = (C.c_int * 1)(63)
@@ -703,7 +713,7 @@ def test_host_pointer_api_keeps_up_with_the_device_rate(api):
     assert np.array_equal(out, dout.cpu().numpy())
     ratio = best["dev"] / best["host"]
     print(f"host-pointer X25519: {n / best['host'] / 1e6:.1f} M ops/s, device-resident {n / best['dev'] / 1e6:.1f} M ops/s, ratio {ratio:.2f}")
-    assert ratio >= 0.6, best                 # measured 0.77-0.85; round 1 was 0.48
+    assert ratio >= 0.8, best                 # measured 0.85-0.90; round 1 was 0.48
 
 
 def test_bench_self_launches_two_ranks():

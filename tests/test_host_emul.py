@@ -192,4 +192,16 @@ def test_blinding_is_real_and_output_neutral(dev, emul):
         assert np.array_equal(bpub, pub) and np.array_equal(bpriv, priv)
         assert np.array_equal(dev.sign(priv, msg, blinding=ctx), sig)
         assert t != 0
+        # a context is caller-supplied bytes: the same blinding scalar written as bl + m*L (any m that fits 256 bits) is the
+        # same context mathematically, and k + bl then reaches 2^256 - L and beyond -- where the signed comb's "+ L" would
+        # overflow 256 bits if the sum were not reduced first.  Outputs must not move.
+        for m in (14, 15):
+            big = bl + m * vectors.L
+            if big >= 2**256:
+                continue
+            ctx2 = ctx.copy()
+            ctx2[:32] = vectors.le(big, 32)
+            bpub, bpriv = dev.keypair(sk, blinding=ctx2)
+            assert np.array_equal(bpub, pub) and np.array_equal(bpriv, priv)
+            assert np.array_equal(dev.sign(priv, msg, blinding=ctx2), sig)
     assert len(seen) == 4

@@ -47,8 +47,8 @@ if has prof; then
   BENCHX="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu"
   timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_fetch -o fetch -- $BENCHX > $OUT/prof_fetch.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/prof_write -o write -- $BENCHX > $OUT/prof_write.log 2>&1
-  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $OUT/prof_sq -o sq -- $BENCHX > $OUT/prof_sq.log 2>&1
-  timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM -d $OUT/prof_sq2 -o sq2 -- $BENCHX > $OUT/prof_sq2.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $OUT/prof_sq -o sq -- $BENCHX > $OUT/prof_sq.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQC_ICACHE_REQ SQC_ICACHE_MISSES -d $OUT/prof_sq2 -o sq2 -- $BENCHX > $OUT/prof_sq2.log 2>&1
   cd $REPO
   S=$(find $OUT/prof_stats -name '*.db' | head -1)
   [ -n "$S" ] && python tools/rocpd_summary.py stats $S > $OUT/kernel_stats.txt && cat $OUT/kernel_stats.txt

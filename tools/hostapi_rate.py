@@ -90,6 +90,24 @@ for name, cfn, rfn, pfn, dfn, moved in (
           f"({moved * n / tc / 1e9:5.1f} GB/s moved, staging inclusive; numpy wrapper {tp * 1e3:7.2f} ms) | *_dev "
           f"{td * 1e3:7.2f} ms = {n / td / 1e6:7.1f} M ops/s | ratio {td / tc:.2f} | caller's arrays registered "
           f"{tr * 1e3:7.2f} ms = {n / tr / 1e6:7.1f} M ops/s, ratio {td / tr:.2f}")
+# the multi-GPU C entry points over every device of the box (one here: the same shard / worker-thread / pinned-pipeline /
+# gather / slab-download code as for eight), against the single-GPU *_batch call on the same pageable arrays
+import ctypes as C  # noqa: E402
+ndev = min(api.device_count(), 8)
+mh = C.c_void_p()
+assert L.c25519_amd_multi_create(C.byref(mh), (C.c_int * ndev)(*range(ndev)), ndev) == 0
+m32, m64, mok = np.zeros((n, 32), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32)
+for name, mfn in (("x25519", lambda: L.curve25519_dh_CreateSharedKey_multi(mh, P(m32), P(pk), P(sk), n)),
+                  ("sign", lambda: L.ed25519_SignMessage_multi(mh, P(m64), P(priv), P(msg), 32, n)),
+                  ("verify", lambda: L.ed25519_VerifySignature_multi(mh, P(mok), P(sig), P(pub), P(msg), 32, n))):
+    assert mfn() == 0
+    tm = host_rate(mfn)
+    rows[name].update(multi_devices=ndev, multi_ms=round(tm * 1e3, 3), multi_Mops=round(n / tm / 1e6, 2),
+                      multi_over_batch=round(rows[name]["c_abi_ms"] * 1e-3 / tm, 3))
+    print(f"{name:7s} *_multi over {ndev} device(s) {tm * 1e3:8.2f} ms = {n / tm / 1e6:7.1f} M ops/s | ratio to *_batch "
+          f"{rows[name]['c_abi_ms'] * 1e-3 / tm:.2f}")
+L.c25519_amd_multi_destroy(mh)
+assert np.array_equal(m32, h32) and np.array_equal(m64, h64) and np.array_equal(mok, hok)
 assert np.array_equal(hok, np.ones(n, np.int32)) and np.array_equal(reg["hok"], hok)
 assert np.array_equal(reg["h32"], h32) and np.array_equal(reg["h64"], h64)
 for v in reg.values():

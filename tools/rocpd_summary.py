@@ -55,6 +55,14 @@ def pmc_json(paths):
                 continue
             out.setdefault(short(k), {})[c] = v
             out[short(k)].setdefault("dispatch_ms", {})[c] = d / 1e6
+        # the shader clock counter of the pass that also holds the VALU activity counter (bench.py's valu_busy needs the two
+        # from the same run: profiled clocks differ from pass to pass)
+        names = {r[0] for r in db.execute("select distinct counter_name from counters_collection")}
+        if "SQ_ACTIVE_INST_VALU" in names and "GRBM_GUI_ACTIVE" in names:
+            for k, v in db.execute("select kernel_name, avg(value) from counters_collection where counter_name = 'GRBM_GUI_ACTIVE' "
+                                   "group by kernel_name"):
+                if not k.startswith(("void at::", "__amd")):
+                    out[short(k)]["GRBM_GUI_ACTIVE_same_pass"] = v
     print(json.dumps(out, indent=1, sort_keys=True))
 
 
