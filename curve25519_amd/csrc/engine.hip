@@ -622,17 +622,21 @@ struct FinishVerify {                        // verdict = (enc(T) == enc(R) byte
 constexpr int INV_BLOCK = 64;
 constexpr int INV_MAX_K = 16;
 
-// K is a compile-time constant and both loops are unrolled: a lane's K elements and their K prefix products live in
-// registers (a lone wave per SIMD has the whole register file: 64-thread workgroups, no occupancy to protect), so the
-// loads of all K elements are issued up front instead of one dependent round trip per element and per pass, and the
-// prefix products never go to memory.  (`prefix` stays in the signature for the scratch layout's sake.)
+// K is a compile-time constant and the loops are unrolled: a lane's K elements live in registers (a lone wave per SIMD has
+// the whole register file: 64-thread workgroups, no occupancy to protect), so the loads of all K elements are issued up
+// front instead of one dependent round trip per element and per pass.  The K - 1 prefix products a lane needs again on
+// the way back stay in registers up to K = 14; at K = 16 they are parked in LDS (15 x 2560 bytes per wave, four waves
+// per CU: 150 of the 160 KiB, which nothing else in this kernel uses) -- with all 32 field elements in registers the
+// allocator spilled 14-25 of them to scratch.  (`prefix` stays in the signature for the scratch layout's sake.)
 template <typename Fin, int K>
 __global__ void __launch_bounds__(INV_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) k_batch_invert(const u32* Z, u32* prefix, size_t n, size_t m, Fin fin)
 {
     (void)prefix;
+    constexpr bool PREFIX_IN_LDS = K > 14;
+    __shared__ u32 pre_lds[PREFIX_IN_LDS ? (K - 1) * 10 * INV_BLOCK : 1];
     const size_t j = (size_t)blockIdx.x * INV_BLOCK + threadIdx.x;
     if (j >= m) return;
-    fe z[K], pre[K];
+    fe z[K], pre[PREFIX_IN_LDS ? 1 : K];
     u32 zero_mask = 0;
 #pragma unroll
     for (int t = 0; t < K; t++) {
@@ -640,20 +644,28 @@ __global__ void __launch_bounds__(INV_BLOCK) __attribute__((amdgpu_waves_per_eu(
         if (e < n) soa_load_fe(z[t], Z, n, e);
         else fe_set_u32(z[t], 1);                           // past the end: a factor of one
     }
+    fe acc;
 #pragma unroll
     for (int t = 0; t < K; t++) {
         zero_mask |= (fe_zero_to_one(z[t]) & 1u) << t;      // z == 0 (mod p) takes no part in the product
-        if (t == 0) pre[0] = z[0];
-        else fe_mul(pre[t], pre[t - 1], z[t]);
+        if (t == 0) acc = z[0];
+        else fe_mul(acc, acc, z[t]);
+        if (t < K - 1) {
+            if (PREFIX_IN_LDS) lds_put_fe(pre_lds + t * 10 * INV_BLOCK, INV_BLOCK, threadIdx.x, acc);
+            else pre[t] = acc;
+        }
     }
     fe inv;
-    fe_invert(inv, pre[K - 1]);
+    fe_invert(inv, acc);
 #pragma unroll
     for (int t = K - 1; t >= 0; t--) {
         const size_t e = j + (size_t)t * m;
         fe zi;
         if (t > 0) {
-            fe_mul(zi, inv, pre[t - 1]);
+            fe p;
+            if (PREFIX_IN_LDS) lds_get_fe(p, pre_lds + (t - 1) * 10 * INV_BLOCK, INV_BLOCK, threadIdx.x);
+            else p = pre[t - 1];
+            fe_mul(zi, inv, p);
             fe_mul(inv, inv, z[t]);
         } else {
             zi = inv;

@@ -191,6 +191,9 @@ template <typename Launch>
 int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch launch)
 {
     const int D = (int)m->dev.size();
+    // C25519_AMD_MULTI_FORCE_GATHER=1: a one-device handle takes the gather path too (how the tests run the N > 1 code --
+    // resident results, grouped ncclGather, slab download -- on a one-GPU box)
+    const bool gathers = D > 1 || getenv("C25519_AMD_MULTI_FORCE_GATHER") != nullptr;
     int prev = 0;
     C25519_TRY(hipGetDevice(&prev));
     std::vector<size_t> lo(D + 1);
@@ -207,9 +210,13 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
                 for (int a = 0; a < na; a++) {
                     pa[a] = Arr{ arr[a].in ? (const char*)arr[a].in + off * arr[a].elem : nullptr,
                                  arr[a].out && !arr[a].gather ? (char*)arr[a].out + off * arr[a].elem : nullptr, arr[a].elem };
-                    if (arr[a].out && arr[a].gather) {
+                    if (arr[a].out && arr[a].gather && gathers) {
                         C25519_RC(reserve(m->buf[a][d], m->cap[a][d], arr[a].elem * rows));
                         pa[a].dev = m->buf[a][d];
+                    } else if (arr[a].out && arr[a].gather) {
+                        // a handle of ONE device: the gather would hand the device its own rows back, so they leave
+                        // through the worker's pipeline like any output (piece by piece, under the next piece's kernels)
+                        pa[a].out = (char*)arr[a].out + off * arr[a].elem;
                     }
                 }
                 if (!cnt) return 0;
@@ -224,7 +231,7 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
         }
         int rc = 0;
         for (int d = 0; d < D; d++) { const int r = m->worker[d]->wait(); if (r && !rc) rc = r; }
-        if (rc) return rc;
+        if (rc || !gathers) return rc;
         // 2. the one exchange step: every device's rows of each gathered output -> devices[0]
         for (int a = 0; a < na; a++) {
             if (!arr[a].out || !arr[a].gather || !rows) continue;

@@ -636,12 +636,30 @@ def test_bench_mixed_and_self_launch_run():
             assert set(line["roofline"]["parts"]) == {"x25519", "sign", "verify"}
 
 
-def test_c_abi_multi_device_entry_points(api):
+def test_reference_openssl_harness_runs_on_this_library():
+    """The reference's second-opinion harness, test/openssl_test.c, compiled where it lies by `make -C oracle ref-openssl`
+    and linked against libcurve25519_amd.so + libcrypto: the key pair, public key, shared key and signature of OpenSSL's
+    X25519 / Ed25519 against this library's single-call drop-in API, byte for byte (its memcmp at :218-226).  Exit code =
+    number of mismatching operations."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "openssl_test_on_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/openssl_test_on_amd not built (needs /root/reference and libcrypto at build time)")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    assert "Mismatched" not in p.stdout and p.stdout.count("ratio") == 4
+
+
+@pytest.mark.parametrize("force_gather", [False, True])
+def test_c_abi_multi_device_entry_points(api, force_gather, monkeypatch):
     """The C-level multi-GPU entry points (one worker thread and pinned pipeline per device, one grouped ncclGather per
     output to devices[0]) with EVERY device this box has: on a multi-GPU node that is a real RCCL communicator over xGMI,
     on a one-GPU box a communicator of one rank -- the shard / worker / gather / slab-download code is the same for any
-    count.  Results are the fixture's (the reference's) bytes; sizes that do not divide by the device count included."""
+    count.  Results are the fixture's (the reference's) bytes; sizes that do not divide by the device count included.
+    A one-device handle normally skips the gather (its own rows would come back); force_gather makes it take the N > 1
+    path anyway."""
     from curve25519_amd import _lib
+    if force_gather:
+        monkeypatch.setenv("C25519_AMD_MULTI_FORCE_GATHER", "1")
     L = _lib.load()
     ndev = min(api.device_count(), 8)
     devs = (C.c_int * ndev)(*range(ndev))
