@@ -49,8 +49,8 @@ HBM_PEAK_GBS = 8000.0                                               # MI355X_MIC
 PASS_KERNELS = {
     "x25519": ("k_x25519_fused",),
     "sign": ("k_ed25519_sign_mult", "k_batch_invert<FinishPack>", "k_ed25519_sign_finish"),
-    "verify": ("k_ed25519_verify_fast_scalars", "k_ed25519_verify_fast_points", "k_ed25519_verify_fast_walk"),
-    # (k_ed25519_verify_slow runs beside the walk: nothing to do for on-curve keys)
+    "verify": ("k_ed25519_verify_fast_scalars", "k_ed25519_verify_fast_points", "k_ed25519_verify_fast_walk",
+               "k_ed25519_verify_slow"),                # (the slow list is empty for on-curve keys: a ~10 us launch)
 }
 METRIC_NAME = {
     "x25519": "X25519 shared-key ops/sec (batch=2^20 per GPU, variable-base Montgomery ladder) [+ Ed25519 verifies/sec "

@@ -98,14 +98,8 @@ struct ThreadState {
         bool used = false;
     };
     WorkSlab work[MAX_DEV];
-    // per device: a second stream for work that runs BESIDE a *_dev call's kernels on the caller's stream (forked and
-    // joined with the two events), and one device word that outlives the call's scratch (a counter the call reports)
-    struct Side {
-        hipStream_t stream = nullptr;
-        hipEvent_t fork = nullptr, join = nullptr;
-        unsigned* counter = nullptr;
-    };
-    Side side[MAX_DEV];
+    // per device: one device word that outlives a call's scratch (a counter the call reports afterwards)
+    unsigned* report_word[MAX_DEV] = {};
     WorkSlab lane_work[LANES];             // ... and one per pipeline lane, so that the pieces of a *_batch call do not
                                            // wait for each other's kernels (they belong to the staging device)
 
@@ -193,21 +187,17 @@ struct ThreadState {
         *out = w.ptr;
         return 0;
     }
-    int side_for_current_device(Side** out)
+    int report_word_for_current_device(unsigned** out)
     {
         int dev = 0;
         C25519_TRY(hipGetDevice(&dev));
         if (dev < 0 || dev >= MAX_DEV) return bad_arg("device ordinal out of range");
         arm_exit_guard();
-        Side& sd = side[dev];
-        if (!sd.stream) C25519_TRY(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
-        if (!sd.fork) C25519_TRY(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
-        if (!sd.join) C25519_TRY(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
-        if (!sd.counter) {
-            C25519_TRY(hipMalloc(&sd.counter, 256));
-            C25519_TRY(hipMemset(sd.counter, 0, 256));
+        if (!report_word[dev]) {
+            C25519_TRY(hipMalloc(&report_word[dev], 256));
+            C25519_TRY(hipMemset(report_word[dev], 0, 256));
         }
-        *out = &sd;
+        *out = report_word[dev];
         return 0;
     }
     int release_work(hipStream_t s)
@@ -255,16 +245,12 @@ struct ThreadState {
         (void)hipGetDevice(&cur);
         for (int d = 0; d < MAX_DEV; d++) {
             WorkSlab& w = work[d];
-            Side& sd = side[d];
-            if (!w.ptr && !w.done && !sd.stream && !sd.counter) continue;
+            if (!w.ptr && !w.done && !report_word[d]) continue;
             (void)hipSetDevice(d);
             (void)hipDeviceSynchronize();
             free_slab(w);
-            if (sd.counter) (void)hipFree(sd.counter);
-            if (sd.fork) (void)hipEventDestroy(sd.fork);
-            if (sd.join) (void)hipEventDestroy(sd.join);
-            if (sd.stream) (void)hipStreamDestroy(sd.stream);
-            sd = Side();
+            if (report_word[d]) (void)hipFree(report_word[d]);
+            report_word[d] = nullptr;
         }
         (void)hipGetLastError();
         if (cur >= 0) (void)hipSetDevice(cur);

@@ -498,11 +498,11 @@ C25519_DEV int verify_reference_order_lane(const u32 (&pkw)[8], const void* sig,
 }
 
 // step 5: the elements on the slow list (off-curve keys -- the reference does not reject them, so neither may we -- and
-// the practically nonexistent over-long vectors), one per lane, in the reference's order.  A fixed small grid strides
-// over the list (SLOW_GRID workgroups fill the chip at this kernel's two waves per SIMD; a full-size grid of workgroups
-// that only look at the counter and leave still has to be dispatched beside the walk, 232 registers and 30 KiB of LDS
-// each, and was measured to hold the walk back).  It runs on the thread's side stream beside the walk, whose lanes skip
-// the listed elements, so a few garbage keys in a batch cost no time at all.
+// the practically nonexistent over-long vectors), one per lane, in the reference's order, behind the walk on the same
+// stream.  A fixed small grid strides over the list: with honest keys the list is empty and the launch costs ~10 us; a
+// batch with garbage keys in it pays one reference-order verification's latency (~1.2 ms) on top.  (Tried and dropped:
+// the same kernel on a second, high-priority stream beside the walk -- its workgroups, 272 registers per lane, only ever
+// found room when the walk's last round drained, so it bought nothing: profiles/r03_ab_verify_structure.txt.)
 constexpr unsigned SLOW_GRID = 512;
 __global__ void __launch_bounds__(ED_BLOCK, 1) k_ed25519_verify_slow(FastScratch fs, int* verdict, const void* sig, const void* pk,
                                                                      Msgs msgs, const u32* __restrict__ g_tbl)
@@ -845,8 +845,7 @@ inline size_t verify_scratch_bytes(size_t n)
 }
 
 // fast = true: the lattice path (verify_fast.cuh) decides every element whose key is on the curve and whose short vector
-// fits; the reference's order runs for the others in a kernel of its own, on the thread's side stream beside the walk
-// (C25519_AMD_VERIFY_NO_SIDE_STREAM=1: behind it on the caller's stream).  fast = false: reference order for everything,
+// fits; the reference's order runs for the others in a kernel of its own behind the walk.  fast = false: reference order for everything,
 // and Fin decides what leaves it: the verdict, or enc(T) for the test hook.
 // what the calling thread's last fast-path verification left behind for c25519_amd_verify_last_slow_elements
 struct LastVerify { const u32* count = nullptr; hipStream_t stream = nullptr; int device = -1; };
@@ -855,7 +854,6 @@ thread_local LastVerify tl_last_verify;
 template <typename MakeFin>
 int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t stream, int* verdict, bool fast, MakeFin make_fin)
 {
-    static const bool side_ok = getenv("C25519_AMD_VERIFY_NO_SIDE_STREAM") == nullptr;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
@@ -864,8 +862,8 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
     u32* tables = (u32*)w + proj_words(n);
     const unsigned grid = grid_for(n, ED_BLOCK);
     if (fast) {
-        ThreadState::Side* side = nullptr;
-        C25519_RC(tls().side_for_current_device(&side));
+        unsigned* report = nullptr;
+        C25519_RC(tls().report_word_for_current_device(&report));
         FastScratch fs;
         fs.tables = tables;
         fs.sigma = tables + n * VERIFY_TABLE_WORDS;
@@ -874,29 +872,16 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
         fs.flags = fs.tau + round_up(5 * n, 4);
         fs.slow_list = fs.flags + round_up(n, 4);
         fs.slow_count = fs.slow_list + round_up(n, 4);
-        fs.slow_report = side->counter;
+        fs.slow_report = report;
         k_ed25519_verify_fast_scalars<<<grid_for(n, FS_BLOCK), FS_BLOCK, 0, stream>>>(fs, sig, pk, msgs, n);
         C25519_TRY(hipGetLastError());
         k_ed25519_verify_fast_points<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
         C25519_TRY(hipGetLastError());
-        const unsigned slow_grid = grid < SLOW_GRID ? grid : SLOW_GRID;
-        const bool fork = side_ok && side->stream != stream;
-        if (fork) {                                   // the slow list's kernel beside the walk, joined behind it
-            C25519_TRY(hipEventRecord(side->fork, stream));
-            C25519_TRY(hipStreamWaitEvent(side->stream, side->fork, 0));
-            k_ed25519_verify_slow<<<slow_grid, ED_BLOCK, 0, side->stream>>>(fs, verdict, sig, pk, msgs, tbl);
-            C25519_TRY(hipGetLastError());
-            C25519_TRY(hipEventRecord(side->join, side->stream));
-        }
         k_ed25519_verify_fast_walk<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
         C25519_TRY(hipGetLastError());
-        if (fork) {
-            C25519_TRY(hipStreamWaitEvent(stream, side->join, 0));
-        } else {
-            k_ed25519_verify_slow<<<slow_grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
-            C25519_TRY(hipGetLastError());
-        }
-        tl_last_verify.count = side->counter; tl_last_verify.stream = stream;
+        k_ed25519_verify_slow<<<grid < SLOW_GRID ? grid : SLOW_GRID, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
+        C25519_TRY(hipGetLastError());
+        tl_last_verify.count = report; tl_last_verify.stream = stream;
         (void)hipGetDevice(&tl_last_verify.device);
         return tls().release_work(stream);
     }
