@@ -82,13 +82,16 @@ def measured_mad_peak():
     chains (committed summary).  It is the half-rate class' ~37.5 T.  The compiler-generated 16-per-trip loops of
     tools/ubench/valu_rates, which rounds 1 and early 2 divided by, read 28-32 T: loop overhead, fetch-line placement
     of the loop top and s_nop padding between asm statements, not the instruction (profiles/README.md)."""
-    try:
-        path = latest_profile("r[0-9][0-9]_mad_peak.json")
-        with open(path) as f:
-            rates = json.load(f)["rates"]
-        return rates["v_mad_u64_u32"], os.path.basename(path)
-    except Exception:
-        return None, None
+    best, src = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_mad_peak.json"))):
+        try:
+            with open(path) as f:
+                r = json.load(f)["rates"]["v_mad_u64_u32"]
+        except Exception:
+            continue
+        if best is None or r > best:                 # boxes differ in sustained clock: the fastest one seen is the roof
+            best, src = r, os.path.basename(path)
+    return best, src
 
 
 def measured_traffic(kernels):
