@@ -9,9 +9,18 @@
  * source/ed25519_verify.c:287-313).  All arithmetic runs on an AMD MI355X (gfx950) through HIP;
  * a call made with no usable device aborts the process -- there is no CPU fallback.
  *
- * Blinding contexts are accepted for source compatibility.  Blinding is an output-neutral
- * side-channel countermeasure in the reference (signatures are byte-identical with and without it),
- * so a non-NULL context does not change any output here either.
+ * Blinding is real: ed25519_Blinding_Init derives the reference's 192-byte context (bl, zr, BP) on the
+ * device, and a non-NULL context makes key generation / signing walk the scalar k + bl from a starting
+ * point whose Z is randomised by zr and add BP afterwards (reference source/ed25519_sign.c:254-259,
+ * :289-331).  It is output-neutral, in the reference and here: signatures and public keys are
+ * byte-identical with and without a context.
+ *
+ * Cost of ONE call: these are the reference's single-operation prototypes, and each call runs as a device
+ * batch of one -- a whole kernel pass for one lane, about 0.4 ms per signature, 0.7 ms per verification,
+ * 1.2 ms per X25519 (profiles/r03_batch_sweep.txt), i.e. SLOWER than the reference on one host core (43 us,
+ * 190 us and 93 us there).  The device pays off through the *_batch / *_dev forms in curve25519_amd.h: from
+ * about 16 operations per call a batch beats one host core, from a few hundred it beats sixteen, and the
+ * quoted throughput needs 2^17 and more per call.
  */
 #ifndef CURVE25519_AMD_ED25519_SIGNATURE_H
 #define CURVE25519_AMD_ED25519_SIGNATURE_H

@@ -8,11 +8,13 @@
 #include "verify_fast.cuh"
 
 #include <mutex>
+#include <thread>
 #include <vector>
 
 using namespace c25519;
 
 namespace c25519 { unsigned long long emul_mad_overflows = 0; LatCounters emul_lat_counters = { 0, 0, 0 }; }
+thread_local EmulWave* emul_wave = nullptr;
 
 namespace {
 
@@ -269,6 +271,36 @@ void emul_lattice(unsigned char* rho_out, unsigned char* tau_out, int* tau_neg, 
         tau_neg[i] = neg ? 1 : 0;
         memcpy(rho_out + 20 * i, rho, 20);
         memcpy(tau_out + 20 * i, tau, 20);
+    }
+}
+
+// lattice reduction with the elements grouped into "waves" of `lanes` host threads running in lock-step (valu_model.h):
+// the wave-level control flow of sc_lattice_short -- __any-guarded loop exits, lanes that idle while others iterate -- as
+// on the device.  Results must equal the one-lane run's.  n is rounded down to whole waves.
+void emul_lattice_waves(unsigned char* rho_out, unsigned char* tau_out, int* tau_neg, int* fits, const unsigned char* h, size_t n,
+                        int lanes)
+{
+    for (size_t base = 0; base + lanes <= n; base += lanes) {
+        EmulWave w;
+        w.lanes = lanes; w.arrived = 0; w.generation = 0; w.acc = false; w.result = false;
+        pthread_mutex_init(&w.mu, nullptr);
+        pthread_cond_init(&w.cv, nullptr);
+        std::vector<std::thread> th;
+        for (int l = 0; l < lanes; l++)
+            th.emplace_back([&, l] {
+                emul_wave = &w;
+                const size_t i = base + l;
+                u32 hw[8], rho[5], tau[5], neg;
+                rd32(hw, h, i);
+                fits[i] = sc_lattice_short(rho, tau, neg, hw) ? 1 : 0;
+                tau_neg[i] = neg ? 1 : 0;
+                memcpy(rho_out + 20 * i, rho, 20);
+                memcpy(tau_out + 20 * i, tau, 20);
+                emul_wave = nullptr;
+            });
+        for (auto& t : th) t.join();
+        pthread_mutex_destroy(&w.mu);
+        pthread_cond_destroy(&w.cv);
     }
 }
 

@@ -6,6 +6,7 @@
 // and it is not a fallback: libcurve25519_amd.so has no host arithmetic at all.
 #pragma once
 #define C25519_VALU_PRIMITIVES 1
+#include <pthread.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
@@ -22,7 +23,38 @@ struct emul_dim3 { unsigned x, y, z; };
 static const emul_dim3 threadIdx = { 0, 0, 0 }, blockIdx = { 0, 0, 0 }, blockDim = { 1, 1, 1 };
 static inline void __syncthreads() {}
 static inline int __syncthreads_or(int p) { return p; }
-static inline bool __any(bool p) { return p; }           // a "wave" of one lane
+// __any(): a "wave" of one lane by default.  emul_wave_run() (emul.cpp) runs G host threads as the lanes of one wave in
+// lock-step: each lane's code then meets every __any at the same point (the device source only branches on wave-uniform
+// values around them) and gets the OR over the group -- so the divergent paths of the lattice reduction (lanes idling
+// while others still iterate, the word-shift hints, loops that end when the LAST lane is done) run on the CPU too.
+struct EmulWave {
+    int lanes;
+    int arrived, generation;
+    bool acc, result;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+};
+extern thread_local EmulWave* emul_wave;                 // the wave this host thread is a lane of (nullptr: alone)
+static inline bool __any(bool p)
+{
+    EmulWave* w = emul_wave;
+    if (!w) return p;
+    pthread_mutex_lock(&w->mu);
+    w->acc = w->acc || p;
+    const int gen = w->generation;
+    if (++w->arrived == w->lanes) {                       // last one in: publish and release the others
+        w->result = w->acc;
+        w->acc = false;
+        w->arrived = 0;
+        w->generation++;
+        pthread_cond_broadcast(&w->cv);
+    } else {
+        while (w->generation == gen) pthread_cond_wait(&w->cv, &w->mu);
+    }
+    const bool r = w->result;
+    pthread_mutex_unlock(&w->mu);
+    return r;
+}
 
 namespace c25519 {
 
@@ -32,7 +64,7 @@ typedef uint64_t u64;
 // loop-trip counters of the lattice reduction (verify_fast.cuh), read by tests/test_verify_fast.py
 struct LatCounters { unsigned long long lehmer_outer, lehmer_inner, exact_steps; };
 extern LatCounters emul_lat_counters;
-#define C25519_LAT_COUNT(what) (++::c25519::emul_lat_counters.what)
+#define C25519_LAT_COUNT(what) __atomic_fetch_add(&::c25519::emul_lat_counters.what, 1ULL, __ATOMIC_RELAXED)
 
 inline u32 dbl32(u32 x) { return x + x; }
 inline u32 alignbit32(u32 hi, u32 lo, int s) { return (u32)((((u64)hi << 32) | lo) >> s); }

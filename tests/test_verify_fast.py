@@ -62,6 +62,36 @@ def test_short_vector_properties(emul):
     assert [int(f) for f in fits[:12]] == [1, 1, 1, 1, 0, 0, 1, 1, 1, 1, 0, 1]
 
 
+def test_short_vector_search_in_lock_step_waves(emul):
+    """The same search with the elements grouped into waves of 8 and 64 lanes that run in lock-step, __any taken over the
+    wave as on the device (tests/host_emul/valu_model.h): lanes that are done idle while others iterate, loops end when
+    the LAST lane is done, word-shift hints come from other lanes.  Hand-picked h (0, 1, L-1, ... -- the ones with freak
+    quotients) sit beside random ones in every wave; every element's result must equal its one-lane result."""
+    hs = vectors.lattice_inputs()[:12] + [int.from_bytes(synth.random_bytes((1, 32), 0x5eed + i)[0].tobytes(), "little") % vectors.L
+                                          for i in range(116)]
+    n = len(hs)                                                      # 128: two waves of 64, sixteen of 8
+    order = np.arange(n).reshape(2, 64).T.reshape(-1)               # interleave: every wave of 8 holds structured and random h
+    h = np.stack([vectors.le(hs[i], 32) for i in order])
+
+    def run(lanes):
+        rho, tau = np.zeros((n, 20), np.uint8), np.zeros((n, 20), np.uint8)
+        neg, fits = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        if lanes == 1:
+            emul.emul_lattice(C.c_void_p(rho.ctypes.data), C.c_void_p(tau.ctypes.data), C.c_void_p(neg.ctypes.data),
+                              C.c_void_p(fits.ctypes.data), C.c_void_p(h.ctypes.data), C.c_size_t(n))
+        else:
+            emul.emul_lattice_waves(C.c_void_p(rho.ctypes.data), C.c_void_p(tau.ctypes.data), C.c_void_p(neg.ctypes.data),
+                                    C.c_void_p(fits.ctypes.data), C.c_void_p(h.ctypes.data), C.c_size_t(n), C.c_int(lanes))
+        return rho, tau, neg, fits
+
+    one = run(1)
+    for lanes in (8, 64):
+        got = run(lanes)
+        for a, b in zip(one, got):
+            assert np.array_equal(a, b), lanes
+    assert one[3].sum() > 100
+
+
 def test_fast_path_equals_the_oracle(emul, oracle):
     n = 1500
     sk, msg = synth.random_bytes((n, 32), 0x111), synth.random_bytes((n, 40), 0x222)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""tools/verify_worst_case.py -- ed25519_VerifySignature_dev when an adversary chooses the inputs: every 256-element
-workgroup contains one off-curve public key, so no workgroup can take the lattice path and all of them run the
-reference's operation order inside the walk kernel.  Prints the pass time against the all-valid batch.
+"""tools/verify_worst_case.py -- ed25519_VerifySignature_dev when an adversary chooses the inputs.  An off-curve public
+key cannot take the lattice path: its element goes on the slow list and the reference's operation order runs for it
+behind the walk.  Four batches against the all-valid one: a single garbage key (the slow kernel's latency, one lane),
+one per 256 elements, every second key, every key (the walk's waves then find nothing to do and leave).
 
     python tools/verify_worst_case.py [--n 1048576]
 """
@@ -46,12 +47,16 @@ def timed(pk_np, label):
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 5
     print(f"{label:46s} {ms:8.3f} ms per 2^{n.bit_length() - 1}  = {n / ms / 1e3:7.1f} M verifies/s   "
-          f"accepted {int(ok.sum())}  reference-order workgroups {L.c25519_amd_verify_last_slow_elements()} of {(n + 255) // 256}")
+          f"accepted {int(ok.sum())}  reference-order elements {L.c25519_amd_verify_last_slow_elements()} of {n}")
     return ms
 
 
 base = timed(pub, "all keys on the curve (lattice path)")
-bad = pub.copy()
-bad[128::256] = off_curve_key()
-worst = timed(bad, "one off-curve key in every workgroup")
+off = off_curve_key()
+worst = base
+for label, sel in (("ONE off-curve key in the batch", slice(12345, 12346)), ("one off-curve key per 256 elements", slice(128, None, 256)),
+                   ("every second key off the curve", slice(0, None, 2)), ("every key off the curve", slice(0, None))):
+    bad = pub.copy()
+    bad[sel] = off
+    worst = max(worst, timed(bad, label))
 print(f"worst case / normal = {worst / base:.2f}")
