@@ -471,32 +471,6 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fa
     verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
 }
 
-// the reference-order path for one element, start to finish (own table, own inversion): what ed25519_VerifySignature does
-// (ed25519_verify.c:163-176 = Verify_Init + Verify_Check)
-C25519_DEV int verify_reference_order_lane(const u32 (&pkw)[8], const void* sig, size_t i, const uint8_t* msg, size_t len,
-                                           u32* lane_table, const u32* lds_tbl)
-{
-    u32 Sw[8], h[8], Rw[8], enc[8], xw[8], yw[8];
-    const QTableLimbs tbl{ lane_table };
-    {
-        ge_ext Q;
-        ed_decode_neg_key(Q, pkw);
-        qtable_build(tbl, Q);
-    }
-    load32(Rw, sig, 2 * i);
-    ed_hram(h, Rw, pkw, msg, len);
-    sc_mod(h);
-    load32(Sw, sig, 2 * i + 1);
-    ge_ext T;
-    ge_poly_mult(T, Sw, h, tbl, lds_tbl);
-    ge_to_affine_words(xw, yw, T);                            // z^(p-2): Z == 0 gives 0 like the reference
-    ge_pack(enc, xw, yw);
-    u32 diff = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
-    return diff == 0 ? 1 : 0;
-}
-
 // step 5: the elements on the slow list (off-curve keys -- the reference does not reject them, so neither may we -- and
 // the practically nonexistent over-long vectors), one per lane, in the reference's order, behind the walk on the same
 // stream.  A fixed small grid strides over the list: with honest keys the list is empty and the launch costs ~10 us; a
@@ -504,7 +478,7 @@ C25519_DEV int verify_reference_order_lane(const u32 (&pkw)[8], const void* sig,
 // the same kernel on a second, high-priority stream beside the walk -- its workgroups, 272 registers per lane, only ever
 // found room when the walk's last round drained, so it bought nothing: profiles/r03_ab_verify_structure.txt.)
 constexpr unsigned SLOW_GRID = 512;
-__global__ void __launch_bounds__(ED_BLOCK, 1) k_ed25519_verify_slow(FastScratch fs, int* verdict, const void* sig, const void* pk,
+__global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_slow(FastScratch fs, int* verdict, const void* sig, const void* pk,
                                                                      Msgs msgs, const u32* __restrict__ g_tbl)
 {
     const u32 count = *fs.slow_count;
@@ -516,7 +490,10 @@ __global__ void __launch_bounds__(ED_BLOCK, 1) k_ed25519_verify_slow(FastScratch
         const size_t i = fs.slow_list[k];
         u32 pkw[8];
         load32(pkw, pk, i);
-        verdict[i] = verify_reference_order_lane(pkw, sig, i, msgs.ptr(i), msgs.len(i), fs.tables + i * FAST_TABLE_WORDS, lds_tbl);
+        u32 Rw[8], Sw[8];
+        load32(Rw, sig, 2 * i);
+        load32(Sw, sig, 2 * i + 1);
+        verdict[i] = ed_verify_reference_order(pkw, Rw, Sw, msgs.ptr(i), msgs.len(i), fs.tables + i * FAST_TABLE_WORDS, lds_tbl);
     }
 }
 

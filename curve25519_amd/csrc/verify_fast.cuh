@@ -16,6 +16,7 @@
 // Public data only: nothing here needs to be constant-time.
 #pragma once
 #include "ge25519.cuh"
+#include "lanes.cuh"
 #include "sc25519.cuh"
 #include "sha512.cuh"
 
@@ -499,6 +500,94 @@ C25519_DEV void wtable_build(const Tbl& tbl, const fe& x, const fe& y)
         else ge_double<true>(S);
         ge_store_pe_row(rows + ((0x8547632u >> (4 * step)) & 15u) * PE_WORDS, S);
     }
+}
+
+// ---- the reference's 16-row 4-fold table, built with the streamed operations above -----------------------------------------------
+// qtable_build (ge25519.cuh; ed25519_Verify_Init :199-229) for a lane-private limb table: the same points in the same
+// order by the same formulas -- row top+s = Q + row s with Q the extended and row s the precomputed operand, as the
+// reference's edp_AddPoint has them (that matters: for an off-curve "key" the values depend on it) -- but each sum is
+// formed in ONE extended point from a row streamed out of memory and leaves through ge_store_pe_row, so the build needs the
+// registers of the walk (Q, the sum, a product's temporaries), not 175.  rows: 16 x PE_WORDS.  Q is consumed.
+C25519_DEV void qtable_build_streamed(u32* rows, ge_ext& Q)
+{
+    const QTableLimbs t{ rows };
+    {
+        ge_pe pe;
+        fe_set_u32(pe.ypx, 1); fe_set_u32(pe.ymx, 1); fe_set_u32(pe.t2d, 0); fe_set_u32(pe.z2, 2);
+        t.store(0, pe);
+    }
+    ge_store_pe_row(rows + PE_WORDS, Q);
+#pragma unroll 1
+    for (int blk = 1; blk < 4; blk++) {               // Q <- 2^64 Q, then fill rows [2^blk, 2^(blk+1))
+#pragma unroll 1
+        for (int i = 0; i < 63; i++) ge_double<false>(Q);
+        ge_double<true>(Q);
+        const int top = 1 << blk;
+        ge_store_pe_row(rows + top * PE_WORDS, Q);
+        // the sums restart from the row just written (PE -> extended is one product; the coordinates come back doubled,
+        // which the homogeneous formulas do not see), so Q itself does not have to stay in registers beside them
+#pragma unroll 1
+        for (int s = 1; s <= top; s++) {
+            ge_pe pe;
+            t.load(pe, (u32)top);
+            ge_from_pe(Q, pe);
+            if (s == top) break;                      // ... and Q is back for the next block's doublings
+            ge_add_pe_row<true>(Q, rows + s * PE_WORDS, 0u);
+            ge_store_pe_row(rows + (top + s) * PE_WORDS, Q);
+        }
+    }
+}
+
+// S = s*B + h*Q by the interleaved 4-fold / 8-fold walk (ge_poly_mult, ge25519.cuh; edp_PolyPointMultiply :243-280) with the
+// rows of the lane's 4-fold table and of the LDS base table streamed into the additions.  s and h are consumed.
+C25519_DEV void ge_poly_mult_streamed(ge_ext& S, u32 (&s)[8], u32 (&h)[8], const u32* rows, const u32* lds_tbl)
+{
+    {
+        ge_pe pe;
+        const QTableLimbs t{ const_cast<u32*>(rows) };
+        t.load(pe, fold4_next(h, false));
+        ge_from_pe(S, pe);
+    }
+#pragma unroll 1
+    for (int i = 1; i < 32; i++) {
+        ge_double(S);
+        ge_add_pe_row<false>(S, rows + fold4_next(h, false) * PE_WORDS, 0u);
+    }
+#pragma unroll 1
+    for (int i = 32; i < 64; i++) {
+        ge_double(S);
+        ge_add_pa_lds(S, lds_tbl, fold8_next(s), true);     // T feeds the addition that follows
+        ge_add_pe_row<false>(S, rows + fold4_next(h, true) * PE_WORDS, 0u);
+    }
+}
+
+// the reference-order path for one element, start to finish (own table, own inversion): what ed25519_VerifySignature does
+// (ed25519_verify.c:163-176 = Verify_Init + Verify_Check), on the streamed forms above: 180 registers instead of the 268 of
+// the generic ones, two waves per SIMD.  lane_table: 16 x PE_WORDS of lane-private memory.  Sw is consumed.
+// enc_out (tests): enc(T), what the verdict compares with the R bytes.
+C25519_DEV int ed_verify_reference_order(const u32 (&pkw)[8], const u32 (&Rw)[8], u32 (&Sw)[8], const uint8_t* msg, size_t len,
+                                         u32* lane_table, const u32* lds_tbl, u32* enc_out = nullptr)
+{
+    u32 h[8], enc[8], xw[8], yw[8];
+    {
+        ge_ext Q;
+        ed_decode_neg_key(Q, pkw);
+        qtable_build_streamed(lane_table, Q);
+    }
+    ed_hram(h, Rw, pkw, msg, len);
+    sc_mod(h);
+    ge_ext T;
+    ge_poly_mult_streamed(T, Sw, h, lane_table, lds_tbl);
+    ge_to_affine_words(xw, yw, T);                            // z^(p-2): Z == 0 gives 0 like the reference
+    ge_pack(enc, xw, yw);
+    u32 diff = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
+    if (enc_out) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) enc_out[j] = enc[j];
+    }
+    return diff == 0 ? 1 : 0;
 }
 
 // ---- the walk ----------------------------------------------------------------------------------------------------------

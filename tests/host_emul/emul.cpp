@@ -224,6 +224,23 @@ void emul_ed25519_verify(int* verdict, unsigned char* point /* may be NULL */, c
     }
 }
 
+// the slow list's path (ed_verify_reference_order, verify_fast.cuh: the streamed table build and 4-fold walk) per element
+void emul_ed25519_verify_slow(int* verdict, unsigned char* point, const unsigned char* sig, const unsigned char* pk,
+                              const unsigned char* msg, size_t len, size_t n)
+{
+    const u32* tbl = tables() + (size_t)REF_TBL_OFFSET;
+    std::vector<u32> q(QTABLE_LIMB_WORDS);
+    for (size_t i = 0; i < n; i++) {
+        u32 pkw[8], Rw[8], Sw[8];
+        rd32(pkw, pk, i);
+        rd32(Rw, sig, 2 * i);
+        rd32(Sw, sig, 2 * i + 1);
+        u32 enc[8];
+        verdict[i] = ed_verify_reference_order(pkw, Rw, Sw, msg + len * i, len, q.data(), tbl, enc);
+        wr32(point, i, enc);
+    }
+}
+
 // the lattice fast path (verify_fast.cuh), one element at a time: verdicts (meaningful where need_slow[i] == 0) and the
 // need_slow flags
 void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char* sig, const unsigned char* pk,

@@ -122,6 +122,31 @@ def test_fast_path_equals_the_oracle(emul, oracle):
     assert not s.any() and np.array_equal(v, oracle.ed25519_verify(ssig, pub[:m], bmsg[:m]))
 
 
+def test_slow_list_path_equals_the_oracle(emul, oracle):
+    """The kernel behind the walk decides the elements on the slow list with ed_verify_reference_order: the reference's
+    Verify_Init + Verify_Check on the streamed table build / 4-fold walk.  Its verdicts against the oracle on valid and
+    corrupted signatures, S + L, and above all garbage keys and garbage signatures -- off-curve "points", where the result
+    depends on the exact order of operations."""
+    n = 600
+    sk, msg = synth.random_bytes((n, 32), 0x311), synth.random_bytes((n, 33), 0x322)
+    pub, priv = oracle.ed25519_keypair(sk, threads=8)
+    sig = oracle.ed25519_sign(priv, msg, threads=8)
+    bsig, bmsg, _ = synth.corrupt_for_verify(sig, msg)
+    for i in range(0, 40, 3):
+        S = int.from_bytes(bsig[i, 32:].tobytes(), "little")
+        if S + vectors.L < 2**256:
+            bsig[i, 32:] = vectors.le(S + vectors.L, 32)
+    gs, gp, gm = synth.random_bytes((n, 64), 51), synth.random_bytes((n, 32), 52), synth.random_bytes((n, 33), 53)
+    for s_, p_, m_ in ((bsig, pub, bmsg), (gs, gp, gm), (bsig, gp, bmsg)):
+        s_, p_, m_ = np.ascontiguousarray(s_), np.ascontiguousarray(p_), np.ascontiguousarray(m_)
+        v, pt = np.empty(n, np.int32), np.empty((n, 32), np.uint8)
+        emul.emul_ed25519_verify_slow(C.c_void_p(v.ctypes.data), C.c_void_p(pt.ctypes.data), C.c_void_p(s_.ctypes.data),
+                                      C.c_void_p(p_.ctypes.data), C.c_void_p(m_.ctypes.data), C.c_size_t(m_.shape[1]), C.c_size_t(n))
+        assert np.array_equal(v, oracle.ed25519_verify(s_, p_, m_, threads=8))
+        # ... and enc(T) itself: for garbage keys every verdict is 0 whatever the path computes, the point is not
+        assert np.array_equal(pt, oracle.ed25519_verify_point(s_, p_, m_))
+
+
 def test_fast_path_on_torsion(emul, oracle):
     sig, pk, msg = vectors.torsion_signature_cases()
     v, s = run_fast(emul, sig, pk, msg)
