@@ -472,12 +472,13 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fa
 }
 
 // step 5: the elements on the slow list (off-curve keys -- the reference does not reject them, so neither may we -- and
-// the practically nonexistent over-long vectors), one per lane, in the reference's order, behind the walk on the same
-// stream.  A fixed small grid strides over the list: with honest keys the list is empty and the launch costs ~10 us; a
-// batch with garbage keys in it pays one reference-order verification's latency (~1.2 ms) on top.  (Tried and dropped:
-// the same kernel on a second, high-priority stream beside the walk -- its workgroups, 272 registers per lane, only ever
-// found room when the walk's last round drained, so it bought nothing: profiles/r03_ab_verify_structure.txt.)
-constexpr unsigned SLOW_GRID = 512;
+// the practically nonexistent over-long vectors), one per lane, in the reference's order (ed_verify_reference_order),
+// behind the walk on the same stream.  The grid covers the worst case (every element listed); workgroups beyond the
+// list's end read the counter and leave: with honest keys that is all of them and costs ~10 us.  A batch with garbage keys
+// in it pays one reference-order verification's latency (~1.3 ms) on top.
+// (Tried and dropped: the kernel on a second, high-priority stream beside the walk -- its workgroups only ever found room
+// when the walk's last round drained, profiles/r03_ab_verify_structure.txt; a fixed small grid striding over the list --
+// any loop around the body makes the compiler keep ~60 field constants in registers across trips: 268 instead of 200.)
 __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_slow(FastScratch fs, int* verdict, const void* sig, const void* pk,
                                                                      Msgs msgs, const u32* __restrict__ g_tbl)
 {
@@ -486,15 +487,14 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_slow(FastScratch
     if ((size_t)blockIdx.x * ED_BLOCK >= count) return;
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
     lds_stage_words(lds_tbl, g_tbl + REF_TBL_OFFSET, REF_TBL_WORDS);
-    for (size_t k = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x; k < count; k += (size_t)gridDim.x * ED_BLOCK) {
-        const size_t i = fs.slow_list[k];
-        u32 pkw[8];
-        load32(pkw, pk, i);
-        u32 Rw[8], Sw[8];
-        load32(Rw, sig, 2 * i);
-        load32(Sw, sig, 2 * i + 1);
-        verdict[i] = ed_verify_reference_order(pkw, Rw, Sw, msgs.ptr(i), msgs.len(i), fs.tables + i * FAST_TABLE_WORDS, lds_tbl);
-    }
+    const size_t k = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    if (k >= count) return;
+    const size_t i = fs.slow_list[k];
+    u32 pkw[8], Rw[8], Sw[8];
+    load32(pkw, pk, i);
+    load32(Rw, sig, 2 * i);
+    load32(Sw, sig, 2 * i + 1);
+    verdict[i] = ed_verify_reference_order(pkw, Rw, Sw, msgs.ptr(i), msgs.len(i), fs.tables + i * FAST_TABLE_WORDS, lds_tbl);
 }
 
 // Same check with ONE key for the whole batch (the reference's two-phase use: Verify_Init once, many
@@ -856,7 +856,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
         C25519_TRY(hipGetLastError());
         k_ed25519_verify_fast_walk<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
         C25519_TRY(hipGetLastError());
-        k_ed25519_verify_slow<<<grid < SLOW_GRID ? grid : SLOW_GRID, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
+        k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
         C25519_TRY(hipGetLastError());
         tl_last_verify.count = report; tl_last_verify.stream = stream;
         (void)hipGetDevice(&tl_last_verify.device);
