@@ -136,12 +136,14 @@ int ed25519_Verify_Check_dev(void *verdict, const void *ctx, const void *sig, co
 
 /* Multi-GPU (BASELINE.json north_star: "batches shard embarrassingly across the 8 GPUs of one node
  * with a single RCCL gather over xGMI") ------------------------------------------------------------------------------
- * One host thread drives n_dev devices.  A call cuts the batch into contiguous shards (device d owns elements
- * [n*d/n_dev, n*(d+1)/n_dev)), every device uploads its shard and runs the same kernels as the single-GPU entry points
- * on its own stream, and each result array is gathered to devices[0] with ONE grouped ncclGather (RCCL,
- * /opt/rocm/include/rccl/rccl.h:745; loaded with dlopen on first use) before the host reads it from the root device.
- * Host pointers, synchronous, same byte layouts and results as the *_batch functions.  The handle owns one stream, one
- * RCCL communicator and grow-only staging buffers per device; it is not thread-safe (one handle per calling thread). */
+ * A handle owns ONE WORKER THREAD PER DEVICE.  A call cuts the batch into contiguous shards (device d owns elements
+ * [n*d/n_dev, n*(d+1)/n_dev)); every worker runs its shard through the same pinned, pieced pipeline as the single-GPU
+ * *_batch functions (all devices upload over their own PCIe links at the same time, nothing is copied from or to
+ * pageable memory), results stay resident on the device, each result array is gathered to devices[0] with ONE grouped
+ * ncclGather (RCCL, /opt/rocm/include/rccl/rccl.h:745; loaded with dlopen on first use) and the root's worker streams
+ * the gathered slab to the caller.  A handle of one device skips the gather.  Host pointers, synchronous, same byte
+ * layouts and results as the *_batch functions.  The handle also owns one stream and one RCCL communicator per device and
+ * grow-only result buffers (zeroed before they are freed); it is not thread-safe (one call at a time per handle). */
 typedef struct c25519_amd_multi c25519_amd_multi;
 int  c25519_amd_multi_create(c25519_amd_multi **m, const int *devices, int n_dev);
 void c25519_amd_multi_destroy(c25519_amd_multi *m);

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""tools/verify_opcount.py -- operation counts of the ways to walk  sigma*B + tau*Q + rho*(-R)  (tau, rho ~ 128-bit short
+lattice vectors, sigma 253 bits on the LDS comb table) on a 64-lane SIMT machine, priced with the kernels' own
+v_mad_u64_u32 counts per operation (profiles/r03_isa_mix.txt).  VERDICT r02 asked for a table-light joint walk (JSF over
+{Q, R, Q+R, Q-R}); this prints what each shape costs per signature and how many table bytes it writes / reads.
+
+    python tools/verify_opcount.py > profiles/r03_verify_opcount.txt
+"""
+import random
+
+# v_mad_u64_u32 per operation, counted in the compiled kernels (100 per product + 1 fold, 55 + 1 per square)
+DBL, DBL_T = 527, 627            # doubling without / with the T product (3 M + 4 S, + 1 M)
+ADD_PE, ADD_PE_T = 707, 807      # + a projective precomputed row (7 M / 8 M)
+ADD_PA, ADD_PA_T = 606, 707      # + an affine precomputed row (6 M / 7 M)
+TO_PE = 101                      # extended -> precomputed row (one product by 2d)
+SIGMA = 32 * ADD_PA + 8 * 101    # sigma's 32 columns: affine additions riding on doublings the walk does anyway (+ the T's)
+BITS = 130                       # a typical wave's longest vector (127-131 bits), the walk's starting point
+
+
+def jsf(a, b):
+    """joint sparse form of two non-negative integers (Solinas): two signed digit strings, least significant first"""
+    da, db, ua, ub = [], [], 0, 0
+    while a + ua or b + ub:
+        la, lb = a + ua, b + ub
+        x = 0 if la % 2 == 0 else (2 - la % 4)
+        if x and la % 8 in (3, 5) and lb % 4 == 2:
+            x = -x
+        y = 0 if lb % 2 == 0 else (2 - lb % 4)
+        if y and lb % 8 in (3, 5) and la % 4 == 2:
+            y = -y
+        if 2 * ua == 1 + x:
+            ua = 1 - ua
+        if 2 * ub == 1 + y:
+            ub = 1 - ub
+        da.append(x); db.append(y)
+        a //= 2; b //= 2
+    return da, db
+
+
+def jsf_densities(trials=400, lanes=64):
+    rng = random.Random(25519)
+    per_lane, per_wave = 0.0, 0.0
+    for _ in range(trials):
+        cols = []
+        for _ in range(lanes):
+            da, db = jsf(rng.getrandbits(128) | 1, rng.getrandbits(128))
+            n = max(len(da), len(db))
+            da += [0] * (n - len(da)); db += [0] * (n - len(db))
+            cols.append([1 if (x or y) else 0 for x, y in zip(da, db)])
+        n = max(len(c) for c in cols)
+        for c in cols:
+            c += [0] * (n - len(c))
+        per_lane += sum(sum(c) for c in cols) / (lanes * n)
+        per_wave += sum(1 for i in range(n) if any(c[i] for c in cols)) / n
+    return per_lane / trials, per_wave / trials
+
+
+def main():
+    lane_d, wave_d = jsf_densities()
+    rows = []
+    # (name, doublings, pe additions, pa additions, table build MADs, table bytes written, row reads x bytes)
+    rounds = (BITS + 3) // 4
+    build16 = 2 * (4 * DBL_T + 3 * ADD_PE_T + 8 * TO_PE + 101 + 2 * 101)
+    rows.append(("two signed radix-16 window tables (shipped): 9 rows each", 4 * rounds, 2 * rounds + 1, 0, build16, 2 * 1440, (2 * rounds + 2) * 256))
+    r8 = (BITS + 2) // 3
+    build8 = 2 * (2 * DBL_T + 1 * ADD_PE_T + 4 * TO_PE + 101)
+    rows.append(("two signed radix-8 tables: 5 rows each", 3 * r8, 2 * r8 + 1, 0, build8, 2 * 800, (2 * r8 + 2) * 256))
+    r32 = (BITS + 4) // 5
+    build32 = 2 * (8 * DBL_T + 7 * ADD_PE_T + 16 * TO_PE + 101)
+    rows.append(("two signed radix-32 tables: 17 rows each", 5 * r32, 2 * r32 + 1, 0, build32, 2 * 2720, (2 * r32 + 2) * 256))
+    pos = (BITS + 1) // 2
+    buildj = 2 * DBL_T + 10 * ADD_PE_T + 8 * TO_PE + 2 * 101
+    rows.append(("joint signed radix-4 table aQ + bR, a in {1,3}, b in {+-1,+-3}: 8 rows", 2 * pos, pos + 2, 0, buildj, 1280, (pos + 2) * 256))
+    buildjsf = 2 * ADD_PE_T + 4 * TO_PE + 2 * 101
+    rows.append((f"JSF over {{Q, R, Q+R, Q-R}}, one lane alone (joint density {lane_d:.3f})", BITS + 1, round(lane_d * (BITS + 1)), 0, buildjsf, 640, round(lane_d * (BITS + 1)) * 256))
+    rows.append((f"JSF over {{Q, R, Q+R, Q-R}}, 64 lanes in lock-step (positions some lane needs: {wave_d:.3f})", BITS + 1, round(wave_d * (BITS + 1)), 0, buildjsf, 640, round(wave_d * (BITS + 1)) * 256))
+    print("# Ways to compute  sigma*B + tau*Q + rho*(-R)  for one signature, tau and rho %d bits (a typical wave's start), priced" % BITS)
+    print("# with the kernels' own v_mad_u64_u32 counts per operation: doubling %d (%d with T), + projective row %d (%d), + affine" % (DBL, DBL_T, ADD_PE, ADD_PE_T))
+    print("# row %d (%d), row conversion %d.  Common to all rows of the table and not listed: sigma's 32 affine additions on" % (ADD_PA, ADD_PA_T, TO_PE))
+    print("# the LDS comb table (%d), the two square roots (2 x 16 900), the scalar kernel.  tools/verify_opcount.py" % SIGMA)
+    print(f"{'walk of tau*Q + rho*(-R)':88s} {'dbl':>4s} {'add':>4s} {'walk MADs':>10s} {'tables':>7s} {'total':>8s} {'vs shipped':>10s} {'B written':>9s} {'B read':>7s}")
+    base = None
+    for name, dbl, pe, pa, build, wr, rd in rows:
+        walk = dbl * DBL + (dbl // 4) * (DBL_T - DBL) + pe * ((ADD_PE + ADD_PE_T) // 2) + pa * ADD_PA
+        total = walk + build
+        base = base or total
+        print(f"{name:88s} {dbl:4d} {pe + pa:4d} {walk:10d} {build:7d} {total:8d} {100.0 * (total - base) / base:+9.1f}% {wr:9d} {rd:7d}")
+    print("#")
+    print("# * A wave executes an addition at every position where ANY of its 64 lanes has a non-zero column; the joint sparse")
+    print("#   form's zero columns (half of them for one scalar pair) line up across 64 independent pairs with probability ~2^-64,")
+    print("#   so in lock-step the JSF walk performs an addition at practically every position: twice the additions of the")
+    print("#   radix-16 windows for 4 % fewer doublings.  (Lanes could be compacted by column pattern only by moving 40-register")
+    print("#   accumulators between lanes every step.)")
+    print("# * The joint signed radix-4 table is the only shape that walks as cheaply as two radix-16 tables (2 doublings + 1")
+    print("#   addition per 2 bits = 4 + 2 per 4 bits); it saves table construction and 1.6 KB of table per element, about 2 % of the")
+    print("#   pass's MADs, for a recoding that needs tau odd (a correction addition when it is even).  Not built: the table")
+    print("#   traffic is not what the pass waits for (profiles/r03_ab_verify_structure.txt, blocks 5 and 6).")
+    print("# * Wider windows lose to table construction, narrower ones to additions: radix 16 is the optimum of the family.")
+
+
+if __name__ == "__main__":
+    main()
