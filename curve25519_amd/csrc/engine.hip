@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VC_WAVES) k_ed25519_verify_ch
 //   bit 2  the short vector fits the walk             bit 3  tau < 0
 //   bit 4  the element is on the slow list            bits 8..13  top nonzero digit of the element's scalars
 struct FastScratch {
-    u32 *tables;            // per lane: window table of +-Q, then of -R (2 x WTABLE_WORDS, lane-contiguous)
+    u32 *tables;            // per lane: window table of +-Q, then of -R (2 x WTABLE_WORDS of packed 128-byte rows, 128-byte aligned)
     u32 *sigma, *rho, *tau, *flags;
     u32 *slow_list;         // indices of the elements the reference-order kernel has to decide ...
     u32 *slow_count;        // ... and how many
@@ -387,7 +387,7 @@ constexpr size_t FAST_TABLE_WORDS = 2 * WTABLE_WORDS;
 constexpr int FS_BLOCK = 256;
 constexpr u32 FLAG_R_OK = 1u, FLAG_KEY_OK = 2u, FLAG_FITS = 4u, FLAG_TAU_NEG = 8u, FLAG_SLOW = 16u;
 #ifndef C25519_VW_WAVES
-#define C25519_VW_WAVES 3            // waves per SIMD the register allocator aims at: the walk kernel ...
+#define C25519_VW_WAVES 2            // waves per SIMD the register allocator aims at: the walk kernel (rows prefetched) ...
 #endif
 #ifndef C25519_VD_WAVES
 #define C25519_VD_WAVES 3            // ... and the point decoding + table kernel
@@ -435,12 +435,11 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VD_WAVES) k_ed25519_verify_fa
         atomicOr(&fs.flags[e], ok ? FLAG_KEY_OK | FLAG_SLOW : FLAG_SLOW);
         fs.slow_list[atomicAdd(fs.slow_count, 1u)] = (u32)e;      // (the compiler aggregates this per wave)
     }
-    // the point's window table, right here: a table is 1440 bytes of 16-byte stores scattered over as many cache lines, and
+    // the point's window table, right here: a table is 1152 bytes of 16-byte stores scattered over as many cache lines, and
     // they hide under the other waves' square roots (in a kernel of their own: 1.3 ms with the SIMDs idle half the time; in
     // front of the walk, inside its kernel: 1.0 ms; here 0.6 ms -- profiles/r03_ab_verify_structure.txt).
     // (An element that turns out to be on the slow list gets tables nobody reads: the key lane cannot tell the R lane in time.)
-    const QTableLimbs tbl{ fs.tables + e * FAST_TABLE_WORDS + (is_r ? WTABLE_WORDS : 0) };
-    wtable_build(tbl, X, Y);
+    wtable_build(fs.tables + e * FAST_TABLE_WORDS + (is_r ? WTABLE_WORDS : 0), X, Y);
 }
 
 // step 3: the walk and the neutral-element test.  Across a digit round nothing but the accumulator point lives in
@@ -464,10 +463,9 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fa
     }
     top = __builtin_amdgcn_readfirstlane(top);           // wave-uniform by construction: let the walk's loops be scalar ones
     if (!walks) return;
-    const size_t base = i * FAST_TABLE_WORDS;
-    const QTableLimbs tq{ fs.tables + base }, tr{ fs.tables + base + WTABLE_WORDS };
+    const u32* tq = fs.tables + i * FAST_TABLE_WORDS;
     const WalkScalars sc{ fs.sigma, fs.tau, fs.rho, n, i };
-    const u32 neutral = ge_walk_is_neutral(sc, tq, tr, lds_tbl, top < 8 ? 8 : top);
+    const u32 neutral = ge_walk_is_neutral(sc, tq, tq + WTABLE_WORDS, lds_tbl, top < 8 ? 8 : top);
     verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
 }
 
@@ -815,6 +813,7 @@ int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t 
 // time for one element), projective results of the reference-order path (the fast path keeps its decoded points there),
 // the fast path's scalars, flags and slow list
 constexpr size_t VERIFY_TABLE_WORDS = FAST_TABLE_WORDS > QTABLE_LIMB_WORDS ? FAST_TABLE_WORDS : QTABLE_LIMB_WORDS;
+static_assert(FAST_TABLE_WORDS % 32 == 0 && VERIFY_TABLE_WORDS % 32 == 0, "per-lane tables must keep their rows 128-byte aligned");
 inline size_t verify_scalar_words(size_t n) { return round_up(8 * n, 4) + 2 * round_up(5 * n, 4) + 2 * round_up(n, 4) + 4; }
 inline size_t verify_scratch_bytes(size_t n)
 {
@@ -835,15 +834,15 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
     C25519_RC(tls().acquire_work(&w, verify_scratch_bytes(n), stream));
-    const ProjScratch scr = carve_proj((u32*)w, n);
-    u32* tables = (u32*)w + proj_words(n);
+    u32* tables = (u32*)w;                                  // first in the slab (hipMalloc: 256-byte aligned): packed rows are
+    const ProjScratch scr = carve_proj(tables + n * VERIFY_TABLE_WORDS, n);   // whole 128-byte lines
     const unsigned grid = grid_for(n, ED_BLOCK);
     if (fast) {
         unsigned* report = nullptr;
         C25519_RC(tls().report_word_for_current_device(&report));
         FastScratch fs;
         fs.tables = tables;
-        fs.sigma = tables + n * VERIFY_TABLE_WORDS;
+        fs.sigma = tables + n * VERIFY_TABLE_WORDS + proj_words(n);
         fs.rho = fs.sigma + round_up(8 * n, 4);
         fs.tau = fs.rho + round_up(5 * n, 4);
         fs.flags = fs.tau + round_up(5 * n, 4);

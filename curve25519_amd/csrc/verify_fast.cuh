@@ -361,15 +361,81 @@ C25519_DEV void sc_fold8_columns(u32 (&cols)[8], const u32 (&k)[8])
     }
 }
 
-// ---- per-lane window tables: rows 0..8 = 0, P, 2P, ..., 8P in PE form ---------------------------------------------------------
+// ---- packed table rows -------------------------------------------------------------------------------------------------
+// A precomputed point (Y+X, Y-X, 2dT, 2Z) is stored as four 256-bit integers, 8 words each: ONE 128-byte row, 128-byte
+// aligned, instead of 40 limbs (160 bytes over two cache lines).  Measured before it was built (timing experiment,
+// profiles/r03_ab_verify_structure.txt block 7): one line and 8 loads per row instead of two lines and 12 loads is worth 6 %
+// of the verification pass -- the texture path's share of a VALU-bound kernel's clock -- against ~18 unpack instructions
+// per field.  Packing is a plain positional sum (limb i at bit ceil(25.5 i)), so limbs need not be strictly below 2^w, only
+// the value below 2^256 (true of a product's output and of fe_carry32's); unpacking is fe_from_words, bit 255 included.
+constexpr int ROW_WORDS = 32;
+#ifndef C25519_WALK_PREFETCH
+#define C25519_WALK_PREFETCH 1       // A/B switch: 0 = the walk loads each row field right before the product that uses it
+#endif
+#ifndef C25519_WALK_LDS_PREFETCH
+#define C25519_WALK_LDS_PREFETCH 0   // A/B switch: 1 = the LDS base-table row of a sigma column is read before the doubling in front of it
+#endif
+
+C25519_DEV void fe_pack_words(u32 (&w)[8], const fe& a)
+{
+    u64 acc = (u64)a.v[0] + ((u64)a.v[1] << 26);
+    w[0] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[2] << 19;
+    w[1] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[3] << 13;
+    w[2] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[4] << 6;
+    w[3] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[5] + ((u64)a.v[6] << 25);
+    w[4] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[7] << 19;
+    w[5] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[8] << 12;
+    w[6] = (u32)acc; acc >>= 32;
+    acc += (u64)a.v[9] << 6;
+    w[7] = (u32)acc;
+}
+// one field of a row: p = row + 8 * field (32-byte aligned)
+C25519_DEV void load_field(fe& f, const u32* p)
+{
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1];
+    const u32 w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+    fe_from_words(f, w);
+}
+C25519_DEV void store_field(u32* p, const fe& f)
+{
+    u32 w[8];
+    fe_pack_words(w, f);
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+C25519_DEV void row_load_pe(ge_pe& q, const u32* row)
+{
+    load_field(q.ypx, row);
+    load_field(q.ymx, row + 8);
+    load_field(q.t2d, row + 16);
+    load_field(q.z2, row + 24);
+}
+C25519_DEV void row_store_neutral(u32* row)             // (Y+X, Y-X, 2dT, 2Z) of the neutral element: 1, 1, 0, 2
+{
+    uint4* q = reinterpret_cast<uint4*>(row);
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    q[0] = make_uint4(1, 0, 0, 0); q[1] = zero;
+    q[2] = make_uint4(1, 0, 0, 0); q[3] = zero;
+    q[4] = zero;                   q[5] = zero;
+    q[6] = make_uint4(2, 0, 0, 0); q[7] = zero;
+}
+
+// ---- per-lane window tables: rows 0..8 = 0, P, 2P, ..., 8P as packed rows ------------------------------------------------------
 constexpr int WTABLE_ROWS = 9;
-constexpr size_t WTABLE_WORDS = WTABLE_ROWS * PE_WORDS;   // 360 words = 1440 bytes per table
+constexpr size_t WTABLE_WORDS = WTABLE_ROWS * ROW_WORDS;  // 288 words = 1152 bytes per table
 
 // (x, y) affine.  ONE extended point lives in registers: P's own row is re-read from the table for the three "+ P"
 // steps (ge_add_pe_row below), 2P and 4P for the doublings that restart from them (a product and two carry passes each):
 // P, 2P, 3P, 6P, 7P, then (2P ->) 4P, 5P, then (4P ->) 8P.  Built this way the tables fit the walk kernel's registers.
-template <typename Tbl>
-C25519_DEV void wtable_build(const Tbl& tbl, const fe& x, const fe& y);
+C25519_DEV void wtable_build(u32* rows, const fe& x, const fe& y);
 
 // q <- -q when neg is all-ones: swap Y+X and Y-X, negate 2dT
 C25519_DEV void pe_cond_neg(ge_pe& q, u32 neg)
@@ -384,38 +450,81 @@ C25519_DEV void pe_cond_neg(ge_pe& q, u32 neg)
 
 // S += (neg ? -row : row), the row read from memory one field at a time, each right before the product that consumes it:
 // a whole row in registers (40) on top of the accumulator (40) and the addition's temporaries is what pushes the walk
-// over the register budget.  Negation is free here: -q swaps Y+X and Y-X (two base offsets) and negates 2dT (ten
+// over the register budget.  Negation is free here: -q swaps Y+X and Y-X (two field offsets) and negates 2dT (ten
 // subtractions), instead of thirty selects on a loaded row.  The sums B-A, B+A are formed as soon as A and B exist and
 // D-C, D+C as soon as C and D do, so at most four temporaries live beside the accumulator.
-C25519_DEV void load_fe_words(fe& f, const u32* p)
-{
-#pragma unroll
-    for (int i = 0; i < 10; i++) f.v[i] = p[i];
-}
 template <bool NEED_T>
 C25519_DEV void ge_add_pe_row(ge_ext& S, const u32* row, u32 neg)
 {
-    const u32* p_ypx = row + (neg ? 10 : 0);        // field that multiplies Y+X
-    const u32* p_ymx = row + (neg ? 0 : 10);        // field that multiplies Y-X
+    const u32* p_ypx = row + (neg ? 8 : 0);         // field that multiplies Y+X
+    const u32* p_ymx = row + (neg ? 0 : 8);         // field that multiplies Y-X
     fe q, a, b, e, f, g, h;
     fe_sub(a, S.Y, S.X);
-    load_fe_words(q, p_ymx);
+    load_field(q, p_ymx);
     fe_mul(a, a, q);
     fe_add(b, S.Y, S.X);
-    load_fe_words(q, p_ypx);
+    load_field(q, p_ypx);
     fe_mul(b, b, q);
     fe_sub(e, b, a);
     fe_add(h, b, a);
-    load_fe_words(q, row + 20);
+    load_field(q, row + 16);
     fe_neg(a, q);                                    // 2p - t2d: beta 2, fine as the second operand of a product
     fe_select(q, neg, a, q);
     fe_mul(a, S.T, q);                               // C
-    load_fe_words(q, row + 30);
+    load_field(q, row + 24);
     fe_mul(b, S.Z, q);                               // D
     fe_sub(f, b, a);                                 // beta 3: still a legal second operand
     fe_add(g, b, a);
     // second operands f, h, f, h: their 19-multiples (nine v_mul_lo_u32 each) are formed twice, not four times, and the
     // doubled odd limbs of the first operands e, e, g, g likewise
+    fe_mul(S.X, e, f);
+    if (NEED_T) fe_mul(S.T, e, h);
+    fe_mul(S.Z, g, f);
+    fe_mul(S.Y, g, h);
+}
+
+// The same addition from a row already fetched into registers (its 32 packed words).  The walk fetches the two rows of a
+// digit round at the TOP of the round -- their addresses only depend on the round's digits -- so the loads are 12 000
+// cycles old when the additions want them: measured 4.5 % of the pass against loading each field right before its product
+// (profiles/r03_ab_verify_structure.txt block 8), at two waves per SIMD instead of three (64 more registers), which the
+// VALU-bound walk does not mind.  -row: the words of Y+X and Y-X trade places before they are unpacked.
+struct packed_row { uint4 q[8]; };
+C25519_DEV void row_fetch(packed_row& r, const u32* row)
+{
+    const uint4* p = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.q[i] = p[i];
+}
+// field k of the row, or field k_neg where neg is all-ones
+C25519_DEV void field_of(fe& f, const packed_row& r, int k, int k_neg, u32 neg)
+{
+    const uint4 a = r.q[2 * k], b = r.q[2 * k + 1], c = r.q[2 * k_neg], d = r.q[2 * k_neg + 1];
+    const u32 wa[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w }, wb[8] = { c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
+    u32 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = neg ? wb[i] : wa[i];
+    fe_from_words(f, w);
+}
+template <bool NEED_T>
+C25519_DEV void ge_add_pe_regs(ge_ext& S, const packed_row& r, u32 neg)
+{
+    fe q, a, b, e, f, g, h;
+    fe_sub(a, S.Y, S.X);
+    field_of(q, r, 1, 0, neg);
+    fe_mul(a, a, q);
+    fe_add(b, S.Y, S.X);
+    field_of(q, r, 0, 1, neg);
+    fe_mul(b, b, q);
+    fe_sub(e, b, a);
+    fe_add(h, b, a);
+    field_of(q, r, 2, 2, 0u);
+    fe_neg(a, q);                                    // 2p - t2d: beta 2, fine as the second operand of a product
+    fe_select(q, neg, a, q);
+    fe_mul(a, S.T, q);                               // C
+    field_of(q, r, 3, 3, 0u);
+    fe_mul(b, S.Z, q);                               // D
+    fe_sub(f, b, a);
+    fe_add(g, b, a);
     fe_mul(S.X, e, f);
     if (NEED_T) fe_mul(S.T, e, h);
     fe_mul(S.Z, g, f);
@@ -450,42 +559,24 @@ C25519_DEV void ge_add_pa_lds(ge_ext& S, const u32* tbl, u32 r, bool need_t)
     fe_mul(S.Y, g, h);
 }
 
-// row <- PE form of S (ge_to_pe), written two fields at a time so that twenty words, not forty, wait in registers for
-// their stores (rows are 16-byte aligned: five 16-byte stores per half)
-C25519_DEV void store_two_fields(u32* p, const fe& a, const fe& b)
-{
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
-    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
-    q[2] = make_uint4(a.v[8], a.v[9], b.v[0], b.v[1]);
-    q[3] = make_uint4(b.v[2], b.v[3], b.v[4], b.v[5]);
-    q[4] = make_uint4(b.v[6], b.v[7], b.v[8], b.v[9]);
-}
+// row <- precomputed form of S (ge_to_pe), packed, a field at a time
 C25519_DEV void ge_store_pe_row(u32* row, const ge_ext& S)
 {
-    fe t, a, b;
-    fe_add(t, S.Y, S.X);  fe_carry32(a, t);
-    fe_sub(t, S.Y, S.X);  fe_carry32(b, t);
-    store_two_fields(row, a, b);
-    fe_mul(a, S.T, fe_const(K_2D));
-    fe_add(t, S.Z, S.Z);  fe_carry32(b, t);
-    store_two_fields(row + 20, a, b);
+    fe t, a;
+    fe_add(t, S.Y, S.X);  fe_carry32(a, t);  store_field(row, a);
+    fe_sub(t, S.Y, S.X);  fe_carry32(a, t);  store_field(row + 8, a);
+    fe_mul(a, S.T, fe_const(K_2D));          store_field(row + 16, a);
+    fe_add(t, S.Z, S.Z);  fe_carry32(a, t);  store_field(row + 24, a);
 }
 
-template <typename Tbl>
-C25519_DEV void wtable_build(const Tbl& tbl, const fe& x, const fe& y)
+C25519_DEV void wtable_build(u32* rows, const fe& x, const fe& y)
 {
     ge_ext S;
-    {
-        ge_pe pe;
-        fe_set_u32(pe.ypx, 1); fe_set_u32(pe.ymx, 1); fe_set_u32(pe.t2d, 0); fe_set_u32(pe.z2, 2);
-        tbl.store(0, pe);
-    }
+    row_store_neutral(rows);
     S.X = x; S.Y = y;
     fe_mul(S.T, x, y);
     fe_set_u32(S.Z, 1);
-    u32* const rows = tbl.base;
-    ge_store_pe_row(rows + PE_WORDS, S);
+    ge_store_pe_row(rows + ROW_WORDS, S);
     // seven steps, alternately a doubling and "+ P", as a loop (one copy of each operation, and the scheduler cannot
     // stretch live ranges across steps: the straight-line version took 207 registers, this one fits the 168 of three
     // waves per SIMD): rows 2, 3, 6, 7, then from 2P: 4, 5, then from 4P: 8
@@ -493,12 +584,12 @@ C25519_DEV void wtable_build(const Tbl& tbl, const fe& x, const fe& y)
     for (int step = 0; step < 7; step++) {
         if (step == 4 || step == 6) {
             ge_pe pe;
-            tbl.load(pe, step == 4 ? 2u : 4u);
+            row_load_pe(pe, rows + (step == 4 ? 2 : 4) * ROW_WORDS);
             ge_from_pe(S, pe);
         }
-        if (step & 1) ge_add_pe_row<true>(S, rows + PE_WORDS, 0u);
+        if (step & 1) ge_add_pe_row<true>(S, rows + ROW_WORDS, 0u);
         else ge_double<true>(S);
-        ge_store_pe_row(rows + ((0x8547632u >> (4 * step)) & 15u) * PE_WORDS, S);
+        ge_store_pe_row(rows + ((0x8547632u >> (4 * step)) & 15u) * ROW_WORDS, S);
     }
 }
 
@@ -507,33 +598,28 @@ C25519_DEV void wtable_build(const Tbl& tbl, const fe& x, const fe& y)
 // order by the same formulas -- row top+s = Q + row s with Q the extended and row s the precomputed operand, as the
 // reference's edp_AddPoint has them (that matters: for an off-curve "key" the values depend on it) -- but each sum is
 // formed in ONE extended point from a row streamed out of memory and leaves through ge_store_pe_row, so the build needs the
-// registers of the walk (Q, the sum, a product's temporaries), not 175.  rows: 16 x PE_WORDS.  Q is consumed.
+// registers of the walk (Q, the sum, a product's temporaries), not 175.  rows: 16 packed rows.  Q is consumed.
 C25519_DEV void qtable_build_streamed(u32* rows, ge_ext& Q)
 {
-    const QTableLimbs t{ rows };
-    {
-        ge_pe pe;
-        fe_set_u32(pe.ypx, 1); fe_set_u32(pe.ymx, 1); fe_set_u32(pe.t2d, 0); fe_set_u32(pe.z2, 2);
-        t.store(0, pe);
-    }
-    ge_store_pe_row(rows + PE_WORDS, Q);
+    row_store_neutral(rows);
+    ge_store_pe_row(rows + ROW_WORDS, Q);
 #pragma unroll 1
     for (int blk = 1; blk < 4; blk++) {               // Q <- 2^64 Q, then fill rows [2^blk, 2^(blk+1))
 #pragma unroll 1
         for (int i = 0; i < 63; i++) ge_double<false>(Q);
         ge_double<true>(Q);
         const int top = 1 << blk;
-        ge_store_pe_row(rows + top * PE_WORDS, Q);
-        // the sums restart from the row just written (PE -> extended is one product; the coordinates come back doubled,
-        // which the homogeneous formulas do not see), so Q itself does not have to stay in registers beside them
+        ge_store_pe_row(rows + top * ROW_WORDS, Q);
+        // the sums restart from the row just written (precomputed -> extended is one product; the coordinates come back
+        // doubled, which the homogeneous formulas do not see), so Q itself does not have to stay in registers beside them
 #pragma unroll 1
         for (int s = 1; s <= top; s++) {
             ge_pe pe;
-            t.load(pe, (u32)top);
+            row_load_pe(pe, rows + top * ROW_WORDS);
             ge_from_pe(Q, pe);
             if (s == top) break;                      // ... and Q is back for the next block's doublings
-            ge_add_pe_row<true>(Q, rows + s * PE_WORDS, 0u);
-            ge_store_pe_row(rows + (top + s) * PE_WORDS, Q);
+            ge_add_pe_row<true>(Q, rows + s * ROW_WORDS, 0u);
+            ge_store_pe_row(rows + (top + s) * ROW_WORDS, Q);
         }
     }
 }
@@ -544,26 +630,25 @@ C25519_DEV void ge_poly_mult_streamed(ge_ext& S, u32 (&s)[8], u32 (&h)[8], const
 {
     {
         ge_pe pe;
-        const QTableLimbs t{ const_cast<u32*>(rows) };
-        t.load(pe, fold4_next(h, false));
+        row_load_pe(pe, rows + fold4_next(h, false) * ROW_WORDS);
         ge_from_pe(S, pe);
     }
 #pragma unroll 1
     for (int i = 1; i < 32; i++) {
         ge_double(S);
-        ge_add_pe_row<false>(S, rows + fold4_next(h, false) * PE_WORDS, 0u);
+        ge_add_pe_row<false>(S, rows + fold4_next(h, false) * ROW_WORDS, 0u);
     }
 #pragma unroll 1
     for (int i = 32; i < 64; i++) {
         ge_double(S);
         ge_add_pa_lds(S, lds_tbl, fold8_next(s), true);     // T feeds the addition that follows
-        ge_add_pe_row<false>(S, rows + fold4_next(h, true) * PE_WORDS, 0u);
+        ge_add_pe_row<false>(S, rows + fold4_next(h, true) * ROW_WORDS, 0u);
     }
 }
 
 // the reference-order path for one element, start to finish (own table, own inversion): what ed25519_VerifySignature does
 // (ed25519_verify.c:163-176 = Verify_Init + Verify_Check), on the streamed forms above: 180 registers instead of the 268 of
-// the generic ones, two waves per SIMD.  lane_table: 16 x PE_WORDS of lane-private memory.  Sw is consumed.
+// the generic ones, two waves per SIMD.  lane_table: 16 packed rows of lane-private, 128-byte aligned memory.  Sw is consumed.
 // enc_out (tests): enc(T), what the verdict compares with the R bytes.
 C25519_DEV int ed_verify_reference_order(const u32 (&pkw)[8], const u32 (&Rw)[8], u32 (&Sw)[8], const uint8_t* msg, size_t len,
                                          u32* lane_table, const u32* lds_tbl, u32* enc_out = nullptr)
@@ -608,24 +693,30 @@ struct WalkScalars {
 // ride the last eight digits).  The kernels pass the maximum of walk_top_digit() over the wave: typical short vectors
 // have 127-131 bits, so a wave starts at digit 32 or 33 and walks 33-34 rounds of four doublings and two table
 // additions; leading zero digits would have added the neutral row, so skipping them is exact.
-template <typename Tbl>
-C25519_DEV u32 ge_walk_is_neutral(const WalkScalars& sc, const Tbl& tq, const Tbl& tr, const u32* lds_tbl, int top)
+// tq, tr: the element's two window tables (WTABLE_ROWS packed rows each).
+C25519_DEV u32 ge_walk_is_neutral(const WalkScalars& sc, const u32* tq, const u32* tr, const u32* lds_tbl, int top)
 {
     ge_ext S;
     {
         ge_pe pe;
         u32 neg;
         const u32 m = signed16_of(neg, sc.tau_word(top >> 3), top & 7);
-        tq.load(pe, m);
+        row_load_pe(pe, tq + m * ROW_WORDS);
         pe_cond_neg(pe, neg);
         ge_from_pe(S, pe);
         const u32 m2 = signed16_of(neg, sc.rho_word(top >> 3), top & 7);
-        ge_add_pe_row<false>(S, tr.base + (size_t)m2 * PE_WORDS, neg);
+        ge_add_pe_row<false>(S, tr + m2 * ROW_WORDS, neg);
     }
     // sigma's 8-fold columns ride on the last 32 doublings (the reference's own trick, ed25519_verify.c:266-279)
 #pragma unroll 1
     for (int i = top - 1; i >= 0; i--) {
         const u32 tw = sc.tau_word(i >> 3), rw = sc.rho_word(i >> 3);      // in flight under the doublings
+#if C25519_WALK_PREFETCH
+        u32 negq, negr;
+        packed_row rq, rr;
+        row_fetch(rq, tq + signed16_of(negq, tw, i & 7) * ROW_WORDS);
+        row_fetch(rr, tr + signed16_of(negr, rw, i & 7) * ROW_WORDS);
+#endif
         if (i >= 8) {
 #pragma unroll 1
             for (int j = 0; j < 3; j++) ge_double<false>(S);
@@ -634,16 +725,28 @@ C25519_DEV u32 ge_walk_is_neutral(const WalkScalars& sc, const Tbl& tq, const Tb
             u32 cols = sc.sigma_word(7 - i);
 #pragma unroll 1
             for (int j = 0; j < 4; j++) {
+#if C25519_WALK_LDS_PREFETCH
+                ge_pa pa;
+                lds_load_pa(pa, lds_tbl, cols & 255u);               // the LDS row, too, is on its way while S doubles
+                ge_double<true>(S);
+                ge_add_pa_rt(S, pa, j == 3);
+#else
                 ge_double<true>(S);
                 ge_add_pa_lds(S, lds_tbl, cols & 255u, j == 3);      // T feeds the key-table addition that follows the last one
+#endif
                 cols >>= 8;
             }
         }
+#if C25519_WALK_PREFETCH
+        ge_add_pe_regs<true>(S, rq, negq);
+        ge_add_pe_regs<false>(S, rr, negr);
+#else
         u32 neg;
         const u32 mq = signed16_of(neg, tw, i & 7);
-        ge_add_pe_row<true>(S, tq.base + (size_t)mq * PE_WORDS, neg);
+        ge_add_pe_row<true>(S, tq + mq * ROW_WORDS, neg);
         const u32 mr = signed16_of(neg, rw, i & 7);
-        ge_add_pe_row<false>(S, tr.base + (size_t)mr * PE_WORDS, neg);
+        ge_add_pe_row<false>(S, tr + mr * ROW_WORDS, neg);
+#endif
     }
     // neutral element: X == 0 and Y == Z (Z != 0 for on-curve inputs under the complete law)
     u32 xw[8], dw[8], acc = 0;

@@ -253,7 +253,8 @@ void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char*
         rd32(pkw, pk, i);
         rd32(Rw, sig, 2 * i);
         rd32(Sw, sig, 2 * i + 1);
-        const QTableLimbs tq{ q.data() }, tr{ q.data() + WTABLE_WORDS };
+        u32* const tq = q.data();
+        u32* const tr = q.data() + WTABLE_WORDS;
         // the kernels' chain: scalars -> decode (key, then R) -> tables -> walk
         const u32 lat_ok = ed_verify_fast_scalars(cols, rho, tau, tau_neg, pkw, Rw, Sw, msg + len * i, len);
         fe QX, QY, RX, RY;
