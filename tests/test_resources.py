@@ -23,7 +23,8 @@ def usage():
 # kernel (demangled prefix) -> the most registers it may allocate per lane (VGPR + AGPR): what its occupancy target allows
 HOT = {
     "k_x25519_fused<false>": 128, "k_x25519_fused<true>": 128,
-    "k_ed25519_verify_fast_scalars": 128, "k_ed25519_verify_fast_points": 168, "k_ed25519_verify_fast_walk": 168,
+    "k_ed25519_verify_fast_scalars": 128, "k_ed25519_verify_fast_points": 168, "k_ed25519_verify_fast_walk": 256,
+    "k_ed25519_verify_slow": 256,
     "k_ed25519_sign_mult<false>": 128, "k_ed25519_sign_mult<true>": 128,
     "k_ed25519_keypair_mult<false>": 128, "k_ed25519_keypair_mult<true>": 128,
     "k_x25519_public_fast_mult": 128, "k_ed25519_sign_finish": 128,
