@@ -118,7 +118,7 @@ int ed25519_VerifySignature_ragged_dev(void *verdict, const void *sig, const voi
 long c25519_amd_verify_last_slow_elements(void);
 
 /* bytes of device scratch ed25519_VerifySignature_dev needs for n elements (per-lane 4-fold tables);
- * the library allocates and caches it per host thread (about 3.1 KB per element). */
+ * the library allocates and caches it per host thread (about 2.8 KB per element). */
 size_t ed25519_VerifySignature_scratch_bytes(size_t n);
 
 /* Two-phase verification (reference include/ed25519_signature.h:77-93): one key, many signatures.
