@@ -436,16 +436,19 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VD_WAVES) k_ed25519_verify_fa
         fs.slow_list[atomicAdd(fs.slow_count, 1u)] = (u32)e;      // (the compiler aggregates this per wave)
     }
     // the point's window table, right here: a table is 1152 bytes of 16-byte stores scattered over as many cache lines, and
-    // they hide under the other waves' square roots (in a kernel of their own: 1.3 ms with the SIMDs idle half the time; in
-    // front of the walk, inside its kernel: 1.0 ms; here 0.6 ms -- profiles/r03_ab_verify_structure.txt).
+    // they hide under the other waves' square roots (measured with the earlier 160-byte rows: in a kernel of their own 1.3 ms
+    // with the SIMDs idle half the time; in front of the walk, inside its kernel, 1.0 ms; here 0.6 ms --
+    // profiles/r03_ab_verify_structure.txt).
     // (An element that turns out to be on the slow list gets tables nobody reads: the key lane cannot tell the R lane in time.)
     wtable_build(fs.tables + e * FAST_TABLE_WORDS + (is_r ? WTABLE_WORDS : 0), X, Y);
 }
 
-// step 3: the walk and the neutral-element test.  Across a digit round nothing but the accumulator point lives in
-// registers (the scalars are fetched a word at a time, table rows and LDS rows a field at a time): 154 registers, three
-// waves per SIMD, no spills.  The kernel is VALU-bound -- every SIMD issues ~100 % of the time (SQ_ACTIVE_INST_ANY against
-// SQ_BUSY_CYCLES, profiles/r03_pmc.txt), and it measured the same at two, three and four waves per SIMD.
+// step 3: the walk and the neutral-element test (ge_walk_is_neutral).  Beside the accumulator point only the round's two
+// packed table rows live in registers -- fetched at the top of the round, unpacked field by field when the additions want
+// them -- ; the scalars are fetched a word at a time, LDS rows a field at a time: 216 registers, two waves per SIMD, no
+// spills.  The kernel is VALU-bound: a SIMD has a VALU instruction executing in 97 % of the shader's cycles
+// (SQ_ACTIVE_INST_VALU * 4 / 1024 against GRBM_GUI_ACTIVE / 8, profiles/r03_pmc.txt), and it measured the same at two,
+// three (154 registers without the prefetch) and four waves per SIMD.
 __global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fast_walk(FastScratch fs, int* verdict, size_t n,
                                                                                         const u32* __restrict__ g_tbl)
 {

@@ -532,8 +532,8 @@ C25519_DEV void ge_add_pe_regs(ge_ext& S, const packed_row& r, u32 neg)
 }
 
 // S += row r of the limb-major LDS base table ([30][256] words), one field at a time like ge_add_pe_row.  need_t is a
-// run-time (wave-uniform) flag on purpose: ONE copy of the addition in the walk's loop keeps the register allocation
-// at 154 VGPRs (three waves per SIMD, no spills); the two template instances of ge_add_pa cost 182.
+// run-time (wave-uniform) flag on purpose: ONE copy of the addition in the walk's loop saves 28 registers against the two
+// template instances of ge_add_pa (154 against 182 when this was measured, without the row prefetch).
 C25519_DEV void ge_add_pa_lds(ge_ext& S, const u32* tbl, u32 r, bool need_t)
 {
     fe q, a, b, e, f, g, h;
