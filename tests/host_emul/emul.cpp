@@ -272,6 +272,20 @@ void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char*
     }
 }
 
+// fe_pack_words / fe_from_words on raw limbs (10 u32 per element in, 8 words out, 10 limbs back)
+void emul_fe_pack_roundtrip(unsigned* words_out /* n x 8 */, unsigned* limbs_out /* n x 10 */, const unsigned* limbs_in /* n x 10 */, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        fe a, b;
+        for (int j = 0; j < 10; j++) a.v[j] = limbs_in[10 * i + j];
+        u32 w[8];
+        fe_pack_words(w, a);
+        fe_from_words(b, w);
+        for (int j = 0; j < 8; j++) words_out[8 * i + j] = w[j];
+        for (int j = 0; j < 10; j++) limbs_out[10 * i + j] = b.v[j];
+    }
+}
+
 // loop trips of the lattice reduction since the last call (outer Lehmer steps, their inner iterations, exact steps)
 void emul_lattice_counters(unsigned long long* out3)
 {

@@ -62,6 +62,43 @@ def test_short_vector_properties(emul):
     assert [int(f) for f in fits[:12]] == [1, 1, 1, 1, 0, 0, 1, 1, 1, 1, 0, 1]
 
 
+def test_packed_table_rows_keep_the_value(emul):
+    """Table rows are stored as 256-bit integers (fe_pack_words) and unpacked by fe_from_words.  Packing is a positional sum,
+    so it must be exact for every limb pattern the kernels can hand it -- fe_carry32 outputs (limb 1 may be 2^25, limb 0 up to
+    2^26 + a little), product outputs (every limb up to 2^w + 2^17), all-ones and all-zero limbs -- as long as the value stays
+    below 2^256; and the unpacked limbs must be 'reduced' again (fit the second-operand bound of a product) and congruent."""
+    P = 2**255 - 19
+    W = [26, 25] * 5
+    POS = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
+    rng = np.random.default_rng(0x9ac4)
+    pats = []
+    pats.append([0] * 10)
+    pats.append([(1 << w) - 1 for w in W])                                  # all limbs all-ones: 2^255 - 1
+    pats.append([(1 << w) + (1 << 17) - 1 for w in W])                      # a product output at its bound
+    pats.append([(1 << 26) + 18, 1 << 25] + [(1 << w) - 1 for w in W[2:]])  # fe_carry32's worst wrap
+    pats.append([(1 << 26) - 1, 1 << 25] + [0] * 7 + [(1 << 25) - 1])
+    for _ in range(2000):
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            pats.append([int(rng.integers(0, (1 << w) + (1 << 17))) for w in W])
+        elif kind == 1:
+            pats.append([int(rng.integers((1 << w) - 4, (1 << w) + (1 << 17))) for w in W])
+        else:
+            pats.append([int(rng.integers(0, 1 << w)) for w in W])
+    n = len(pats)
+    limbs = np.array(pats, dtype=np.uint32)
+    words, back = np.zeros((n, 8), np.uint32), np.zeros((n, 10), np.uint32)
+    emul.emul_fe_pack_roundtrip(C.c_void_p(words.ctypes.data), C.c_void_p(back.ctypes.data), C.c_void_p(limbs.ctypes.data), C.c_size_t(n))
+    for i, l in enumerate(pats):
+        value = sum(x << p for x, p in zip(l, POS))
+        assert value < 2**256
+        packed = sum(int(w) << (32 * k) for k, w in enumerate(words[i]))
+        assert packed == value, (i, l)
+        got = sum(int(x) << p for x, p in zip(back[i], POS))
+        assert got % P == value % P, (i, l)
+        assert all(int(back[i][j]) < (1 << W[j]) + (1 << 17) for j in range(10)), (i, list(back[i]))
+
+
 def test_short_vector_search_in_lock_step_waves(emul):
     """The same search with the elements grouped into waves of 8 and 64 lanes that run in lock-step, __any taken over the
     wave as on the device (tests/host_emul/valu_model.h): lanes that are done idle while others iterate, loops end when

@@ -330,6 +330,14 @@ def main():
 
     for v in ge_add_pe_row(R, R, R, R, R, R, t2d_neg, R) + ge_add_pa_lds(R, R, R, R, CANON, CANON, CANON):
         need(all(v[i] <= R[i] for i in range(10)), "streamed addition: output not reduced")
+    # packed table rows (fe_pack_words): what ge_store_pe_row packs -- fe_carry32 outputs and one product -- stays below
+    # 2^256 as a positional sum, and what fe_from_words hands back is a legal second operand again
+    POS = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
+    for v, what in ((carry32(add(R, R)), "row Y+X"), (carry32(sub(R, R, "row Y-X")), "row Y-X"), (mul(R, CANON, "row 2dT"), "row 2dT"),
+                    (carry32(add(R, R)), "row 2Z")):
+        need(sum(x << p for x, p in zip(v, POS)) < 1 << 256, f"packed {what} does not fit 256 bits")
+    for v in ge_add_pe_row(R, R, R, R, FROM_WORDS, FROM_WORDS, select(neg(FROM_WORDS, "row neg"), FROM_WORDS), FROM_WORDS):
+        need(all(v[i] <= R[i] for i in range(10)), "addition of an unpacked row: output not reduced")
     mul(t2d_neg, CANON, "from_pe T of a negated row")        # ge_from_pe: t2d is the FIRST operand (beta <= 5)
     to_words(add(mul(sqr(R, "check x^2"), add(R, ONE), "check v x^2"), R), "calc check c + u")      # ge_calc_x_checked
     to_words(sub(R, R, "neutral Y - Z"), "neutral test to_words")
