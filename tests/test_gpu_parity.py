@@ -753,7 +753,7 @@ def test_bench_self_launches_two_ranks():
 
 
 def test_lattice_fast_path_and_reference_order_agree(api, oracle):
-    """ed25519_VerifySignature's default path decides on-curve workgroups with the exact lattice-shortened walk
+    """ed25519_VerifySignature's default path decides every element whose key is on the curve with the exact lattice-shortened walk
     (csrc/verify_fast.cuh) and runs the reference's operation order for the rest.  Every class of input where the two
     could differ, against the oracle: corrupted signatures, S >= L, keys / R's with torsion components (a cofactored
     check would accept eight times as many), small-order keys, R encodings no encoder produces, garbage.  The
@@ -785,7 +785,7 @@ def test_lattice_fast_path_and_reference_order_agree(api, oracle):
     m = sp.shape[0]
     ssig = np.ascontiguousarray(np.concatenate([sp, bsig[:m, 32:]], axis=1))
     assert np.array_equal(api.ed25519_VerifySignature(ssig, pub[:m], bmsg[:m]), oracle.ed25519_verify(ssig, pub[:m], bmsg[:m]))
-    # one garbage key in a batch sends exactly its 256-element workgroup down the reference-order path
+    # a garbage key in a batch sends exactly its own element down the reference-order path (the slow list)
     mixed = pub.copy()
     gkey = synth.random_bytes((64, 32), 0x999)
     off = next(k for k in gkey if vectors.ed_decode(int.from_bytes(k.tobytes(), "little") & (2**255 - 1), 0) is None)
