@@ -32,6 +32,9 @@ C25519_DEV u32 dbl32(u32 x)
     return r;
 }
 
+// a / b in single precision, a few ulp off (v_rcp_f32 + v_mul_f32): used only where an estimate is wanted
+C25519_DEV float fast_div(float a, float b) { return __fdividef(a, b); }
+
 // (hi:lo) >> s, low 32 bits   (v_alignbit_b32)
 C25519_DEV u32 alignbit32(u32 hi, u32 lo, int s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
 

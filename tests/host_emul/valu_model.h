@@ -67,6 +67,7 @@ extern LatCounters emul_lat_counters;
 #define C25519_LAT_COUNT(what) __atomic_fetch_add(&::c25519::emul_lat_counters.what, 1ULL, __ATOMIC_RELAXED)
 
 inline u32 dbl32(u32 x) { return x + x; }
+inline float fast_div(float a, float b) { return a / b; }
 inline u32 alignbit32(u32 hi, u32 lo, int s) { return (u32)((((u64)hi << 32) | lo) >> s); }
 
 // v_mad_u64_u32 wraps modulo 2^64 exactly like unsigned C arithmetic; the model additionally REPORTS a wrap,
