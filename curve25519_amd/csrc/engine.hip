@@ -156,8 +156,9 @@ __global__ void __launch_bounds__(XF_BLOCK, C25519_XF_WAVES) k_x25519_fused(void
 // ge_base_mult (ge_signed_comb_row).  Two more workgroups: row k = sum over set bits i of k of 2^(32 i) * B as canonical
 // (Y+X, Y-X, 2dT) -- the content of the reference's source/base_folding8.h, derived from B by doubling/adding (the recipe
 // of test/curve25519_selftest.c:498-551) -- written twice: limb-major limbs after the signed tables (REF_TBL_OFFSET:
-// verification's sigma columns) and 96-byte canonical rows for inspection.
-__global__ void __launch_bounds__(BASE_ROWS) k_gen_base_table(u32* tbl_limbs /*[BASE_NT][30][128] + [30][256]*/,
+// the reference-order verification's sigma columns) and 96-byte canonical rows for inspection.  SC_ROWS / 128 more: the
+// lattice walk's signed comb table (SC_TBL_OFFSET).
+__global__ void __launch_bounds__(BASE_ROWS) k_gen_base_table(u32* tbl_limbs /*[BASE_NT][30][128] + [30][256] + [30][SC_ROWS]*/,
                                                               u32* tbl_bytes /*[256][24]*/)
 {
     u32 rows[3][8];
@@ -172,6 +173,19 @@ __global__ void __launch_bounds__(BASE_ROWS) k_gen_base_table(u32* tbl_limbs /*[
             fe_from_words(c, rows[f]);            // canonical value back in limb form
 #pragma unroll
             for (int l = 0; l < 10; l++) limbs[(10 * f + l) * BASE_ROWS + idx] = c.v[l];
+        }
+        return;
+    }
+    if (blockIdx.x >= BASE_NT + 256 / BASE_ROWS) {            // the verification walk's signed comb: SC_ROWS rows
+        const u32 idx = (blockIdx.x - (BASE_NT + 256 / BASE_ROWS)) * BASE_ROWS + threadIdx.x;
+        ge_signed_comb_row(rows, idx, 0, SC_TEETH, SC_COLS);
+        u32* limbs = tbl_limbs + SC_TBL_OFFSET;
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            fe c;
+            fe_from_words(c, rows[f]);
+#pragma unroll
+            for (int l = 0; l < 10; l++) limbs[(10 * f + l) * SC_ROWS + idx] = c.v[l];
         }
         return;
     }
@@ -372,7 +386,7 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VC_WAVES) k_ed25519_verify_ch
 // Four kernels.  scalars -> points -> walk decide every element whose key is on the curve (and whose short
 // vector fits the walk: a random one practically always does); the elements they cannot decide are collected in a list
 // and k_ed25519_verify_slow runs the reference's own operation order for exactly those.
-// Per-element hand-over, struct-of-arrays: sigma_cols[8] (the 32 column bytes of sigma), rho[5], tau[5] (biased), a flag word
+// Per-element hand-over, struct-of-arrays: sigma_cols[SIGMA_WORDS] (sigma's signed comb columns), rho[5], tau[5] (biased), a flag word
 //   bit 0  R decodes canonically onto the curve      bit 1  the key is on the curve
 //   bit 2  the short vector fits the walk             bit 3  tau < 0
 //   bit 4  the element is on the slow list            bits 8..13  top nonzero digit of the element's scalars
@@ -389,6 +403,10 @@ constexpr u32 FLAG_R_OK = 1u, FLAG_KEY_OK = 2u, FLAG_FITS = 4u, FLAG_TAU_NEG = 8
 #ifndef C25519_VW_WAVES
 #define C25519_VW_WAVES 2            // waves per SIMD the register allocator aims at: the walk kernel (rows prefetched) ...
 #endif
+#ifndef C25519_WALK_BLOCK
+#define C25519_WALK_BLOCK C25519_ED_BLOCK       // lanes per walk workgroup (they share one staged comb table)
+#endif
+constexpr int WALK_BLOCK = C25519_WALK_BLOCK;
 #ifndef C25519_VD_WAVES
 #define C25519_VD_WAVES 3            // ... and the point decoding + table kernel
 #endif
@@ -400,12 +418,13 @@ __global__ void __launch_bounds__(FS_BLOCK) k_ed25519_verify_fast_scalars(FastSc
     const size_t i = (size_t)blockIdx.x * FS_BLOCK + threadIdx.x;
     if (i == 0) *fs.slow_count = 0;
     if (i >= n) return;
-    u32 pkw[8], Rw[8], Sw[8], cols[8], rho[5], tau[5], tau_neg;
+    u32 pkw[8], Rw[8], Sw[8], cols[SIGMA_WORDS], rho[5], tau[5], tau_neg;
     load32(pkw, pk, i);
     load32(Rw, sig, 2 * i);
     load32(Sw, sig, 2 * i + 1);
     const u32 lat_ok = ed_verify_fast_scalars(cols, rho, tau, tau_neg, pkw, Rw, Sw, msgs.ptr(i), msgs.len(i));
-    soa_store8(fs.sigma, n, i, cols);
+#pragma unroll
+    for (int w = 0; w < SIGMA_WORDS; w++) fs.sigma[(size_t)w * n + i] = cols[w];
 #pragma unroll
     for (int w = 0; w < 5; w++) { fs.rho[(size_t)w * n + i] = rho[w]; fs.tau[(size_t)w * n + i] = tau[w]; }
     const int top = lat_ok ? walk_top_digit(tau, rho) : 0;
@@ -449,12 +468,12 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VD_WAVES) k_ed25519_verify_fa
 // spills.  The kernel is VALU-bound: a SIMD has a VALU instruction executing in 97 % of the shader's cycles
 // (SQ_ACTIVE_INST_VALU * 4 / 1024 against GRBM_GUI_ACTIVE / 8, profiles/r03_pmc.txt), and it measured the same at two,
 // three (154 registers without the prefetch) and four waves per SIMD.
-__global__ void __launch_bounds__(ED_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fast_walk(FastScratch fs, int* verdict, size_t n,
+__global__ void __launch_bounds__(WALK_BLOCK, C25519_VW_WAVES) k_ed25519_verify_fast_walk(FastScratch fs, int* verdict, size_t n,
                                                                                         const u32* __restrict__ g_tbl)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
-    lds_stage_words(lds_tbl, g_tbl + REF_TBL_OFFSET, REF_TBL_WORDS);
-    const size_t i = (size_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[SC_TBL_WORDS];
+    lds_stage_words(lds_tbl, g_tbl + SC_TBL_OFFSET, SC_TBL_WORDS);
+    const size_t i = (size_t)blockIdx.x * WALK_BLOCK + threadIdx.x;
     const u32 f = i < n ? fs.flags[i] : FLAG_SLOW;
     const bool walks = !(f & FLAG_SLOW);
     // the wave walks from its longest element's first digit (the others' digits above their own are zero)
@@ -711,16 +730,16 @@ constexpr int MAX_DEVICES = 64;
 struct DeviceTables {
     std::once_flag once;
     int rc = 0;
-    u32* limbs = nullptr;     // [BASE_NT][30][128] signed comb tables 2^28 Ts .. Ts, then [30][256]: the reference's table T
+    u32* limbs = nullptr;     // [BASE_NT][30][128] signed comb tables 2^28 Ts .. Ts, [30][256]: the reference's table T, [30][SC_ROWS]: the lattice walk's comb
     u32* bytes = nullptr;     // [256][24]
 };
 DeviceTables g_tables[MAX_DEVICES];
 
 int init_tables(DeviceTables& t)
 {
-    C25519_TRY(hipMalloc(&t.limbs, (REF_TBL_OFFSET + REF_TBL_WORDS) * sizeof(u32)));
+    C25519_TRY(hipMalloc(&t.limbs, ALL_TBL_WORDS * sizeof(u32)));
     C25519_TRY(hipMalloc(&t.bytes, 256 * 24 * sizeof(u32)));
-    k_gen_base_table<<<BASE_NT + 256 / BASE_ROWS, BASE_ROWS, 0, nullptr>>>(t.limbs, t.bytes);
+    k_gen_base_table<<<BASE_NT + (256 + SC_ROWS) / BASE_ROWS, BASE_ROWS, 0, nullptr>>>(t.limbs, t.bytes);
     C25519_TRY(hipGetLastError());
     C25519_TRY(hipStreamSynchronize(nullptr));
     return 0;
@@ -817,7 +836,7 @@ int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t 
 // the fast path's scalars, flags and slow list
 constexpr size_t VERIFY_TABLE_WORDS = FAST_TABLE_WORDS > QTABLE_LIMB_WORDS ? FAST_TABLE_WORDS : QTABLE_LIMB_WORDS;
 static_assert(FAST_TABLE_WORDS % 32 == 0 && VERIFY_TABLE_WORDS % 32 == 0, "per-lane tables must keep their rows 128-byte aligned");
-inline size_t verify_scalar_words(size_t n) { return round_up(8 * n, 4) + 2 * round_up(5 * n, 4) + 2 * round_up(n, 4) + 4; }
+inline size_t verify_scalar_words(size_t n) { return round_up(SIGMA_WORDS * n, 4) + 2 * round_up(5 * n, 4) + 2 * round_up(n, 4) + 4; }
 inline size_t verify_scratch_bytes(size_t n)
 {
     return (n * VERIFY_TABLE_WORDS + proj_words(n) + verify_scalar_words(n)) * sizeof(u32);
@@ -846,7 +865,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
         FastScratch fs;
         fs.tables = tables;
         fs.sigma = tables + n * VERIFY_TABLE_WORDS + proj_words(n);
-        fs.rho = fs.sigma + round_up(8 * n, 4);
+        fs.rho = fs.sigma + round_up(SIGMA_WORDS * n, 4);
         fs.tau = fs.rho + round_up(5 * n, 4);
         fs.flags = fs.tau + round_up(5 * n, 4);
         fs.slow_list = fs.flags + round_up(n, 4);
@@ -856,7 +875,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
         C25519_TRY(hipGetLastError());
         k_ed25519_verify_fast_points<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
         C25519_TRY(hipGetLastError());
-        k_ed25519_verify_fast_walk<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
+        k_ed25519_verify_fast_walk<<<grid_for(n, WALK_BLOCK), WALK_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
         C25519_TRY(hipGetLastError());
         k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
         C25519_TRY(hipGetLastError());

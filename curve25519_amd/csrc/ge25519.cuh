@@ -249,6 +249,21 @@ constexpr int BASE_ROWS = 128;
 constexpr int BASE_TBL_WORDS = PA_WORDS * BASE_ROWS;
 constexpr int REF_TBL_WORDS = PA_WORDS * 256;
 constexpr int REF_TBL_OFFSET = BASE_NT * BASE_TBL_WORDS;
+// Verification's walk adds sigma*B as ONE signed comb of SC_TEETH teeth SC_COLS bits apart (verify_fast.cuh): 2^(teeth-1)
+// rows and a sign, SC_COLS additions riding the walk's last SC_COLS doublings.  The reference's 8-fold table (256 rows,
+// 32 additions: edp_PolyPointMultiply, ed25519_verify.c:266-279) is the 8-tooth unsigned member of the family; ten signed
+// teeth are 512 rows = 60 KiB of LDS, which two 256-lane workgroups per CU still hold, and 26 additions.
+#ifndef C25519_WALK_COMB_TEETH
+#define C25519_WALK_COMB_TEETH 10
+#endif
+constexpr int SC_TEETH = C25519_WALK_COMB_TEETH;
+constexpr int SC_COLS = (254 + SC_TEETH - 1) / SC_TEETH;     // the recoded scalar has SC_TEETH * SC_COLS >= 254 digits
+constexpr int SC_ROWS = 1 << (SC_TEETH - 1);
+constexpr int SC_TBL_WORDS = PA_WORDS * SC_ROWS;
+constexpr int SC_TBL_OFFSET = REF_TBL_OFFSET + REF_TBL_WORDS;
+constexpr int SC_ROUNDS = (SC_COLS + 3) / 4;                 // digit rounds (four doublings each) that carry columns
+constexpr int SIGMA_WORDS = 2 * SC_ROUNDS;                   // two 16-bit columns per word, two words per round
+constexpr int ALL_TBL_WORDS = SC_TBL_OFFSET + SC_TBL_WORDS;
 
 // w of the recoding above.  k < 2^255 + 2^254 (clamped scalars, scalars mod L).
 C25519_DEV void sc_signed_comb(u32 (&w)[8], const u32 (&k)[8])

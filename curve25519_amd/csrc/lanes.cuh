@@ -215,9 +215,11 @@ C25519_DEV void ge_base_table_row(u32 (&rows)[3][8], u32 k, int extra)
     for (int f = 0; f < 3; f++) fe_to_words(rows[f], row[f]);
 }
 
-// row idx (7 bits) of a signed comb table: 2^extra * (2^224 + sum over j < 7 of (bit j of idx ? + : -) 2^(32 j)) * B, as
-// canonical words of (Y+X, Y-X, 2dT) -- what ge_base_mult's recoding selects for a column whose top digit is +1
-C25519_DEV void ge_signed_comb_row(u32 (&rows)[3][8], u32 idx, int extra)
+// row idx (teeth - 1 bits) of a signed comb table with `teeth` teeth `spacing` bits apart:
+// 2^extra * (2^(spacing*(teeth-1)) + sum over j < teeth-1 of (bit j of idx ? + : -) 2^(spacing j)) * B, as canonical words
+// of (Y+X, Y-X, 2dT) -- what the signed recodings (ge_base_mult: 8 x 32; the verification walk: SC_TEETH x SC_COLS) select
+// for a column whose top digit is +1
+C25519_DEV void ge_signed_comb_row(u32 (&rows)[3][8], u32 idx, int extra, int teeth = 8, int spacing = 32)
 {
     ge_pa B, Bn;
     B.ypx = fe_const(K_BY); B.ymx = fe_const(K_BY);
@@ -234,9 +236,9 @@ C25519_DEV void ge_signed_comb_row(u32 (&rows)[3][8], u32 idx, int extra)
     fe_set_u32(S.X, 0); fe_set_u32(S.Y, 1); fe_set_u32(S.Z, 1); fe_set_u32(S.T, 0);
     ge_add_pa(S, B);
 #pragma unroll 1
-    for (int i = 6; i >= 0; i--) {                           // Horner over the seven signed teeth, 32 doublings apart
+    for (int i = teeth - 2; i >= 0; i--) {                   // Horner over the signed teeth, `spacing` doublings apart
 #pragma unroll 1
-        for (int j = 0; j < 32; j++) ge_double(S);
+        for (int j = 0; j < spacing; j++) ge_double(S);
         if ((idx >> i) & 1) ge_add_pa(S, B);
         else ge_add_pa(S, Bn);
     }

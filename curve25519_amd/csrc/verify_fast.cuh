@@ -390,16 +390,43 @@ C25519_DEV int walk_top_digit(const u32 (&tau_b)[5], const u32 (&rho_b)[5])
     return top;
 }
 
-// the 32 8-fold columns of sigma, one byte each, in walk order: byte n (of word n >> 2) = bit (31 - n) of every word
-// (ecp_8Folds, curve25519_utils.c:144-153).  The walk reads one word per digit round instead of holding all of sigma.
-C25519_DEV void sc_fold8_columns(u32 (&cols)[8], const u32 (&k)[8])
+// sigma recoded for the walk's signed comb (SC_TEETH teeth, SC_COLS bits apart; the recoding of ge_base_mult, ge25519.cuh):
+// sigma is made odd (+ L when even: L*B = O) and written with SC_TEETH * SC_COLS digits +-1, w = (sigma' >> 1) | top bit;
+// column c = the SC_TEETH bits of w at c, c + SC_COLS, ...: the top one is the column's sign, the others the table row
+// (complemented for a negative column).  Stored 16 bits per column in the order the walk consumes them: digit round i
+// (four doublings) reads words 2i and 2i + 1 = columns 4i+3, 4i+2 | 4i+1, 4i, the first of them in the low half.  The walk
+// reads two words per round instead of holding all of sigma.  sigma < L.
+C25519_DEV void sc_comb_columns(u32 (&cols)[SIGMA_WORDS], const u32 (&k)[8])
 {
+    const u32 even = (k[0] & 1u) - 1u;                       // all-ones when sigma is even
+    u32 t[9], w[9];
+    u64 c = 0;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        u32 w = 0;
+    for (int i = 0; i < 8; i++) {
+        c += (u64)k[i] + (K_L[i] & even);
+        t[i] = (u32)c;
+        c >>= 32;
+    }
+    t[8] = (u32)c;                                           // 0: sigma + L < 2^254
 #pragma unroll
-        for (int b = 0; b < 4; b++) w |= fold8_at(k, 4 * q + b) << (8 * b);
-        cols[q] = w;
+    for (int i = 0; i < 8; i++) w[i] = (t[i] >> 1) | (t[i + 1] << 31);
+    w[8] = 0;
+    constexpr int TOP = SC_TEETH * SC_COLS - 1;              // digit TOP is +1
+    w[TOP >> 5] |= 1u << (TOP & 31);
+    auto column = [&](int col) -> u32 {
+        u32 idx = 0;
+        if (col >= SC_COLS) return 0u;
+#pragma unroll
+        for (int j = 0; j < SC_TEETH; j++) {
+            const int bit = SC_COLS * j + col;
+            idx |= ((w[bit >> 5] >> (bit & 31)) & 1u) << j;
+        }
+        return idx;
+    };
+#pragma unroll
+    for (int r = 0; r < SC_ROUNDS; r++) {
+        cols[2 * r] = column(4 * r + 3) | (column(4 * r + 2) << 16);
+        cols[2 * r + 1] = column(4 * r + 1) | (column(4 * r) << 16);
     }
 }
 
@@ -413,9 +440,6 @@ C25519_DEV void sc_fold8_columns(u32 (&cols)[8], const u32 (&k)[8])
 constexpr int ROW_WORDS = 32;
 #ifndef C25519_WALK_PREFETCH
 #define C25519_WALK_PREFETCH 1       // A/B switch: 0 = the walk loads each row field right before the product that uses it
-#endif
-#ifndef C25519_WALK_LDS_PREFETCH
-#define C25519_WALK_LDS_PREFETCH 0   // A/B switch: 1 = the LDS base-table row of a sigma column is read before the doubling in front of it
 #endif
 
 C25519_DEV void fe_pack_words(u32 (&w)[8], const fe& a)
@@ -601,6 +625,40 @@ C25519_DEV void ge_add_pa_lds(ge_ext& S, const u32* tbl, u32 r, bool need_t)
     fe_mul(S.Y, g, h);
 }
 
+// S += column c of the walk's signed comb table (limb-major LDS table [30][SC_ROWS] words): bit SC_TEETH-1 of c is the sign
+// (0: the column is negative -- row ~c, negated on the way out of LDS: (y+x, y-x, 2dxy) -> (y-x, y+x, -2dxy)), one field at
+// a time like ge_add_pa_lds, need_t a run-time flag for the same reason.
+C25519_DEV void ge_add_pa_comb(ge_ext& S, const u32* tbl, u32 c, bool need_t)
+{
+    const u32 neg = ((c >> (SC_TEETH - 1)) & 1u) - 1u;       // all-ones: negative column
+    const u32 r = (c ^ neg) & (u32)(SC_ROWS - 1);
+    const u32* p_ypx = tbl + (neg ? 10 * SC_ROWS : 0) + r;
+    const u32* p_ymx = tbl + (neg ? 0 : 10 * SC_ROWS) + r;
+    fe q, a, b, e, f, g, h;
+    fe_sub(a, S.Y, S.X);
+#pragma unroll
+    for (int i = 0; i < 10; i++) q.v[i] = p_ymx[i * SC_ROWS];
+    fe_mul(a, a, q);
+    fe_add(b, S.Y, S.X);
+#pragma unroll
+    for (int i = 0; i < 10; i++) q.v[i] = p_ypx[i * SC_ROWS];
+    fe_mul(b, b, q);
+    fe_sub(e, b, a);
+    fe_add(h, b, a);
+#pragma unroll
+    for (int i = 0; i < 10; i++) q.v[i] = tbl[(20 + i) * SC_ROWS + r];
+    fe_neg(a, q);                                    // 2p - 2dxy: beta 2, fine as the second operand of a product
+    fe_select(q, neg, a, q);
+    fe_mul(a, S.T, q);                               // C
+    fe_add(b, S.Z, S.Z);                             // D
+    fe_sub(f, b, a);
+    fe_add(g, b, a);
+    fe_mul(S.X, f, e);
+    if (need_t) fe_mul(S.T, e, h);
+    fe_mul(S.Z, f, g);
+    fe_mul(S.Y, g, h);
+}
+
 // row <- precomputed form of S (ge_to_pe), packed, a field at a time
 C25519_DEV void ge_store_pe_row(u32* row, const ge_ext& S)
 {
@@ -720,7 +778,7 @@ C25519_DEV int ed_verify_reference_order(const u32 (&pkw)[8], const u32 (&Rw)[8]
 // ---- the walk ----------------------------------------------------------------------------------------------------------
 // Where a lane's scalars live while it walks: struct-of-arrays scratch written by the scalars kernel (word w of element i
 // at base[w * n + i]; the host emulation passes n = 1, i = 0).  The walk fetches ONE word of each per digit round -- the
-// round's nibble of tau and rho, the round's four column bytes of sigma -- instead of holding 18 words in registers.
+// round's nibble of tau and rho, the round's four comb columns of sigma -- instead of holding 18 words in registers.
 struct WalkScalars {
     const u32 *sigma_cols, *tau, *rho;
     size_t n, i;
@@ -731,8 +789,8 @@ struct WalkScalars {
 
 // W = sigma*B + tau*Q + rho*Rn from the two window tables (Q and Rn = -R already carry the signs of tau and of the
 // equation), the biased scalars and the LDS base table; returns all-ones iff W is the neutral element.
-// `top`: the walk starts at this digit; every digit above it must be zero in both scalars, and top >= 8 (sigma's columns
-// ride the last eight digits).  The kernels pass the maximum of walk_top_digit() over the wave: typical short vectors
+// `top`: the walk starts at this digit; every digit above it must be zero in both scalars, and top >= SC_ROUNDS (sigma's
+// columns ride the last SC_ROUNDS digit rounds; the kernels pass at least 8).  The kernels pass the maximum of walk_top_digit() over the wave: typical short vectors
 // have 127-131 bits, so a wave starts at digit 32 or 33 and walks 33-34 rounds of four doublings and two table
 // additions; leading zero digits would have added the neutral row, so skipping them is exact.
 // tq, tr: the element's two window tables (WTABLE_ROWS packed rows each).
@@ -749,7 +807,8 @@ C25519_DEV u32 ge_walk_is_neutral(const WalkScalars& sc, const u32* tq, const u3
         const u32 m2 = signed16_of(neg, sc.rho_word(top >> 3), top & 7);
         ge_add_pe_row<false>(S, tr + m2 * ROW_WORDS, neg);
     }
-    // sigma's 8-fold columns ride on the last 32 doublings (the reference's own trick, ed25519_verify.c:266-279)
+    // sigma's comb columns ride on the last SC_COLS doublings (the reference's own trick with its 8-fold table,
+    // ed25519_verify.c:266-279): column c is added with c doublings to go
 #pragma unroll 1
     for (int i = top - 1; i >= 0; i--) {
         const u32 tw = sc.tau_word(i >> 3), rw = sc.rho_word(i >> 3);      // in flight under the doublings
@@ -759,24 +818,18 @@ C25519_DEV u32 ge_walk_is_neutral(const WalkScalars& sc, const u32* tq, const u3
         row_fetch(rq, tq + signed16_of(negq, tw, i & 7) * ROW_WORDS);
         row_fetch(rr, tr + signed16_of(negr, rw, i & 7) * ROW_WORDS);
 #endif
-        if (i >= 8) {
+        if (i >= SC_ROUNDS) {
 #pragma unroll 1
             for (int j = 0; j < 3; j++) ge_double<false>(S);
             ge_double<true>(S);
         } else {
-            u32 cols = sc.sigma_word(7 - i);
+            u64 cols = (u64)sc.sigma_word(2 * i) | ((u64)sc.sigma_word(2 * i + 1) << 32);
 #pragma unroll 1
             for (int j = 0; j < 4; j++) {
-#if C25519_WALK_LDS_PREFETCH
-                ge_pa pa;
-                lds_load_pa(pa, lds_tbl, cols & 255u);               // the LDS row, too, is on its way while S doubles
                 ge_double<true>(S);
-                ge_add_pa_rt(S, pa, j == 3);
-#else
-                ge_double<true>(S);
-                ge_add_pa_lds(S, lds_tbl, cols & 255u, j == 3);      // T feeds the key-table addition that follows the last one
-#endif
-                cols >>= 8;
+                if (4 * i + 3 - j < SC_COLS)                         // wave-uniform: the first round may carry fewer than four
+                    ge_add_pa_comb(S, lds_tbl, (u32)cols & 0xffffu, j == 3);   // T feeds the key-table addition behind the last one
+                cols >>= 16;
             }
         }
 #if C25519_WALK_PREFETCH
@@ -803,9 +856,9 @@ C25519_DEV u32 ge_walk_is_neutral(const WalkScalars& sc, const u32* tq, const u3
 
 // ---- one element, in four steps (four kernels in engine.hip; the CPU tests chain them) --------------------------------------
 // step 1, integers only: h = H(R || pk || m) mod L, the short vector, sigma = rho * s mod L.  rho and tau come back
-// BIASED (bias_signed16) and sigma as its 32 column bytes (sc_fold8_columns), ready for the walk.  Returns all-ones if
+// BIASED (bias_signed16) and sigma as its signed comb columns (sc_comb_columns), ready for the walk.  Returns all-ones if
 // the vector fits the walk.
-C25519_DEV u32 ed_verify_fast_scalars(u32 (&sigma_cols)[8], u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative, const u32 (&pkw)[8],
+C25519_DEV u32 ed_verify_fast_scalars(u32 (&sigma_cols)[SIGMA_WORDS], u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative, const u32 (&pkw)[8],
                                       const u32 (&Rw)[8], const u32 (&Sw)[8], const uint8_t* msg, size_t len)
 {
     u32 h[8], sigma[8];
@@ -821,7 +874,7 @@ C25519_DEV u32 ed_verify_fast_scalars(u32 (&sigma_cols)[8], u32 (&rho)[5], u32 (
     }
     const u32 lat_ok = sc_lattice_short(rho, tau, tau_negative, h);
     sc_mul_short(sigma, rho, Sw);
-    sc_fold8_columns(sigma_cols, sigma);
+    sc_comb_columns(sigma_cols, sigma);
     u32 b[5];
     bias_signed16(b, rho);
 #pragma unroll

@@ -179,8 +179,8 @@ int c25519_amd_fe_selftest(unsigned char *out, const unsigned char *a, const uns
 int c25519_amd_sc_selftest(unsigned char *out, const unsigned char *a, const unsigned char *b, size_t n, int op);
 
 /* fold recodings of n 32-byte scalars (reference ecp_8Folds / ecp_4Folds, source/curve25519_utils.c:144 / :125):
- * out is n x 128 bytes: the 32 8-fold columns as the fixed-base walk indexes them, the same 32 as the verification
- * walk consumes them, and the 64 4-fold columns. */
+ * out is n x 128 bytes: the 32 8-fold columns as the fixed-base walk indexes them, the same 32 as the reference-order
+ * verification walk consumes them, and the 64 4-fold columns. */
 int c25519_amd_fold_selftest(unsigned char *out, const unsigned char *k, size_t n);
 
 #ifdef __cplusplus

@@ -18,14 +18,14 @@ thread_local EmulWave* emul_wave = nullptr;
 
 namespace {
 
-std::vector<u32> g_tbl;                 // [BASE_NT][30][128] signed comb tables, then [30][256] the reference's table:
+std::vector<u32> g_tbl;                 // [BASE_NT][30][128] signed comb tables, [30][256] the reference's table, [30][SC_ROWS] the walk's comb:
                                         // limb-major, as k_gen_base_table lays them out
 std::vector<u32> g_tbl_bytes;           // [256][24]
 std::once_flag g_tbl_once;
 
 void build_tables()
 {
-    g_tbl.assign((size_t)REF_TBL_OFFSET + REF_TBL_WORDS, 0);
+    g_tbl.assign((size_t)ALL_TBL_WORDS, 0);
     g_tbl_bytes.assign(256 * 24, 0);
     for (int group = 0; group < BASE_NT; group++)
         for (u32 idx = 0; idx < (u32)BASE_ROWS; idx++) {
@@ -37,6 +37,15 @@ void build_tables()
                 for (int l = 0; l < 10; l++) g_tbl[(size_t)group * BASE_TBL_WORDS + (10 * f + l) * BASE_ROWS + idx] = c.v[l];
             }
         }
+    for (u32 idx = 0; idx < (u32)SC_ROWS; idx++) {          // the lattice walk's signed comb
+        u32 rows[3][8];
+        ge_signed_comb_row(rows, idx, 0, SC_TEETH, SC_COLS);
+        for (int f = 0; f < 3; f++) {
+            fe c;
+            fe_from_words(c, rows[f]);
+            for (int l = 0; l < 10; l++) g_tbl[(size_t)SC_TBL_OFFSET + (10 * f + l) * SC_ROWS + idx] = c.v[l];
+        }
+    }
     for (u32 k = 0; k < 256; k++) {
         u32 rows[3][8];
         ge_base_table_row(rows, k, 0);
@@ -246,10 +255,10 @@ void emul_ed25519_verify_slow(int* verdict, unsigned char* point, const unsigned
 void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char* sig, const unsigned char* pk,
                               const unsigned char* msg, size_t len, size_t n)
 {
-    const u32* tbl = tables() + (size_t)REF_TBL_OFFSET;
+    const u32* tbl = tables() + (size_t)SC_TBL_OFFSET;
     std::vector<u32> q(2 * WTABLE_WORDS);
     for (size_t i = 0; i < n; i++) {
-        u32 pkw[8], Rw[8], Sw[8], cols[8], rho[5], tau[5], tau_neg;
+        u32 pkw[8], Rw[8], Sw[8], cols[SIGMA_WORDS], rho[5], tau[5], tau_neg;
         rd32(pkw, pk, i);
         rd32(Rw, sig, 2 * i);
         rd32(Sw, sig, 2 * i + 1);
@@ -269,6 +278,18 @@ void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char*
         const WalkScalars sc{ cols, tau, rho, 1, 0 };
         const u32 neutral = ge_walk_is_neutral(sc, tq, tr, tbl, top < 8 ? 8 : top);
         verdict[i] = (r_ok && neutral) ? 1 : 0;
+    }
+}
+
+// sc_comb_columns: sigma (n x 32 bytes, < L) -> SIGMA_WORDS words of 16-bit columns in walk order; dims = {teeth, columns}
+void emul_comb_columns(unsigned* words_out, int* dims, const unsigned char* sigma, size_t n)
+{
+    dims[0] = SC_TEETH; dims[1] = SC_COLS; dims[2] = SIGMA_WORDS;
+    for (size_t i = 0; i < n; i++) {
+        u32 k[8], cols[SIGMA_WORDS];
+        rd32(k, sigma, i);
+        sc_comb_columns(cols, k);
+        for (int w = 0; w < SIGMA_WORDS; w++) words_out[(size_t)SIGMA_WORDS * i + w] = cols[w];
     }
 }
 

@@ -99,6 +99,38 @@ def test_packed_table_rows_keep_the_value(emul):
         assert all(int(back[i][j]) < (1 << W[j]) + (1 << 17) for j in range(10)), (i, list(back[i]))
 
 
+def test_sigma_comb_columns_recompose_to_sigma(emul):
+    """sc_comb_columns (verify_fast.cuh): the 16-bit columns the walk reads, taken apart the way ge_add_pa_comb reads them
+    (top tooth = sign, the others the row index, complemented for a negative column; row idx stands for
+    2^(S(T-1)) + sum of +-2^(S j)), recompose to sigma mod L -- for even and odd sigma, 0, 1, L - 1 and random values."""
+    L = vectors.L
+    sig = [0, 1, 2, L - 1, L - 2, 2**252, 2**252 - 1, (1 << 252) + 1] + \
+          [int.from_bytes(synth.random_bytes((1, 32), 0xc0b + i)[0].tobytes(), "little") % L for i in range(56)]
+    n = len(sig)
+    k = np.stack([vectors.le(x, 32) for x in sig])
+    dims = np.zeros(3, np.int32)
+    out = np.zeros((n, 32), np.uint32)
+    emul.emul_comb_columns(C.c_void_p(out.ctypes.data), C.c_void_p(dims.ctypes.data), C.c_void_p(k.ctypes.data), C.c_size_t(n))
+    teeth, ncols, words = (int(x) for x in dims)
+    out = out.reshape(-1)[: n * words].reshape(n, words)
+    assert teeth * ncols >= 254 and words == 2 * ((ncols + 3) // 4)
+    for i, x in enumerate(sig):
+        total = 0
+        for r in range(words // 2):
+            halves = [int(out[i][2 * r]) & 0xffff, int(out[i][2 * r]) >> 16, int(out[i][2 * r + 1]) & 0xffff, int(out[i][2 * r + 1]) >> 16]
+            for col, c in zip((4 * r + 3, 4 * r + 2, 4 * r + 1, 4 * r), halves):
+                if col >= ncols:
+                    assert c == 0
+                    continue
+                assert c < (1 << teeth)
+                positive = (c >> (teeth - 1)) & 1
+                idx = (c if positive else ~c) & ((1 << (teeth - 1)) - 1)
+                row = (1 << (ncols * (teeth - 1))) + sum((1 if (idx >> j) & 1 else -1) << (ncols * j) for j in range(teeth - 1))
+                total += (row if positive else -row) << col
+        assert total % L == x % L, (i, x)
+        assert total in (x, x + L)                      # sigma itself when odd, sigma + L when even
+
+
 def test_short_vector_search_in_lock_step_waves(emul):
     """The same search with the elements grouped into waves of 8 and 64 lanes that run in lock-step, __any taken over the
     wave as on the device (tests/host_emul/valu_model.h): lanes that are done idle while others iterate, loops end when

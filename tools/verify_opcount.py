@@ -13,7 +13,7 @@ DBL, DBL_T = 527, 627            # doubling without / with the T product (3 M + 
 ADD_PE, ADD_PE_T = 707, 807      # + a projective precomputed row (7 M / 8 M)
 ADD_PA, ADD_PA_T = 606, 707      # + an affine precomputed row (6 M / 7 M)
 TO_PE = 101                      # extended -> precomputed row (one product by 2d)
-SIGMA = 32 * ADD_PA + 8 * 101    # sigma's 32 columns: affine additions riding on doublings the walk does anyway (+ the T's)
+SIGMA = 26 * ADD_PA + 7 * 101    # sigma's 26 signed-comb columns: affine additions riding on doublings the walk does anyway (+ the T's)
 BITS = 130                       # a typical wave's longest vector (127-131 bits), the walk's starting point
 
 
@@ -76,7 +76,7 @@ def main():
     rows.append((f"JSF over {{Q, R, Q+R, Q-R}}, 64 lanes in lock-step (positions some lane needs: {wave_d:.3f})", BITS + 1, round(wave_d * (BITS + 1)), 0, buildjsf, 640, round(wave_d * (BITS + 1)) * 256))
     print("# Ways to compute  sigma*B + tau*Q + rho*(-R)  for one signature, tau and rho %d bits (a typical wave's start), priced" % BITS)
     print("# with the kernels' own v_mad_u64_u32 counts per operation: doubling %d (%d with T), + projective row %d (%d), + affine" % (DBL, DBL_T, ADD_PE, ADD_PE_T))
-    print("# row %d (%d), row conversion %d.  Common to all rows of the table and not listed: sigma's 32 affine additions on" % (ADD_PA, ADD_PA_T, TO_PE))
+    print("# row %d (%d), row conversion %d.  Common to all rows of the table and not listed: sigma's 26 affine additions on" % (ADD_PA, ADD_PA_T, TO_PE))
     print("# the LDS comb table (%d), the two square roots (2 x 16 900), the scalar kernel.  tools/verify_opcount.py" % SIGMA)
     print(f"{'walk of tau*Q + rho*(-R)':88s} {'dbl':>4s} {'add':>4s} {'walk MADs':>10s} {'tables':>7s} {'total':>8s} {'vs shipped':>10s} {'B written':>9s} {'B read':>7s}")
     base = None
