@@ -86,20 +86,24 @@ struct ThreadState {
     size_t dcap[SETS][SLOTS] = {};
     void* hbuf[SETS][SLOTS] = {};          // pinned host staging (hipHostMalloc)
     size_t hcap[SETS][SLOTS] = {};
-    // work scratch of the *_dev entry points: one grow-only slab PER DEVICE (a thread may drive several GPUs, see
-    // multi_device.hip); consecutive calls reuse it in stream order, a call on another stream first waits for the
-    // previous use
+    // work scratch of the *_dev entry points: grow-only slabs, CALLER_SLABS PER DEVICE (a thread may drive several GPUs, see
+    // multi_device.hip).  Consecutive calls on one stream reuse one slab in stream order; calls on up to CALLER_SLABS
+    // different streams get a slab each and may overlap on the device (a caller that splits a mixed batch over streams
+    // fills one operation's last, partly empty wave of workgroups with the next operation's); a further stream takes the
+    // least recently used slab and first waits for its previous use.
     static constexpr int MAX_DEV = 64;
+    static constexpr int CALLER_SLABS = 4;
     struct WorkSlab {
         void* ptr = nullptr;
         size_t cap = 0;
         hipEvent_t done = nullptr;
         hipStream_t last = nullptr;
         bool used = false;
+        unsigned long stamp = 0;           // when it was last handed out (LRU)
+        unsigned* report = nullptr;        // a device word that outlives a call's scratch (a counter the call reports afterwards)
     };
-    WorkSlab work[MAX_DEV];
-    // per device: one device word that outlives a call's scratch (a counter the call reports afterwards)
-    unsigned* report_word[MAX_DEV] = {};
+    WorkSlab work[MAX_DEV][CALLER_SLABS];
+    unsigned long work_clock = 0;
     WorkSlab lane_work[LANES];             // ... and one per pipeline lane, so that the pieces of a *_batch call do not
                                            // wait for each other's kernels (they belong to the staging device)
 
@@ -108,12 +112,21 @@ struct ThreadState {
         if (s && dev == device)
             for (int l = 0; l < LANES; l++)
                 if (s == stream[l]) return &lane_work[l];
-        return &work[dev];
+        WorkSlab* row = work[dev];
+        for (int k = 0; k < CALLER_SLABS; k++)
+            if (row[k].used && row[k].last == s) return &row[k];
+        WorkSlab* pick = &row[0];
+        for (int k = 0; k < CALLER_SLABS; k++) {
+            if (!row[k].used) return &row[k];
+            if (row[k].stamp < pick->stamp) pick = &row[k];
+        }
+        return pick;
     }
     static void free_slab(WorkSlab& w)     // on the slab's device, after a synchronize
     {
         if (w.ptr) { (void)hipMemset(w.ptr, 0, w.cap); (void)hipFree(w.ptr); }
         if (w.done) (void)hipEventDestroy(w.done);
+        if (w.report) (void)hipFree(w.report);
         w = WorkSlab();
     }
 
@@ -184,20 +197,22 @@ struct ThreadState {
         }
         if (!w.done) C25519_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
         if (w.used && s != w.last) C25519_TRY(hipStreamWaitEvent(s, w.done, 0));
+        w.last = s; w.used = true; w.stamp = ++work_clock;       // the slab is this stream's until release_work
         *out = w.ptr;
         return 0;
     }
-    int report_word_for_current_device(unsigned** out)
+    // the report word of the slab acquire_work(…, s) handed out (call between acquire_work and release_work)
+    int report_word_for(unsigned** out, hipStream_t s)
     {
         int dev = 0;
         C25519_TRY(hipGetDevice(&dev));
         if (dev < 0 || dev >= MAX_DEV) return bad_arg("device ordinal out of range");
-        arm_exit_guard();
-        if (!report_word[dev]) {
-            C25519_TRY(hipMalloc(&report_word[dev], 256));
-            C25519_TRY(hipMemset(report_word[dev], 0, 256));
+        WorkSlab& w = *slab_for(s, dev);
+        if (!w.report) {
+            C25519_TRY(hipMalloc(&w.report, 256));
+            C25519_TRY(hipMemset(w.report, 0, 256));
         }
-        *out = report_word[dev];
+        *out = w.report;
         return 0;
     }
     int release_work(hipStream_t s)
@@ -206,7 +221,6 @@ struct ThreadState {
         C25519_TRY(hipGetDevice(&dev));
         WorkSlab& w = *slab_for(s, dev);
         C25519_TRY(hipEventRecord(w.done, s));
-        w.last = s; w.used = true;
         return 0;
     }
     // free the staging side on its device (the buffers held staged secrets: they are zeroed first)
@@ -244,13 +258,12 @@ struct ThreadState {
         int cur = -1;
         (void)hipGetDevice(&cur);
         for (int d = 0; d < MAX_DEV; d++) {
-            WorkSlab& w = work[d];
-            if (!w.ptr && !w.done && !report_word[d]) continue;
+            bool any = false;
+            for (const WorkSlab& w : work[d]) any = any || w.ptr || w.done || w.report;
+            if (!any) continue;
             (void)hipSetDevice(d);
             (void)hipDeviceSynchronize();
-            free_slab(w);
-            if (report_word[d]) (void)hipFree(report_word[d]);
-            report_word[d] = nullptr;
+            for (WorkSlab& w : work[d]) free_slab(w);
         }
         (void)hipGetLastError();
         if (cur >= 0) (void)hipSetDevice(cur);

@@ -861,7 +861,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
     const unsigned grid = grid_for(n, ED_BLOCK);
     if (fast) {
         unsigned* report = nullptr;
-        C25519_RC(tls().report_word_for_current_device(&report));
+        C25519_RC(tls().report_word_for(&report, stream));
         FastScratch fs;
         fs.tables = tables;
         fs.sigma = tables + n * VERIFY_TABLE_WORDS + proj_words(n);

@@ -34,7 +34,10 @@ const char *c25519_amd_version(void);
 const char *c25519_amd_last_error(void);               /* per-thread, "" when none */
 int  c25519_amd_device_count(void);                    /* usable HIP devices (0 when none) */
 int  c25519_amd_set_device(int device);                /* device used by this host thread */
-/* Each host thread that calls into the library owns four streams, eight sets of pinned + device staging buffers and work
+/* *_dev calls a thread issues on different streams may overlap on the device: each stream gets its own work scratch (up
+ * to four per device; a further stream reuses the least recently used one after waiting for it).  Splitting a mixed batch
+ * over streams is worth ~13 % (one operation's last round of workgroups fills up with the next operation's).
+ * Each host thread that calls into the library owns four streams, eight sets of pinned + device staging buffers and work
  * scratch slabs, all on the device that was current at its first call (they follow the thread to another device on
  * the next call, released on the old one first).  They are freed when the thread exits; a long-lived thread can
  * give them back earlier with this call.  Staging buffers are zeroed before they are freed. */

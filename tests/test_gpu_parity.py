@@ -313,6 +313,49 @@ def test_device_pointer_entry_points(api, oracle):
         api.curve25519_dh_CreateSharedKey_dev(out[: n - 1], out.view(-1)[1:32 * (n - 1) + 1].view(n - 1, 32), sk[: n - 1])
 
 
+def test_operations_on_several_streams_overlap_safely(api, oracle):
+    """A thread that issues X25519, signing and verification on different streams gets a work-scratch slab per stream
+    (up to four per device; a fifth stream reuses the least recently used one behind an event): the calls may overlap on
+    the device and every result equals the one-stream result.  Six streams, three rounds, two sizes per operation, so
+    slabs are shared, regrown and handed from stream to stream while kernels are in flight."""
+    import torch
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    n = 40000
+    sk_np, pk_np = synth.x25519_inputs(n)
+    esk, msg = synth.ed25519_inputs(n)
+    e_shared, _ = oracle.x25519_shared(pk_np, sk_np, threads=THREADS)
+    pub_np, priv_np = api.ed25519_CreateKeyPair(esk)
+    sig_np = api.ed25519_SignMessage(priv_np, msg)
+    bsig, bmsg, bad = synth.corrupt_for_verify(sig_np, msg)
+    pub_np = pub_np.copy()
+    pub_np[5::1000] = synth.random_bytes((len(pub_np[5::1000]), 32), 0x51de)      # garbage keys: the slow list, per stream
+    e_ok = oracle.ed25519_verify(bsig, pub_np, bmsg, threads=THREADS)
+    d = dict(sk=up(sk_np), pk=up(pk_np), priv=up(priv_np), msg=up(msg), bsig=up(bsig), pub=up(pub_np), bmsg=up(bmsg))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev) for _ in range(6)]
+    results = []
+    for rnd in range(3):
+        for j, st in enumerate(streams):
+            m = n if (j + rnd) & 1 else n // 3                       # different sizes: slabs of different capacity
+            with torch.cuda.stream(st):
+                kind = (j + rnd) % 3
+                if kind == 0:
+                    out = torch.empty((m, 32), dtype=torch.uint8, device=dev)
+                    api.curve25519_dh_CreateSharedKey_dev(out, d["pk"][:m], d["sk"][:m].clone())
+                elif kind == 1:
+                    out = torch.empty((m, 64), dtype=torch.uint8, device=dev)
+                    api.ed25519_SignMessage_dev(out, d["priv"][:m], d["msg"][:m])
+                else:
+                    out = torch.empty((m, 1), dtype=torch.int32, device=dev)
+                    api.ed25519_VerifySignature_dev(out, d["bsig"][:m], d["pub"][:m], d["bmsg"][:m])
+                results.append((kind, m, out))
+    torch.cuda.synchronize()
+    for kind, m, out in results:
+        want = (e_shared, sig_np, np.asarray(e_ok).reshape(-1, 1))[kind][:m]
+        assert np.array_equal(out.cpu().numpy().reshape(want.shape), want), (kind, m)
+
+
 def test_two_phase_verification(api, oracle):
     """ed25519_Verify_Init once per key, many ed25519_Verify_Check (reference ed25519_verify.c:282-286):
     same verdicts as the one-shot path and as the oracle; the context has the reference's 2080-byte shape."""
