@@ -41,6 +41,9 @@ constexpr int LAT_CAP_BITS = 158;          // what the 40-digit signed walk can 
 #endif
 constexpr int LAT_LEHMER_STOP = 128;        // Lehmer steps bring the smaller remainder down to this many bits; the
                                             // exact steps (ten times dearer per bit) only finish: 128 / 129 bits
+#ifndef C25519_LAT_BALANCED_STOP
+#define C25519_LAT_BALANCED_STOP 1          // A/B switch: 0 = round 2's stopping rule (both remainders down to 128 / 129 bits)
+#endif
 constexpr int LAT_R = 8, LAT_T = 6;        // words of a remainder (unsigned) / of a cofactor (two's complement)
 
 template <int W>
@@ -275,7 +278,7 @@ C25519_DEV u32 sc_lattice_short(u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative,
         }
     }
     // phase 2: exact steps.  A step subtracts the (shifted) smaller vector from the larger one; it is wanted while the
-    // smaller remainder still has more than 128 bits, or it does not but the larger one has more than 129.
+    // smaller remainder still has more than 128 bits, and after that only where it improves the vector that will be used.
     bool stopped = false;
 #pragma unroll 1
     for (int guard = 0; guard < 400; guard++) {
@@ -288,8 +291,25 @@ C25519_DEV u32 sc_lattice_short(u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative,
         u32 mag[LAT_T];
 #pragma unroll
         for (int i = 0; i < LAT_T; i++) mag[i] = (c ? t1[i] : t0[i]) ^ (0u - ((c ? t1[LAT_T - 1] : t0[LAT_T - 1]) >> 31));
-        const bool room = bitlen_words<LAT_T>(mag) + k0 <= 32 * LAT_T - 3;
+        const int lt_small = bitlen_words<LAT_T>(mag);
+        const bool room = lt_small + k0 <= 32 * LAT_T - 3;
+#if C25519_LAT_BALANCED_STOP
+        // The first vector whose remainder is below 2^128 has a cofactor below N / 2^128 = 2^127.5 (|T_(i+1)| r_i < N):
+        // when that cofactor is odd it is the answer and nothing is left to do.  When it is even, the other vector (odd
+        // cofactor) is the answer, and a step on it -- remainder one bit shorter, cofactor up to |T_small| << k -- is wanted
+        // only while it shortens the longer of the two: the remainder is the longer one and the new cofactor stays below it.
+        // (Round 2's rule ran both remainders down to 128 / 129 bits whatever that did to the cofactor: vectors of up to
+        // 139 bits, every second wave starting its walk a digit higher, and four exact steps per wave instead of two.)
+        u32 magb[LAT_T];
+#pragma unroll
+        for (int i = 0; i < LAT_T; i++) magb[i] = (c ? t0[i] : t1[i]) ^ (0u - ((c ? t0[LAT_T - 1] : t1[LAT_T - 1]) >> 31));
+        const int lt_big = bitlen_words<LAT_T>(magb);
+        const bool small_even = ((c ? t1[0] : t0[0]) & 1u) == 0;
+        const bool improve_big = small_even && lbig > lt_big && lt_small + k0 < lbig;
+        const bool want = sane && !stopped && room && lsmall != 0 && (lsmall > 128 || improve_big);
+#else
         const bool want = sane && !stopped && room && lsmall != 0 && (lsmall > 128 || lbig > 129);
+#endif
         stopped = stopped || (sane && !room);
         if (!__any(want)) break;
         C25519_LAT_COUNT(exact_steps);

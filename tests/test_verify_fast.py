@@ -57,6 +57,21 @@ def test_short_vector_properties(emul):
         assert r % 2 == 1 and 0 < r < 2**158 and abs(t) < 2**158, (x, r, t)
         assert (r * x - t) % vectors.N8L == 0, (x, r, t)                 # tau = rho * h modulo 8L, not just L
     assert fits[12:6012].all(), "a random h practically always has a short vector that fits the walk"
+    # ... and the vector that comes back is as short as an odd-rho vector of this lattice gets: within a bit of the best
+    # convergent (r_i, T_i) of h / 8L with an odd T_i in the longer-component norm.  (The walk starts at the wave's longest
+    # vector's top digit: round 2's stopping rule returned vectors of up to 139 bits where 131 were available.)
+    worst = 0
+    for i in range(12, 6012):
+        a, b, ta, tb, best = vectors.N8L, hs[i], 0, 1, 999
+        while b:
+            if tb & 1:
+                best = min(best, max(b.bit_length(), abs(tb).bit_length()))
+            q = a // b
+            a, b, ta, tb = b, a - q * b, tb, ta - q * tb
+        mine = max(int.from_bytes(rho[i].tobytes(), "little").bit_length(), int.from_bytes(tau[i].tobytes(), "little").bit_length())
+        assert mine <= best + 1, (hs[i], mine, best)
+        worst = max(worst, mine)
+    assert worst <= 136, worst
     # h = L-1, L-2, (L-1)/2 are close to -1, -2, -1/2 modulo L but not modulo 8L: their only short vectors have an even
     # rho, so they (correctly) do not fit and go to the reference-order path; the other hand-picked values do
     assert [int(f) for f in fits[:12]] == [1, 1, 1, 1, 0, 0, 1, 1, 1, 1, 0, 1]
