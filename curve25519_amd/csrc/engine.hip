@@ -78,12 +78,17 @@ C25519_DEV u32 fe_zero_to_one(fe& z)
     return is_zero;
 }
 
-template <bool BASE9>
-__global__ void __launch_bounds__(XF_BLOCK, C25519_XF_WAVES) k_x25519_fused(void* out, const void* pk, void* sk, size_t n)
+// BLOCK lanes per workgroup = 64 x the elements per inverting lane.  XF_BLOCK (512) is the throughput shape; a batch that
+// does not fill the chip with it runs narrower workgroups (x25519_block_for): 2^14 elements are 32 workgroups of 512 -- 32
+// of 256 CUs, two waves per SIMD -- but 256 of 64, one wave on a SIMD of its own, which finishes in little more than half
+// the time; the price, an inversion per 1 / 2 / 4 elements instead of 8, is 2-8 % more instructions.
+template <bool BASE9, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1) k_x25519_fused(void* out, const void* pk, void* sk, size_t n)
 {
+    constexpr int XF_BLOCK = BLOCK, XF_K = BLOCK / 64;       // (shadow the file-scope pair: the body below is shape-agnostic)
     __shared__ u32 zbuf[10 * XF_BLOCK];      // PZ, later 1/PZ
     __shared__ u32 xbuf[10 * XF_BLOCK];      // PX
-    __shared__ u32 pbuf[(XF_K - 1) * 10 * 64];   // prefix products of the inverting wave
+    __shared__ u32 pbuf[(XF_K > 1 ? XF_K - 1 : 1) * 10 * 64];   // prefix products of the inverting wave
     const int tid = threadIdx.x;
     const size_t i = (size_t)blockIdx.x * XF_BLOCK + tid;
     const bool active = i < n;
@@ -217,6 +222,10 @@ __global__ void __launch_bounds__(BASE_ROWS) k_gen_base_table(u32* tbl_limbs /*[
 #endif
 constexpr int ED_BLOCK = C25519_ED_BLOCK;
 constexpr int BM_BLOCK = 1024;            // fixed-base kernels: one 120 KiB set of signed comb tables per 16 waves (4 per SIMD)
+// ... for batches that fill the chip.  The tables allow one workgroup per CU whatever its size, so a small batch runs
+// narrower workgroups on more CUs: 2^14 elements are 16 workgroups of 1024 (16 CUs, four waves per SIMD) or 64 of 256 (one
+// wave per SIMD), which come back sooner (profiles/r03_batch_sweep.txt).
+inline unsigned bm_block_for(size_t n) { return n <= ((size_t)1 << 16) ? 256u : n <= ((size_t)1 << 17) ? 512u : (unsigned)BM_BLOCK; }
 
 C25519_DEV void store_proj(const ProjScratch& scr, size_t n, size_t i, const ge_ext& S)
 {
@@ -246,7 +255,7 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_keypair_mult(ProjScratc
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
     lds_stage_words(lds_tbl, g_tbl, BASE_NT * BASE_TBL_WORDS);
-    const size_t i = (size_t)blockIdx.x * BM_BLOCK + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 seed[8], a[8];
     u64 b_words[4];
@@ -265,7 +274,7 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_x25519_public_fast_mult(ProjScr
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
     lds_stage_words(lds_tbl, g_tbl, BASE_NT * BASE_TBL_WORDS);
-    const size_t i = (size_t)blockIdx.x * BM_BLOCK + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 k[8];
     load32(k, sk, i);
@@ -290,7 +299,7 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_sign_mult(ProjScratch s
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
     lds_stage_words(lds_tbl, g_tbl, BASE_NT * BASE_TBL_WORDS);
-    const size_t i = (size_t)blockIdx.x * BM_BLOCK + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 seed[8], a[8], r[8];
     load32(seed, priv, 2 * i);
@@ -892,6 +901,23 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
     return tls().release_work(stream);
 }
 
+// lanes per X25519 workgroup for a batch of n: the widest shape that still puts a wave on every SIMD the batch can reach
+// (256 CUs x 4 SIMDs; 2^16 elements are 1024 waves).  profiles/r03_batch_sweep.txt has both shapes side by side.
+int x25519_block_for(size_t n)
+{
+    if (n <= ((size_t)1 << 16)) return 64;
+    if (n <= ((size_t)1 << 17)) return 128;
+    if (n <= ((size_t)1 << 18)) return 256;
+    return XF_BLOCK;
+}
+
+template <int BLOCK>
+void x25519_launch(void* out, const void* pk, void* sk, size_t n, hipStream_t stream)
+{
+    if (pk) k_x25519_fused<false, BLOCK><<<grid_for(n, BLOCK), BLOCK, 0, stream>>>(out, pk, sk, n);
+    else    k_x25519_fused<true, BLOCK><<<grid_for(n, BLOCK), BLOCK, 0, stream>>>(out, pk, sk, n);
+}
+
 }  // namespace
 
 extern "C" {
@@ -936,8 +962,12 @@ void c25519_amd_thread_release(void) { tls().release(); }
 
 static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t stream)
 {
-    if (pk) k_x25519_fused<false><<<grid_for(n, XF_BLOCK), XF_BLOCK, 0, stream>>>(out, pk, sk, n);
-    else    k_x25519_fused<true><<<grid_for(n, XF_BLOCK), XF_BLOCK, 0, stream>>>(out, pk, sk, n);
+    switch (x25519_block_for(n)) {
+    case 64:  x25519_launch<64>(out, pk, sk, n, stream); break;
+    case 128: x25519_launch<128>(out, pk, sk, n, stream); break;
+    case 256: x25519_launch<256>(out, pk, sk, n, stream); break;
+    default:  x25519_launch<XF_BLOCK>(out, pk, sk, n, stream); break;
+    }
     C25519_TRY(hipGetLastError());
     return 0;
 }
@@ -969,7 +999,7 @@ int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void
     void* w = nullptr;
     C25519_RC(tls().acquire_work(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
-    k_x25519_public_fast_mult<<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, sk, n, tbl);
+    k_x25519_public_fast_mult<<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, sk, n, tbl);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishX25519{ scr.a, pk, n }, stream));
     return tls().release_work(stream);
@@ -986,9 +1016,9 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
     C25519_RC(tls().acquire_work(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     if (blinding)
-        k_ed25519_keypair_mult<true><<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, priv, sk, n, tbl, (const u32*)blinding);
+        k_ed25519_keypair_mult<true><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, priv, sk, n, tbl, (const u32*)blinding);
     else
-        k_ed25519_keypair_mult<false><<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, priv, sk, n, tbl, nullptr);
+        k_ed25519_keypair_mult<false><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, priv, sk, n, tbl, nullptr);
     C25519_TRY(hipGetLastError());
     // pub[e] and priv[e][32..63] <- enc(A)
     C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, pub, n, 1, 0, priv, 2, 1 }, stream));
@@ -1019,10 +1049,10 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
     u32* a_buf = (u32*)w + proj_words(n);
     u32* r_buf = a_buf + sc_words;
     if (blinding)
-        k_ed25519_sign_mult<true><<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl,
+        k_ed25519_sign_mult<true><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl,
                                                                                (const u32*)blinding);
     else
-        k_ed25519_sign_mult<false><<<grid_for(n, BM_BLOCK), BM_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl,
+        k_ed25519_sign_mult<false><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl,
                                                                                 nullptr);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, sig, n, 2, 0, nullptr, 0, 0 }, stream));   // sig[e][0..31] = enc(R)

@@ -22,7 +22,9 @@ def usage():
 
 # kernel (demangled prefix) -> the most registers it may allocate per lane (VGPR + AGPR): what its occupancy target allows
 HOT = {
-    "k_x25519_fused<false>": 128, "k_x25519_fused<true>": 128,
+    "k_x25519_fused<false, 512>": 128, "k_x25519_fused<true, 512>": 128,
+    "k_x25519_fused<false, 256>": 128, "k_x25519_fused<false, 128>": 128, "k_x25519_fused<false, 64>": 128,   # small batches
+    "k_x25519_fused<true, 256>": 128, "k_x25519_fused<true, 128>": 128, "k_x25519_fused<true, 64>": 128,
     "k_ed25519_verify_fast_scalars": 128, "k_ed25519_verify_fast_points": 168, "k_ed25519_verify_fast_walk": 256,
     "k_ed25519_verify_slow": 256,
     "k_ed25519_sign_mult<false>": 128, "k_ed25519_sign_mult<true>": 128,
@@ -42,6 +44,7 @@ def test_no_kernel_of_a_hot_pass_touches_scratch(usage):
         assert k.get("scratch", 0) == 0, f"{name}: {k.get('scratch')} bytes of scratch per lane ({k.get('vgpr_spill')} VGPRs spilled)"
         if name in HOT:
             assert k["vgpr"] + k.get("agpr", 0) <= HOT[name], f"{name}: {k['vgpr']} + {k.get('agpr', 0)} registers, budget {HOT[name]}"
+    assert set(HOT) <= set(usage), sorted(set(HOT) - set(usage))
     assert seen >= len(HOT) + 15                  # every listed kernel and the inversion's instantiations were found
 
 

@@ -64,7 +64,7 @@ print("# Issue classes as measured by tools/ubench/mad_peak (profiles/r03_mad_pe
 print("# per SIMD, the other VOP3 / 64-bit / multiply instructions (\"half-rate\") 4, VOP2 adds / ands / subs / moves (\"full-rate\") 2.")
 print("# mad_cycle_share = 4*mad / (4*mad + 4*half + 2*full): the most a VALU-bound kernel can reach of the v_mad_u64_u32 roof")
 print("# with this instruction stream; the kernels are VALU-bound (valu_busy 0.96-1.00, r03_pmc.txt).\n")
-show("X25519 ladder step (5 M + 4 S + a24 + 8 add/sub + select): one trip = one scalar bit", "k_x25519_fusedILb0", lambda m: 1200 < m['n'] < 1400)
+show("X25519 ladder step (5 M + 4 S + a24 + 8 add/sub + select): one trip = one scalar bit", "k_x25519_fusedILb0ELi512", lambda m: 1200 < m['n'] < 1400)
 show("verification walk: digit rounds (the biggest loop is one round: 4 doublings or 4 x (doubling + LDS-row addition), then two table-row "
      "additions from prefetched packed rows; inside it the 3-doubling loop and the 4-step sigma loop)", "k_ed25519_verify_fast_walk", lambda m: m['n'] > 800)
 show("verification points kernel: the squaring loops of the square root (99-101 instructions per squaring) and the table-build loop",
