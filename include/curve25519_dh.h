@@ -11,11 +11,11 @@
  *     MI355X (gfx950) through HIP and ABORTS the process with a message on stderr if no usable
  *     device is present -- it never falls back to a CPU implementation.
  *
- * A single call is executed as a device batch of one: a whole kernel pass for one lane, about 1.2 ms
+ * A single call is executed as a device batch of one: a whole kernel pass for one lane, about 0.75 ms
  * (profiles/r03_batch_sweep.txt) against 93 us for the reference on one host core -- the literal drop-in call is
- * correct, not fast.  Throughput comes from the batch entry points in curve25519_amd.h: a call of ~16 operations
- * already beats one host core, ~250 beat sixteen cores, and the quoted rates need 2^17 and more per call
- * (2^16: 54 M/s, 2^17: 99 M/s, 2^20: 122 M/s).
+ * correct, not fast.  Throughput comes from the batch entry points in curve25519_amd.h: a call of ~10 operations
+ * already beats one host core, ~130 beat sixteen cores; batches that do not fill the chip run in narrower workgroups
+ * (2^14 per call: 25 M/s, 2^16: 90 M/s), and the quoted rates need 2^17 and more per call (2^17: 99 M/s, 2^20: 122 M/s).
  */
 #ifndef CURVE25519_AMD_DH_H
 #define CURVE25519_AMD_DH_H

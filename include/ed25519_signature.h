@@ -16,10 +16,11 @@
  * byte-identical with and without a context.
  *
  * Cost of ONE call: these are the reference's single-operation prototypes, and each call runs as a device
- * batch of one -- a whole kernel pass for one lane, about 0.4 ms per signature, 0.7 ms per verification,
- * 1.2 ms per X25519 (profiles/r03_batch_sweep.txt), i.e. SLOWER than the reference on one host core (43 us,
+ * batch of one -- a whole kernel pass for one lane, about 0.2 ms per signature, 0.7 ms per verification,
+ * 0.75 ms per X25519 (profiles/r03_batch_sweep.txt), i.e. SLOWER than the reference on one host core (43 us,
  * 190 us and 93 us there).  The device pays off through the *_batch / *_dev forms in curve25519_amd.h: from
- * about 16 operations per call a batch beats one host core, from a few hundred it beats sixteen, and the
+ * about 10 operations per call a batch beats one host core, from a hundred or two it beats sixteen (small
+ * batches run in narrower workgroups on more CUs: 2^14 signatures per call are 93 M/s, 2^16 330 M/s), and the
  * quoted throughput needs 2^17 and more per call.
  */
 #ifndef CURVE25519_AMD_ED25519_SIGNATURE_H
