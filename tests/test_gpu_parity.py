@@ -267,6 +267,38 @@ def test_full_size_properties(api):
     assert not api.ed25519_VerifySignature(sig, np.roll(pub, 1, axis=0), msg).any(), "wrong key rejects"
 
 
+@pytest.mark.parametrize("n", [65535, 65536, 65537, 131072, 131073, 262144, 262145])
+def test_workgroup_shapes_at_their_boundaries(api, oracle, n):
+    """A *_dev call picks its workgroup shape from n (X25519: 64 / 128 / 256 / 512 lanes up to 2^16 / 2^17 / 2^18 / beyond, an
+    inversion per 1 / 2 / 4 / 8 elements; the fixed-base kernels 256 / 512 / 1024 lanes): every shape, at the sizes where
+    it changes and with a ragged last workgroup, gives the reference's bytes."""
+    import torch
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    sk_np = synth.random_bytes((n, 32), 0xD000 + n % 977)
+    pk_np = synth.random_bytes((n, 32), 0xE000 + n % 977)
+    msg_np = synth.random_bytes((n, 20), 0xF000 + n % 977)
+    pk_np[7] = 0                                                      # a low-order point: its Z is 0 in a shared inversion
+    sk, pk, msg = up(sk_np), up(pk_np), up(msg_np)
+    shared = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    skc = sk.clone()
+    api.curve25519_dh_CreateSharedKey_dev(shared, pk, skc)
+    e_shared, e_clamped = oracle.x25519_shared(pk_np, sk_np, threads=THREADS)
+    assert np.array_equal(shared.cpu().numpy(), e_shared) and np.array_equal(skc.cpu().numpy(), e_clamped)
+    pub = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    priv = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    api.ed25519_CreateKeyPair_dev(pub, priv, sk)
+    e_pub, e_priv = oracle.ed25519_keypair(sk_np, threads=THREADS)
+    assert np.array_equal(pub.cpu().numpy(), e_pub) and np.array_equal(priv.cpu().numpy(), e_priv)
+    sig = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    api.ed25519_SignMessage_dev(sig, priv, msg)
+    assert np.array_equal(sig.cpu().numpy(), oracle.ed25519_sign(e_priv, msg_np, threads=THREADS))
+    ok = torch.empty((n, 1), dtype=torch.int32, device=dev)
+    sig[::3, 33] ^= 4
+    api.ed25519_VerifySignature_dev(ok, sig, pub, msg)
+    assert np.array_equal(ok.cpu().numpy().reshape(-1), oracle.ed25519_verify(sig.cpu().numpy(), e_pub, msg_np, threads=THREADS))
+
+
 def test_large_odd_batch(api, oracle):
     """n = 2^22 + 77 (not a multiple of any tile, 4x the benchmark batch): index arithmetic, scratch carving and
     the batched-inversion tail.  Checked by properties plus an oracle spot check of the first / last rows."""
