@@ -21,6 +21,7 @@
 #include "../../include/curve25519_dh.h"
 #include "../../include/ed25519_signature.h"
 
+#include <algorithm>
 #include <condition_variable>
 #include <initializer_list>
 #include <mutex>
@@ -225,7 +226,12 @@ constexpr int BM_BLOCK = 1024;            // fixed-base kernels: one 120 KiB set
 // ... for batches that fill the chip.  The tables allow one workgroup per CU whatever its size, so a small batch runs
 // narrower workgroups on more CUs: 2^14 elements are 16 workgroups of 1024 (16 CUs, four waves per SIMD) or 64 of 256 (one
 // wave per SIMD), which come back sooner (profiles/r03_batch_sweep.txt).
-inline unsigned bm_block_for(size_t n) { return n <= ((size_t)1 << 16) ? 256u : n <= ((size_t)1 << 17) ? 512u : (unsigned)BM_BLOCK; }
+// (a piece of a pipelined *_batch call takes the shape of the whole call: host_pipeline.hpp, batch_shape_hint)
+inline unsigned bm_block_for(size_t n)
+{
+    n = std::max(n, c25519_host::batch_shape_hint());
+    return n <= ((size_t)1 << 16) ? 256u : n <= ((size_t)1 << 17) ? 512u : (unsigned)BM_BLOCK;
+}
 
 C25519_DEV void store_proj(const ProjScratch& scr, size_t n, size_t i, const ge_ext& S)
 {
@@ -905,6 +911,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
 // (256 CUs x 4 SIMDs; 2^16 elements are 1024 waves).  profiles/r03_batch_sweep.txt has both shapes side by side.
 int x25519_block_for(size_t n)
 {
+    n = std::max(n, c25519_host::batch_shape_hint());         // a piece of a pipelined *_batch call: the whole call counts
     if (n <= ((size_t)1 << 16)) return 64;
     if (n <= ((size_t)1 << 17)) return 128;
     if (n <= ((size_t)1 << 18)) return 256;

@@ -26,7 +26,7 @@ inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 //     stage-out : helper threads (2, or 1; C25519_AMD_DRAINERS) wait for the set's event and copies the results out
 // so both CPU copies and both PCIe directions ride under the kernels of the neighbouring pieces.  Pieces are n/8 for
 // big batches: two of them (2^18 lanes) fill every kernel's occupancy, and a piece cannot finish faster than one
-// ladder's latency (~1.2 ms), so fewer, larger pieces in flight beat many small ones.  Eight buffer sets let a 2^20
+// ladder's latency (~0.7-1.2 ms), so fewer, larger pieces in flight beat many small ones.  Eight buffer sets let a 2^20
 // call stage every piece in without waiting for an earlier one to leave; four streams because the runtime drives four
 // hardware queues (timelines and the rejected shapes: profiles/r02_hostapi_trace.txt, rates: profiles/r02_hostapi.txt).
 struct Arr {
@@ -59,11 +59,22 @@ inline bool host_pinned(const void* p, size_t bytes)
     return true;
 }
 
+// The kernels pick a workgroup shape from the element count they are given (narrow workgroups when the batch would not
+// fill the chip, engine.hip).  The pieces of a pipelined call are small only because they are pieces -- their neighbours
+// fill the chip -- so while a call is in the pipeline its TOTAL count decides the shape.
+inline size_t& batch_shape_hint() { thread_local size_t total = 0; return total; }
+struct ShapeHint {
+    size_t saved;
+    explicit ShapeHint(size_t n) : saved(batch_shape_hint()) { batch_shape_hint() = n; }
+    ~ShapeHint() { batch_shape_hint() = saved; }
+};
+
 template <typename Launch>
 int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
 {
     ThreadState& t = tls();
     C25519_RC(t.ensure());
+    const ShapeHint shape_hint(n);
     const Arr* arr = arrays.begin();
     const int na = (int)arrays.size();
     if (na > ThreadState::SLOTS) return bad_arg("internal: too many arrays");
