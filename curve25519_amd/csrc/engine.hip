@@ -51,7 +51,6 @@ struct ProjScratch {            // projective result + prefix products of the ba
 #define C25519_XF_WAVES 4             // waves per SIMD the register allocator aims at (A/B: profiles/r02_ab_occupancy.txt)
 #endif
 constexpr int XF_BLOCK = C25519_XF_BLOCK;     // waves per workgroup = elements per inverting lane
-constexpr int XF_K = XF_BLOCK / 64;
 
 C25519_DEV void lds_put_fe(u32* buf, int stride, int idx, const fe& f)
 {
@@ -86,12 +85,12 @@ C25519_DEV u32 fe_zero_to_one(fe& z)
 template <bool BASE9, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1) k_x25519_fused(void* out, const void* pk, void* sk, size_t n)
 {
-    constexpr int XF_BLOCK = BLOCK, XF_K = BLOCK / 64;       // (shadow the file-scope pair: the body below is shape-agnostic)
-    __shared__ u32 zbuf[10 * XF_BLOCK];      // PZ, later 1/PZ
-    __shared__ u32 xbuf[10 * XF_BLOCK];      // PX
-    __shared__ u32 pbuf[(XF_K > 1 ? XF_K - 1 : 1) * 10 * 64];   // prefix products of the inverting wave
+    constexpr int K = BLOCK / 64;            // elements per lane of the inverting wave
+    __shared__ u32 zbuf[10 * BLOCK];      // PZ, later 1/PZ
+    __shared__ u32 xbuf[10 * BLOCK];      // PX
+    __shared__ u32 pbuf[(K > 1 ? K - 1 : 1) * 10 * 64];   // prefix products of the inverting wave
     const int tid = threadIdx.x;
-    const size_t i = (size_t)blockIdx.x * XF_BLOCK + tid;
+    const size_t i = (size_t)blockIdx.x * BLOCK + tid;
     const bool active = i < n;
     {
         fe PX, PZ;
@@ -106,8 +105,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1
             fe_set_u32(PX, 0);
             fe_set_u32(PZ, 1);
         }
-        lds_put_fe(zbuf, XF_BLOCK, tid, PZ);
-        lds_put_fe(xbuf, XF_BLOCK, tid, PX);
+        lds_put_fe(zbuf, BLOCK, tid, PZ);
+        lds_put_fe(xbuf, BLOCK, tid, PX);
     }
     __syncthreads();
     if (tid < 64) {
@@ -115,23 +114,23 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1
         fe_set_u32(zero, 0);
         u32 zero_mask = 0;
 #pragma unroll 1
-        for (int t = 0; t < XF_K; t++) {
-            lds_get_fe(z, zbuf, XF_BLOCK, tid + 64 * t);
+        for (int t = 0; t < K; t++) {
+            lds_get_fe(z, zbuf, BLOCK, tid + 64 * t);
             zero_mask |= (fe_zero_to_one(z) & 1u) << t;
             if (t == 0) acc = z; else fe_mul(acc, acc, z);
-            if (t < XF_K - 1) lds_put_fe(pbuf + t * 640, 64, tid, acc);
+            if (t < K - 1) lds_put_fe(pbuf + t * 640, 64, tid, acc);
         }
         fe inv;
         fe_invert(inv, acc);
 #pragma unroll 1
-        for (int t = XF_K - 1; t >= 0; t--) {
+        for (int t = K - 1; t >= 0; t--) {
             fe zi;
             const u32 was_zero = ((zero_mask >> t) & 1u) ? 0xffffffffu : 0u;
             if (t > 0) {
                 fe p;
                 lds_get_fe(p, pbuf + (t - 1) * 640, 64, tid);
                 fe_mul(zi, inv, p);
-                lds_get_fe(z, zbuf, XF_BLOCK, tid + 64 * t);
+                lds_get_fe(z, zbuf, BLOCK, tid + 64 * t);
                 fe one;
                 fe_set_u32(one, 1);
                 fe_select(z, was_zero, one, z);
@@ -140,15 +139,15 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1
             } else {
                 fe_select(zi, was_zero, zero, inv);
             }
-            lds_put_fe(zbuf, XF_BLOCK, tid + 64 * t, zi);
+            lds_put_fe(zbuf, BLOCK, tid + 64 * t, zi);
         }
     }
     __syncthreads();
     if (active) {
         fe x, zi;
         u32 w[8];
-        lds_get_fe(x, xbuf, XF_BLOCK, tid);
-        lds_get_fe(zi, zbuf, XF_BLOCK, tid);
+        lds_get_fe(x, xbuf, BLOCK, tid);
+        lds_get_fe(zi, zbuf, BLOCK, tid);
         fe_mul(x, x, zi);
         fe_to_words(w, x);
         store32(out, i, w);                      // written last: `out` may alias `pk`
