@@ -408,7 +408,9 @@ struct FastScratch {
     u32 *tables;            // per lane: window table of +-Q, then of -R (2 x WTABLE_WORDS of packed 128-byte rows, 128-byte aligned)
     u32 *sigma, *rho, *tau, *flags;
     u32 *slow_list;         // indices of the elements the reference-order kernel has to decide ...
-    u32 *slow_count;        // ... and how many
+    u32 *slow_count;        // ... and how many; [1], [2]: how many elements `order` holds from its front / from its back
+    u32 *order;             // the walk's lane j takes element order[j]: elements whose scalars start at digit 32 or below
+                            // from the front, the few longer ones from the back, so that a wave of 64 rarely holds one
     u32 *slow_report;       // a word that outlives the call's scratch: the count again, for c25519_amd_verify_last_slow_elements
 };
 constexpr size_t FAST_TABLE_WORDS = 2 * WTABLE_WORDS;
@@ -421,6 +423,9 @@ constexpr u32 FLAG_R_OK = 1u, FLAG_KEY_OK = 2u, FLAG_FITS = 4u, FLAG_TAU_NEG = 8
 #define C25519_WALK_BLOCK C25519_ED_BLOCK       // lanes per walk workgroup (they share one staged comb table)
 #endif
 constexpr int WALK_BLOCK = C25519_WALK_BLOCK;
+#ifndef C25519_WALK_SORTED
+#define C25519_WALK_SORTED 1         // A/B switch: 0 = the walk's lane j takes element j
+#endif
 #ifndef C25519_VD_WAVES
 #define C25519_VD_WAVES 3            // ... and the point decoding + table kernel
 #endif
@@ -430,7 +435,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_ed25519_verify_fast_scalars(FastSc
                                                                           Msgs msgs, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * FS_BLOCK + threadIdx.x;
-    if (i == 0) *fs.slow_count = 0;
+    if (i == 0) fs.slow_count[0] = fs.slow_count[1] = fs.slow_count[2] = 0;
     if (i >= n) return;
     u32 pkw[8], Rw[8], Sw[8], cols[SIGMA_WORDS], rho[5], tau[5], tau_neg;
     load32(pkw, pk, i);
@@ -460,6 +465,13 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VD_WAVES) k_ed25519_verify_fa
     const u32 tau_neg = (f & FLAG_TAU_NEG) ? 0xffffffffu : 0u;
     fe X, Y;
     const u32 ok = ed_verify_fast_decode(X, Y, w, is_r ? 0xffffffffu : 0u, tau_neg);
+#if C25519_WALK_SORTED
+    if (!is_r) {                                                   // the walk's order (see FastScratch::order)
+        const bool is_long = ((f >> 8) & 63u) > 32u;
+        const u32 pos = is_long ? (u32)n - 1u - atomicAdd(fs.slow_count + 2, 1u) : atomicAdd(fs.slow_count + 1, 1u);
+        fs.order[pos] = (u32)e;
+    }
+#endif
     if (is_r) {
         if (ok) atomicOr(&fs.flags[e], FLAG_R_OK);
     } else if (ok && (f & FLAG_FITS)) {
@@ -487,7 +499,12 @@ __global__ void __launch_bounds__(WALK_BLOCK, C25519_VW_WAVES) k_ed25519_verify_
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[SC_TBL_WORDS];
     lds_stage_words(lds_tbl, g_tbl + SC_TBL_OFFSET, SC_TBL_WORDS);
-    const size_t i = (size_t)blockIdx.x * WALK_BLOCK + threadIdx.x;
+    const size_t lane = (size_t)blockIdx.x * WALK_BLOCK + threadIdx.x;
+#if C25519_WALK_SORTED
+    const size_t i = lane < n ? fs.order[lane] : n;
+#else
+    const size_t i = lane;
+#endif
     const u32 f = i < n ? fs.flags[i] : FLAG_SLOW;
     const bool walks = !(f & FLAG_SLOW);
     // the wave walks from its longest element's first digit (the others' digits above their own are zero)
@@ -850,7 +867,7 @@ int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t 
 // the fast path's scalars, flags and slow list
 constexpr size_t VERIFY_TABLE_WORDS = FAST_TABLE_WORDS > QTABLE_LIMB_WORDS ? FAST_TABLE_WORDS : QTABLE_LIMB_WORDS;
 static_assert(FAST_TABLE_WORDS % 32 == 0 && VERIFY_TABLE_WORDS % 32 == 0, "per-lane tables must keep their rows 128-byte aligned");
-inline size_t verify_scalar_words(size_t n) { return round_up(SIGMA_WORDS * n, 4) + 2 * round_up(5 * n, 4) + 2 * round_up(n, 4) + 4; }
+inline size_t verify_scalar_words(size_t n) { return round_up(SIGMA_WORDS * n, 4) + 2 * round_up(5 * n, 4) + 3 * round_up(n, 4) + 4; }
 inline size_t verify_scratch_bytes(size_t n)
 {
     return (n * VERIFY_TABLE_WORDS + proj_words(n) + verify_scalar_words(n)) * sizeof(u32);
@@ -883,7 +900,8 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
         fs.tau = fs.rho + round_up(5 * n, 4);
         fs.flags = fs.tau + round_up(5 * n, 4);
         fs.slow_list = fs.flags + round_up(n, 4);
-        fs.slow_count = fs.slow_list + round_up(n, 4);
+        fs.order = fs.slow_list + round_up(n, 4);
+        fs.slow_count = fs.order + round_up(n, 4);
         fs.slow_report = report;
         k_ed25519_verify_fast_scalars<<<grid_for(n, FS_BLOCK), FS_BLOCK, 0, stream>>>(fs, sig, pk, msgs, n);
         C25519_TRY(hipGetLastError());
