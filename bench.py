@@ -40,12 +40,12 @@ BYTES_PER_OP = {"x25519": 96, "sign": 160, "verify": 132}
 MACS_PER_OP = {"x25519": 184104, "sign": 52992, "verify": 245664}  # SURVEY.md 8(a), 32x32 MACs at 72/mul
 # what the device actually issues per operation (v_mad_u64_u32 count from the kernels' ISA): the
 # ladder does the reference's work in 100/55-MAD products; sign walks 3 doublings instead of 31; verification of
-# on-curve keys walks ~134 doublings instead of 255.  verify = walk 139 300 (25.2 rounds of 3 723 above digit 7 for the
-# average wave start at digit 32.2, one round with two and six rounds of 6 551 with four of sigma's 26 comb columns, the
+# on-curve keys walks ~134 doublings instead of 255.  verify = walk 138 600 (25.0 rounds of 3 723 above digit 7 for the
+# average wave start at digit 32.0, one round with two and six rounds of 6 551 with four of sigma's 26 comb columns, the
 # first digit's two rows) + two points of
 # 22 900 each (a 258 S + 24 M square root, a window table of 4 doublings, 3 additions, 8 row conversions) + ~2 000 in the
 # scalar kernel (profiles/r03_isa_mix.txt)
-EXECUTED_MACS_PER_OP = {"x25519": 191400, "sign": 25100, "verify": 187100}
+EXECUTED_MACS_PER_OP = {"x25519": 191400, "sign": 25100, "verify": 186400}
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md
 
 PASS_KERNELS = {
