@@ -798,7 +798,7 @@ def test_host_pointer_api_keeps_up_with_the_device_rate(api):
         fn()
         fn()
         ts = []
-        for _ in range(4):
+        for _ in range(10):                    # best of ten: the boxes' host cores are shared with other tenants
             t0 = time.perf_counter()
             fn()
             ts.append(time.perf_counter() - t0)
