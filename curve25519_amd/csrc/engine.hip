@@ -52,6 +52,38 @@ struct ProjScratch {            // projective result + prefix products of the ba
 #endif
 constexpr int XF_BLOCK = C25519_XF_BLOCK;     // waves per workgroup = elements per inverting lane
 
+// Opt-in measurement build (tools/cycle_probe.py; never the product): -DC25519_CYCLE_PROBE=1 makes every wave of
+// k_x25519_fused stamp s_memtime (one tick = one shader cycle) at its phase boundaries -- entry, end of the ladder, behind
+// the first barrier, behind the shared inversion, behind the second barrier, exit -- with the hardware slot it ran on,
+// so that cycles per ladder step, the idle time of a workgroup's waves during the inversion and the clock of an
+// UN-PROFILED run (kernel wall time / cycles) can be read; =2 additionally accumulates the ten sections of a ladder step.
+#ifdef C25519_CYCLE_PROBE
+constexpr int PROBE_WORDS = 20;
+__device__ unsigned long long* g_cycle_probe = nullptr;
+C25519_DEV unsigned long long probe_now()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+struct SectionTimer {
+    unsigned long long *last, *acc;
+    C25519_DEV void operator()(int id) const
+    {
+#if C25519_CYCLE_PROBE >= 2
+        C25519_SCHED_FENCE();
+        const unsigned long long t = probe_now();
+        if (id >= 0) acc[id] += t - *last;
+        *last = t;
+        C25519_SCHED_FENCE();
+#endif
+    }
+};
+#define C25519_PROBE_STAMP(i) do { C25519_SCHED_FENCE(); probe_t[i] = probe_now(); C25519_SCHED_FENCE(); } while (0)
+#else
+#define C25519_PROBE_STAMP(i) do { } while (0)
+#endif
+
 C25519_DEV void lds_put_fe(u32* buf, int stride, int idx, const fe& f)
 {
 #pragma unroll
@@ -92,6 +124,10 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1
     const int tid = threadIdx.x;
     const size_t i = (size_t)blockIdx.x * BLOCK + tid;
     const bool active = i < n;
+#ifdef C25519_CYCLE_PROBE
+    unsigned long long probe_t[6] = {}, probe_sec[10] = {}, probe_last = 0;
+#endif
+    C25519_PROBE_STAMP(0);
     {
         fe PX, PZ;
         if (active) {
@@ -100,15 +136,21 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1
             load32(k, sk, i);
             clamp_words(k);
             store32(sk, i, k);                   // the reference clamps in the caller's buffer
+#ifdef C25519_CYCLE_PROBE
+            x25519_ladder_xz<BASE9>(PX, PZ, u, k, SectionTimer{ &probe_last, probe_sec });
+#else
             x25519_ladder_xz<BASE9>(PX, PZ, u, k);
+#endif
         } else {
             fe_set_u32(PX, 0);
             fe_set_u32(PZ, 1);
         }
+        C25519_PROBE_STAMP(1);
         lds_put_fe(zbuf, BLOCK, tid, PZ);
         lds_put_fe(xbuf, BLOCK, tid, PX);
     }
     __syncthreads();
+    C25519_PROBE_STAMP(2);
     if (tid < 64) {
         fe acc, z, zero;
         fe_set_u32(zero, 0);
@@ -142,7 +184,9 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1
             lds_put_fe(zbuf, BLOCK, tid + 64 * t, zi);
         }
     }
+    C25519_PROBE_STAMP(3);
     __syncthreads();
+    C25519_PROBE_STAMP(4);
     if (active) {
         fe x, zi;
         u32 w[8];
@@ -152,6 +196,51 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1
         fe_to_words(w, x);
         store32(out, i, w);                      // written last: `out` may alias `pk`
     }
+#ifdef C25519_CYCLE_PROBE
+    C25519_PROBE_STAMP(5);
+    if ((tid & 63) == 0 && g_cycle_probe) {
+        unsigned long long* rec = g_cycle_probe + ((size_t)blockIdx.x * (BLOCK / 64) + tid / 64) * PROBE_WORDS;
+        for (int q = 0; q < 6; q++) rec[q] = probe_t[q];
+        // HW_ID (wave / SIMD / CU / SH / SE slot) and XCC_ID of the wave
+        rec[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        for (int q = 0; q < 10; q++) rec[7 + q] = probe_sec[q];
+    }
+#endif
+}
+
+// The ladder alone: (PX : PZ) to the struct-of-arrays scratch, for k_batch_invert<FinishX25519> behind it.  No LDS, no
+// barrier: every wave is on its own, a finished wave's slot goes to the next workgroup at once.  (k_x25519_fused parks
+// seven of a workgroup's eight waves at a barrier while wave 0 inverts -- and as every workgroup of a full launch takes
+// the same time, both workgroups of a CU get there together: tools/cycle_probe.py, profiles/r04_cycle_probe.txt.)
+constexpr int XL_BLOCK = 256;
+template <bool BASE9>
+__global__ void __launch_bounds__(XL_BLOCK, C25519_XF_WAVES) k_x25519_ladder(u32* X, u32* Z, const void* pk, void* sk, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * XL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+#ifdef C25519_CYCLE_PROBE
+    unsigned long long probe_t[6] = {};
+#endif
+    C25519_PROBE_STAMP(0);
+    u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8];
+    if (!BASE9) load32(u, pk, i);
+    load32(k, sk, i);
+    clamp_words(k);
+    store32(sk, i, k);                           // the reference clamps in the caller's buffer
+    fe PX, PZ;
+    x25519_ladder_xz<BASE9>(PX, PZ, u, k);
+    C25519_PROBE_STAMP(1);
+    soa_store_fe(X, n, i, PX);
+    soa_store_fe(Z, n, i, PZ);
+#ifdef C25519_CYCLE_PROBE
+    C25519_PROBE_STAMP(5);
+    if ((threadIdx.x & 63) == 0 && g_cycle_probe) {
+        unsigned long long* rec = g_cycle_probe + (i / 64) * PROBE_WORDS;
+        probe_t[2] = probe_t[3] = probe_t[4] = probe_t[1];
+        for (int q = 0; q < 6; q++) rec[q] = probe_t[q];
+        rec[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -935,6 +1024,14 @@ int x25519_block_for(size_t n)
     return XF_BLOCK;
 }
 
+// a batch that fills the chip runs the ladder and the shared inversion as two launches (k_x25519_ladder's comment);
+// C25519_AMD_XF_SPLIT=0/1 forces either shape (A/B knob, read per call)
+bool x25519_split_for(size_t n)
+{
+    if (const char* e = getenv("C25519_AMD_XF_SPLIT")) return atoi(e) != 0;
+    return std::max(n, c25519_host::batch_shape_hint()) > ((size_t)1 << 18);
+}
+
 template <int BLOCK>
 void x25519_launch(void* out, const void* pk, void* sk, size_t n, hipStream_t stream)
 {
@@ -979,6 +1076,16 @@ int c25519_amd_set_device(int device)
     return 0;
 }
 
+#ifdef C25519_CYCLE_PROBE
+// measurement builds only: where the waves of k_x25519_fused write their stamps (PROBE_WORDS u64 per wave), or null
+int c25519_amd_probe_set(void* buf)
+{
+    C25519_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_cycle_probe), &buf, sizeof buf));
+    return 0;
+}
+int c25519_amd_probe_words(void) { return PROBE_WORDS; }
+#endif
+
 // frees the calling thread's streams, staging buffers (zeroed first) and work scratch
 void c25519_amd_thread_release(void) { tls().release(); }
 
@@ -986,6 +1093,16 @@ void c25519_amd_thread_release(void) { tls().release(); }
 
 static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t stream)
 {
+    if (x25519_split_for(n)) {
+        void* w = nullptr;
+        C25519_RC(tls().acquire_work(&w, proj_words(n) * sizeof(u32), stream));
+        const ProjScratch scr = carve_proj((u32*)w, n);
+        if (pk) k_x25519_ladder<false><<<grid_for(n, XL_BLOCK), XL_BLOCK, 0, stream>>>(scr.a, scr.z, pk, sk, n);
+        else    k_x25519_ladder<true><<<grid_for(n, XL_BLOCK), XL_BLOCK, 0, stream>>>(scr.a, scr.z, pk, sk, n);
+        C25519_TRY(hipGetLastError());
+        C25519_RC(launch_invert(scr, n, FinishX25519{ scr.a, out, n }, stream));
+        return tls().release_work(stream);
+    }
     switch (x25519_block_for(n)) {
     case 64:  x25519_launch<64>(out, pk, sk, n, stream); break;
     case 128: x25519_launch<128>(out, pk, sk, n, stream); break;

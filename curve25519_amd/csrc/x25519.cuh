@@ -34,10 +34,14 @@ C25519_DEV void mont_double(fe& X, fe& Z)
     fe_mul(Z, B, A);
 }
 
+// no-op section marker of the product build; the opt-in cycle-probe build (engine.hip, -DC25519_CYCLE_PROBE=2) passes
+// one that reads s_memtime, so that the sections of a step can be timed in place (tools/cycle_probe.py)
+struct NoSectionMark { C25519_DEV void operator()(int) const {} };
+
 // BASE9: the difference point is the curve's base point u = 9 (curve25519_dh_CalculatePublicKey), so the
 // one multiplication by it is a 10-MAD small-constant multiply instead of a full product.
-template <bool BASE9 = false>
-C25519_DEV void ladder_step(fe& SX, fe& SZ, fe& DX, fe& DZ, const fe& base, u32 prev_eq)
+template <bool BASE9 = false, typename Mark = NoSectionMark>
+C25519_DEV void ladder_step(fe& SX, fe& SZ, fe& DX, fe& DZ, const fe& base, u32 prev_eq, Mark mark = Mark())
 {
     fe A, B, C, Dp, P, M;
     fe_sub(A, SX, SZ);                 // beta 3
@@ -46,29 +50,37 @@ C25519_DEV void ladder_step(fe& SX, fe& SZ, fe& DX, fe& DZ, const fe& base, u32 
     fe_add(Dp, DX, DZ);                // beta 2
     fe_select(P, prev_eq, Dp, B);      // doubling input, x+z
     fe_select(M, prev_eq, C, A);       // doubling input, x-z
-
+    mark(0);
     fe_mul(A, A, Dp);                  // (x1-z1)(x2+z2)
+    mark(1);
     fe_mul(B, C, B);                   // (x2-z2)(x1+z1)
+    mark(2);
     fe_add(C, A, B);                   // beta 2
     fe_sub(B, A, B);                   // beta 3
+    mark(3);
     fe_sqr(SX, C);                     // x3
     fe_sqr(A, B);
+    mark(4);
     if (BASE9) fe_mul_small(SZ, A, 9);  // z3 = (..)^2 * 9
     else fe_mul(SZ, A, base);          // z3 = (..)^2 * xb
-
+    mark(5);
     fe_sqr(A, P);                      // (x+z)^2
     fe_sqr(B, M);                      // (x-z)^2
+    mark(6);
     fe_mul(DX, A, B);                  // x4
+    mark(7);
     fe_sub(B, A, B);                   // beta 3
     fe_mul121665_add(A, A, B);         // (x+z)^2 + 121665*B
+    mark(8);
     fe_mul(DZ, B, A);                  // z4
+    mark(9);
 }
 
 // (PX : PZ) = clamp(k) * (u : 1), x-only, projective.  k are the CLAMPED scalar words.  The affine result
 // PX/PZ is produced by the shared batched-inversion kernel (engine.hip), which amortises ecp_Inverse
 // (curve25519_dh.c:148) over several elements.
-template <bool BASE9 = false>
-C25519_DEV void x25519_ladder_xz(fe& PX, fe& PZ, const u32 (&u)[8], const u32 (&k)[8])
+template <bool BASE9 = false, typename Mark = NoSectionMark>
+C25519_DEV void x25519_ladder_xz(fe& PX, fe& PZ, const u32 (&u)[8], const u32 (&k)[8], Mark mark = Mark())
 {
     fe X1, SX, SZ, DX, DZ;
     fe_from_words(X1, u);
@@ -95,7 +107,8 @@ C25519_DEV void x25519_ladder_xz(fe& PX, fe& PZ, const u32 (&u)[8], const u32 (&
             const u32 bit = kw >> 31;
             kw <<= 1;
             const u32 eq = (u32)0 - (u32)(bit == prev);
-            ladder_step<BASE9>(SX, SZ, DX, DZ, X1, eq);
+            mark(-1);                                    // step entry
+            ladder_step<BASE9>(SX, SZ, DX, DZ, X1, eq, mark);
             prev = bit;
         }
     }

@@ -118,6 +118,27 @@
     "v_mad_u64_u32 v[40:41], vcc, v39, v38, v[40:41]\n\tv_and_b32 " l ", 0x3ffffff, v40\n\t" \
     "v_lshrrev_b64 v[40:41], 26, v[40:41]\n\t"
 #define FIELD_MULI COLI("v58") COLI("v59") COLI("v60") COLI("v61") COLI("v62") COLI("v63") COLI("v64") COLI("v65") COLI("v66") COLI("v67")
+// full-rate instructions between MADs: the same 8 MADs + 8 masks per group, in runs of 1 / 2 / 4 / 8 (round 4: what does a
+// VOP2 instruction cost when it is NOT part of a run of them?)
+#define M_(c) "v_mad_u64_u32 v[" #c ":" c1_##c "], vcc, v38, v39, v[" #c ":" c1_##c "]\n\t"
+#define c1_40 "41"
+#define c1_42 "43"
+#define c1_44 "45"
+#define c1_46 "47"
+#define c1_48 "49"
+#define c1_50 "51"
+#define c1_52 "53"
+#define c1_54 "55"
+#define A_(r) "v_and_b32 v" #r ", 0x3ffffff, v" #r "\n\t"
+#define RUN1 M_(40) A_(58) M_(42) A_(59) M_(44) A_(60) M_(46) A_(61) M_(48) A_(62) M_(50) A_(63) M_(52) A_(64) M_(54) A_(65)
+#define RUN2 M_(40) M_(42) A_(58) A_(59) M_(44) M_(46) A_(60) A_(61) M_(48) M_(50) A_(62) A_(63) M_(52) M_(54) A_(64) A_(65)
+#define RUN4 M_(40) M_(42) M_(44) M_(46) A_(58) A_(59) A_(60) A_(61) M_(48) M_(50) M_(52) M_(54) A_(62) A_(63) A_(64) A_(65)
+#define RUN8 M_(40) M_(42) M_(44) M_(46) M_(48) M_(50) M_(52) M_(54) A_(58) A_(59) A_(60) A_(61) A_(62) A_(63) A_(64) A_(65)
+// the same with the half-rate 64-bit shift in the place of the MAD, and a mask pair after every third MAD (what a column is)
+#define S_(c) "v_lshrrev_b64 v[" #c ":" c1_##c "], 1, v[" #c ":" c1_##c "]\n\t"
+#define RUN1S S_(40) A_(58) S_(42) A_(59) S_(44) A_(60) S_(46) A_(61) S_(48) A_(62) S_(50) A_(63) S_(52) A_(64) S_(54) A_(65)
+#define ADDV_(r) "v_add_u32 v" #r ", v" #r ", v38\n\t"
+#define RUN1ADD M_(40) ADDV_(58) M_(42) ADDV_(59) M_(44) ADDV_(60) M_(46) ADDV_(61) M_(48) ADDV_(62) M_(50) ADDV_(63) M_(52) ADDV_(64) M_(54) ADDV_(65)
 #define X2(B) B B
 #define X8(B) X2(X2(X2(B)))
 #define X16(B) X2(X8(B))
@@ -150,9 +171,20 @@
           "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
           "v68", "v69", "v70", "v71", "v72", "v73")
 
-template <int ID>
-__global__ void __launch_bounds__(256) k_loop(unsigned* out, unsigned seed, int trips)
+// every wave also leaves its own duration in shader cycles (s_memtime: one tick per shader cycle): the longest one of a
+// launch in which all waves are resident from the start is the launch's SIMD time, so cycles per instruction and the
+// clock the chip sustained under that stream come out of the same run as the lane-op/s figure (round 4)
+__device__ __forceinline__ unsigned long long now_cycles()
 {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+
+template <int ID>
+__global__ void __launch_bounds__(256) k_loop(unsigned* out, unsigned seed, int trips, unsigned long long* cyc)
+{
+    const unsigned long long t0 = now_cycles();
     unsigned a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u, r = 0;
     if constexpr (ID == 0) LOOP(PAD0, X2(MAD8));
     if constexpr (ID == 1) LOOP(PAD2, X2(MAD8));
@@ -175,7 +207,15 @@ __global__ void __launch_bounds__(256) k_loop(unsigned* out, unsigned seed, int 
     if constexpr (ID == 19) LOOP(PAD0, FIELD_MUL2);
     if constexpr (ID == 20) LOOP(PAD0, X2(FIELD_MULC));
     if constexpr (ID == 21) LOOP(PAD0, FIELD_MULI);
+    if constexpr (ID == 22) LOOP(PAD0, X8(RUN1));
+    if constexpr (ID == 23) LOOP(PAD0, X8(RUN2));
+    if constexpr (ID == 24) LOOP(PAD0, X8(RUN4));
+    if constexpr (ID == 25) LOOP(PAD0, X8(RUN8));
+    if constexpr (ID == 26) LOOP(PAD0, X8(RUN1S));
+    if constexpr (ID == 27) LOOP(PAD0, X8(RUN1ADD));
     if (r == 0x12345678u) out[0] = r;
+    const unsigned long long t1 = now_cycles();
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
 }
 
 struct Row { int id; int per_trip; double scale; const char* key; const char* name; };
@@ -201,16 +241,33 @@ static const Row rows[] = {
     { 19, 240, 1, "field_mul_two_products", "two products interleaved MAD by MAD (same 240 instructions per trip)" },
     { 20, 250, 1, "field_mul_column_pairs", "one product, columns in pairs + one 64-bit add per pair (2 x 125 per trip)" },
     { 21, 210, 1, "field_mul_mad_and", "one product, a full-rate mask between dependent MADs (210 per trip, 100 MADs)" },
+    { 22, 128, 1, "mad_and_runs_of_1", "MAD, mask, MAD, mask ... (64 + 64 per trip, independent)" },
+    { 23, 128, 1, "mad_and_runs_of_2", "2 MADs, 2 masks, ... (64 + 64 per trip)" },
+    { 24, 128, 1, "mad_and_runs_of_4", "4 MADs, 4 masks, ... (64 + 64 per trip)" },
+    { 25, 128, 1, "mad_and_runs_of_8", "8 MADs, 8 masks, ... (64 + 64 per trip)" },
+    { 26, 128, 1, "shr64_and_runs_of_1", "v_lshrrev_b64, mask, v_lshrrev_b64, mask ... (64 + 64 per trip)" },
+    { 27, 128, 1, "mad_add_runs_of_1", "MAD, v_add_u32 (VOP2, two VGPRs), MAD, v_add_u32 ... (64 + 64 per trip)" },
 };
 // the field streams again at lower occupancy: what the dependent-MAD penalty costs with 4 / 2 / 1 waves per SIMD
-static const int occupancy_rows[] = { 6, 9, 18, 19, 20, 21 };
+static const int occupancy_rows[] = { 6, 9, 14, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27 };
 
-template <int ID> static void launch(int blocks, unsigned* d, int trips, hipStream_t s) { k_loop<ID><<<blocks, 256, 0, s>>>(d, 1, trips); }
+static unsigned long long* g_cyc;          // [MAX_WAVES] device, g_cyc_host its mirror
+static unsigned long long* g_cyc_host;
+constexpr int MAX_WAVES = 256 * 8 * 4 * 2;
+template <int ID> static void launch(int blocks, unsigned* d, int trips, hipStream_t s) { k_loop<ID><<<blocks, 256, 0, s>>>(d, 1, trips, g_cyc); }
+// the longest wave of the last launch, in shader cycles
+static double longest_wave(int blocks)
+{
+    CHECK(hipMemcpy(g_cyc_host, g_cyc, sizeof(unsigned long long) * blocks * 4, hipMemcpyDeviceToHost));
+    unsigned long long m = 0;
+    for (int i = 0; i < blocks * 4; i++) if (g_cyc_host[i] > m) m = g_cyc_host[i];
+    return (double)m;
+}
 static void dispatch(int id, int blocks, unsigned* d, int trips, hipStream_t s)
 {
     switch (id) {
 #define C(k) case k: launch<k>(blocks, d, trips, s); break;
-        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(18) C(19) C(20) C(21)
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(18) C(19) C(20) C(21) C(22) C(23) C(24) C(25) C(26) C(27)
 #undef C
     }
 }
@@ -220,31 +277,40 @@ int main(int argc, char** argv)
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     unsigned* d; CHECK(hipMalloc(&d, 64));
+    CHECK(hipMalloc(&g_cyc, sizeof(unsigned long long) * MAX_WAVES));
+    g_cyc_host = (unsigned long long*)malloc(sizeof(unsigned long long) * MAX_WAVES);
     hipStream_t s; CHECK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     FILE* jf = argc > 1 ? fopen(argv[1], "w") : nullptr;
     if (jf) fprintf(jf, "{\"device_cus\": %d, \"waves_per_simd\": 8, \"unit\": \"lane-op/s\", \"rates\": {\n", cus);
+    // argv[2]: SIMD cycles per wave-instruction of every row (s_memtime inside the kernels), the issue model's class costs
+    FILE* cj = argc > 2 ? fopen(argv[2], "w") : nullptr;
+    bool cfirst = true;
+    if (cj) fprintf(cj, "{\"unit\": \"SIMD cycles per wave-instruction\", \"cycles\": {\n");
     printf("device %s, %d CUs; 8 waves per SIMD, ~65536 instructions per wave, best of 5\n", prop.name, cus);
     bool first = true;
     for (const Row& r : rows) {
         const int trips = 65536 / r.per_trip;
         const int blocks = cus * 8;
         float best = 1e30f;
+        double cycles = 0;
         for (int rep = 0; rep < 6; rep++) {
             CHECK(hipEventRecord(e0, s));
             dispatch(r.id, blocks, d, trips, s);
             CHECK(hipEventRecord(e1, s));
             CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep && ms < best) best = ms;
+            if (rep && ms < best) { best = ms; cycles = longest_wave(blocks); }
         }
         const double rate = r.scale * (double)blocks * 4 * (double)trips * r.per_trip * 64 / (best * 1e-3);
-        printf("%-78s %8.3f ms  %7.2f T lane-op/s\n", r.name, best, rate / 1e12);
+        const double cpi = cycles / (8.0 * trips * r.per_trip);             // SIMD cycles per wave-instruction
+        printf("%-78s %8.3f ms  %7.2f T lane-op/s  %5.2f cycles/instr  %5.3f GHz\n", r.name, best, rate / 1e12, cpi, cycles / (best * 1e6));
         if (jf) { fprintf(jf, "%s  \"%s\": %.4e", first ? "" : ",\n", r.key, rate); first = false; }
+        if (cj) { fprintf(cj, "%s  \"%s\": %.4f", cfirst ? "" : ",\n", r.key, cpi); cfirst = false; }
     }
     if (jf) fprintf(jf, "\n},\n\"by_occupancy\": {\n");
     first = true;
-    for (int waves : { 4, 2, 1 }) {
+    for (int waves : { 6, 4, 2, 1 }) {
         printf("-- %d wave(s) per SIMD\n", waves);
         for (int id : occupancy_rows) {
             const Row* r = nullptr;
@@ -252,19 +318,23 @@ int main(int argc, char** argv)
             const int trips = 65536 / r->per_trip;
             const int blocks = cus * waves;
             float best = 1e30f;
+            double cycles = 0;
             for (int rep = 0; rep < 6; rep++) {
                 CHECK(hipEventRecord(e0, s));
                 dispatch(r->id, blocks, d, trips, s);
                 CHECK(hipEventRecord(e1, s));
                 CHECK(hipEventSynchronize(e1));
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-                if (rep && ms < best) best = ms;
+                if (rep && ms < best) { best = ms; cycles = longest_wave(blocks); }
             }
             const double rate = (double)blocks * 4 * (double)trips * r->per_trip * 64 / (best * 1e-3);
-            printf("%-78s %8.3f ms  %7.2f T lane-op/s\n", r->name, best, rate / 1e12);
+            const double cpi = cycles / ((double)waves * trips * r->per_trip);
+            printf("%-78s %8.3f ms  %7.2f T lane-op/s  %5.2f cycles/instr  %5.3f GHz\n", r->name, best, rate / 1e12, cpi, cycles / (best * 1e6));
             if (jf) { fprintf(jf, "%s  \"%s@%d\": %.4e", first ? "" : ",\n", r->key, waves, rate); first = false; }
+            if (cj) { fprintf(cj, "%s  \"%s@%d\": %.4f", cfirst ? "" : ",\n", r->key, waves, cpi); cfirst = false; }
         }
     }
     if (jf) { fprintf(jf, "\n}}\n"); fclose(jf); }
+    if (cj) { fprintf(cj, "\n}}\n"); fclose(cj); }
     return 0;
 }
