@@ -42,6 +42,7 @@ SIGNATURES = {
     "c25519_amd_multi_create": [_vp, _vp, C.c_int],
     "c25519_amd_multi_destroy": [_vp],
     "c25519_amd_multi_device_count": [_vp],
+    "c25519_amd_multi_set_gather": [_vp, C.c_int],
     "curve25519_dh_CreateSharedKey_multi": [_vp, _vp, _vp, _vp, _sz],
     "ed25519_SignMessage_multi": [_vp, _vp, _vp, _vp, _sz, _sz],
     "ed25519_VerifySignature_multi": [_vp, _vp, _vp, _vp, _vp, _sz, _sz],

@@ -104,6 +104,8 @@ struct ThreadState {
     };
     WorkSlab work[MAX_DEV][CALLER_SLABS];
     unsigned long work_clock = 0;
+    unsigned long generation = 0;          // bumped whenever streams / slabs / report words are destroyed: a handle to one of
+                                           // them remembered across calls (engine.hip: LastVerify) is stale afterwards
     WorkSlab lane_work[LANES];             // ... and one per pipeline lane, so that the pieces of a *_batch call do not
                                            // wait for each other's kernels (they belong to the staging device)
 
@@ -122,8 +124,9 @@ struct ThreadState {
         }
         return pick;
     }
-    static void free_slab(WorkSlab& w)     // on the slab's device, after a synchronize
+    void free_slab(WorkSlab& w)            // on the slab's device, after a synchronize
     {
+        generation++;
         if (w.ptr) { (void)hipMemset(w.ptr, 0, w.cap); (void)hipFree(w.ptr); }
         if (w.done) (void)hipEventDestroy(w.done);
         if (w.report) (void)hipFree(w.report);
@@ -227,6 +230,7 @@ struct ThreadState {
     void release_staging()
     {
         if (device < 0) return;
+        generation++;
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
@@ -279,5 +283,31 @@ inline ThreadState& tls()
     static thread_local ThreadState s;
     return s;
 }
+
+// A work slab between acquire_work and release_work.  Leaving the scope without release() -- an error return between the
+// two, with kernels possibly queued on the slab already -- still records the slab's `done` event on the stream, so that a
+// stream that takes the slab over later waits for everything that was enqueued, not for a stale event.
+class WorkLease {
+public:
+    WorkLease() = default;
+    WorkLease(const WorkLease&) = delete;
+    WorkLease& operator=(const WorkLease&) = delete;
+    ~WorkLease() { if (live_) { (void)tls().release_work(stream_); (void)hipGetLastError(); } }
+    int acquire(void** out, size_t bytes, hipStream_t s)
+    {
+        C25519_RC(tls().acquire_work(out, bytes, s));
+        stream_ = s; live_ = true;
+        return 0;
+    }
+    int release()
+    {
+        live_ = false;
+        return tls().release_work(stream_);
+    }
+
+private:
+    hipStream_t stream_ = nullptr;
+    bool live_ = false;
+};
 
 }  // namespace c25519_host

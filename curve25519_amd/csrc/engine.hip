@@ -966,7 +966,7 @@ inline size_t verify_scratch_bytes(size_t n)
 // fits; the reference's order runs for the others in a kernel of its own behind the walk.  fast = false: reference order for everything,
 // and Fin decides what leaves it: the verdict, or enc(T) for the test hook.
 // what the calling thread's last fast-path verification left behind for c25519_amd_verify_last_slow_elements
-struct LastVerify { const u32* count = nullptr; hipStream_t stream = nullptr; int device = -1; };
+struct LastVerify { const u32* count = nullptr; hipStream_t stream = nullptr; int device = -1; unsigned long generation = 0; };
 thread_local LastVerify tl_last_verify;
 
 template <typename MakeFin>
@@ -975,7 +975,8 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
-    C25519_RC(tls().acquire_work(&w, verify_scratch_bytes(n), stream));
+    c25519_host::WorkLease lease;
+    C25519_RC(lease.acquire(&w, verify_scratch_bytes(n), stream));
     u32* tables = (u32*)w;                                  // first in the slab (hipMalloc: 256-byte aligned): packed rows are
     const ProjScratch scr = carve_proj(tables + n * VERIFY_TABLE_WORDS, n);   // whole 128-byte lines
     const unsigned grid = grid_for(n, ED_BLOCK);
@@ -1001,8 +1002,9 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
         k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
         C25519_TRY(hipGetLastError());
         tl_last_verify.count = report; tl_last_verify.stream = stream;
+        tl_last_verify.generation = tls().generation;       // the report word and the stream die with the thread's slabs
         (void)hipGetDevice(&tl_last_verify.device);
-        return tls().release_work(stream);
+        return lease.release();
     }
     tl_last_verify = LastVerify();
     k_ed25519_verify_init<QTableLimbs><<<grid, ED_BLOCK, 0, stream>>>(pk, n, tables, VERIFY_TABLE_WORDS);
@@ -1010,7 +1012,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
     k_ed25519_verify_check<QTableLimbs><<<grid, ED_BLOCK, 0, stream>>>(scr, sig, pk, msgs, n, tbl, tables, VERIFY_TABLE_WORDS);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, make_fin(scr), stream));
-    return tls().release_work(stream);
+    return lease.release();
 }
 
 // lanes per X25519 workgroup for a batch of n: the widest shape that still puts a wave on every SIMD the batch can reach
@@ -1087,7 +1089,11 @@ int c25519_amd_probe_words(void) { return PROBE_WORDS; }
 #endif
 
 // frees the calling thread's streams, staging buffers (zeroed first) and work scratch
-void c25519_amd_thread_release(void) { tls().release(); }
+void c25519_amd_thread_release(void)
+{
+    c25519_host::helper_pool_slot().reset();              // the pipeline's parked helper threads
+    tls().release();
+}
 
 // ---- device-pointer entry points ----------------------------------------------------------------
 
@@ -1095,13 +1101,14 @@ static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t
 {
     if (x25519_split_for(n)) {
         void* w = nullptr;
-        C25519_RC(tls().acquire_work(&w, proj_words(n) * sizeof(u32), stream));
+        c25519_host::WorkLease lease;
+        C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
         const ProjScratch scr = carve_proj((u32*)w, n);
         if (pk) k_x25519_ladder<false><<<grid_for(n, XL_BLOCK), XL_BLOCK, 0, stream>>>(scr.a, scr.z, pk, sk, n);
         else    k_x25519_ladder<true><<<grid_for(n, XL_BLOCK), XL_BLOCK, 0, stream>>>(scr.a, scr.z, pk, sk, n);
         C25519_TRY(hipGetLastError());
         C25519_RC(launch_invert(scr, n, FinishX25519{ scr.a, out, n }, stream));
-        return tls().release_work(stream);
+        return lease.release();
     }
     switch (x25519_block_for(n)) {
     case 64:  x25519_launch<64>(out, pk, sk, n, stream); break;
@@ -1138,12 +1145,13 @@ int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
-    C25519_RC(tls().acquire_work(&w, proj_words(n) * sizeof(u32), stream));
+    c25519_host::WorkLease lease;
+    C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     k_x25519_public_fast_mult<<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, sk, n, tbl);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishX25519{ scr.a, pk, n }, stream));
-    return tls().release_work(stream);
+    return lease.release();
 }
 
 static int keypair_dev(void* pub, void* priv, const void* sk, const void* blinding, size_t n, hipStream_t stream)
@@ -1154,7 +1162,8 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
-    C25519_RC(tls().acquire_work(&w, proj_words(n) * sizeof(u32), stream));
+    c25519_host::WorkLease lease;
+    C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     if (blinding)
         k_ed25519_keypair_mult<true><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, priv, sk, n, tbl, (const u32*)blinding);
@@ -1163,7 +1172,7 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
     C25519_TRY(hipGetLastError());
     // pub[e] and priv[e][32..63] <- enc(A)
     C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, pub, n, 1, 0, priv, 2, 1 }, stream));
-    return tls().release_work(stream);
+    return lease.release();
 }
 
 int ed25519_CreateKeyPair_dev(void* pub, void* priv, const void* sk, size_t n, void* stream)
@@ -1185,7 +1194,8 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
     const size_t sc_words = round_up(8 * n, 4);
-    C25519_RC(tls().acquire_work(&w, (proj_words(n) + 2 * sc_words) * sizeof(u32), stream));
+    c25519_host::WorkLease lease;
+    C25519_RC(lease.acquire(&w, (proj_words(n) + 2 * sc_words) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     u32* a_buf = (u32*)w + proj_words(n);
     u32* r_buf = a_buf + sc_words;
@@ -1199,7 +1209,7 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
     C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, sig, n, 2, 0, nullptr, 0, 0 }, stream));   // sig[e][0..31] = enc(R)
     k_ed25519_sign_finish<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(sig, priv, msgs, n, a_buf, r_buf);
     C25519_TRY(hipGetLastError());
-    return tls().release_work(stream);
+    return lease.release();
 }
 
 int ed25519_SignMessage_dev(void* sig, const void* priv, const void* msg, size_t msg_size, size_t n, void* stream)
@@ -1265,6 +1275,7 @@ long c25519_amd_verify_last_slow_elements(void)
     const LastVerify& lv = tl_last_verify;
     int dev = -1;
     if (!lv.count || hipGetDevice(&dev) != hipSuccess || dev != lv.device) return -1;
+    if (lv.generation != tls().generation) return -1;       // c25519_amd_thread_release() / a device switch freed what lv points at
     if (hipStreamSynchronize(lv.stream) != hipSuccess) return -1;
     u32 c = 0;
     if (hipMemcpy(&c, lv.count, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
@@ -1310,13 +1321,14 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     void* w = nullptr;
-    C25519_RC(tls().acquire_work(&w, proj_words(n) * sizeof(u32), stream));
+    c25519_host::WorkLease lease;
+    C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     k_ed25519_verify_check_shared<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
         scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
-    return tls().release_work(stream);
+    return lease.release();
 }
 
 // ---- unit-test hooks (host pointers) ---------------------------------------------------------------

@@ -5,6 +5,8 @@
 #include "capi_common.hpp"
 
 #include <condition_variable>
+#include <functional>
+#include <memory>
 #include <initializer_list>
 #include <mutex>
 #include <system_error>
@@ -14,6 +16,78 @@
 namespace c25519_host {
 
 inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- helper threads of the pipeline: created once per calling thread, parked between calls --------------------------
+// (round 3 created and joined up to six std::threads inside every *_batch call.)  run() hands task(i) to helper i for
+// i < k and returns at once; wait() blocks until all of them have come back.  The tasks reference the caller's locals, so
+// every run() is paired with a wait() before those go out of scope.  A pool that could not start its threads reports
+// ok() == false and the pipeline runs its pieces one after the other instead.
+class HelperPool {
+public:
+    explicit HelperPool(int n)
+    {
+        try {
+            for (int i = 0; i < n; i++) th_.emplace_back([this, i] { loop(i); });
+        } catch (const std::system_error&) {
+            shutdown();
+            failed_ = true;
+        }
+    }
+    ~HelperPool() { shutdown(); }
+    bool ok() const { return !failed_; }
+    int size() const { return (int)th_.size(); }
+    template <typename Task>
+    void run(int k, Task& task)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        task_ = [&task](int i) { task(i); };
+        active_ = k;
+        pending_ = k;
+        gen_++;
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        task_ = nullptr;
+    }
+
+private:
+    void loop(int i)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            std::function<void(int)> t;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && i < active_); });
+                if (stop_) return;
+                seen = gen_;
+                t = task_;
+            }
+            t(i);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    void shutdown()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) if (t.joinable()) t.join();
+        th_.clear();
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::function<void(int)> task_;
+    int active_ = 0, pending_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false, failed_ = false;
+};
 
 // ---- host-pointer pipeline used by the *_batch entry points -------------------------------------------------------
 // A call is cut into pieces; piece c uses buffer set c % SETS (pinned host + device staging), and these roles work on
@@ -69,8 +143,36 @@ struct ShapeHint {
     ~ShapeHint() { batch_shape_hint() = saved; }
 };
 
+// the calling thread's parked helpers (created on the first pipelined call, joined when the thread exits or calls
+// c25519_amd_thread_release())
+inline std::unique_ptr<HelperPool>& helper_pool_slot() { thread_local std::unique_ptr<HelperPool> p; return p; }
+inline HelperPool& helper_pool(int n)
+{
+    auto& p = helper_pool_slot();
+    if (!p || (p->ok() && p->size() < n)) p.reset(new HelperPool(n));
+    return *p;
+}
+
+// rows per piece of a pipelined call of n rows of `row` bytes: n/8 (C25519_AMD_BATCH_PIECES) in multiples of 256 for big
+// batches, everything at once for small ones, at most 256 MiB of staging per buffer set
+inline size_t piece_rows(size_t n, size_t row)
+{
+    static const size_t pieces = [] { const char* e = getenv("C25519_AMD_BATCH_PIECES"); int v = e ? atoi(e) : 0; return (size_t)(v >= 2 && v <= 64 ? v : 8); }();
+    size_t chunk = n >= ((size_t)1 << 17) ? round_up((n + pieces - 1) / pieces, 256) : n;
+    const size_t cap = round_up(((size_t)256 << 20) / (row ? row : 1) + 1, 256);
+    return chunk > cap ? cap : chunk;
+}
+
+// What the multi-GPU layer hangs on a device's pipeline: the piece size (so that every device cuts its shard at the same
+// rows) and a call per piece once its kernels are enqueued -- `computed` is the event behind them on this device (null:
+// the piece has already completed), which another stream can wait for while this pipeline keeps going.
+struct PieceHook {
+    size_t chunk = 0;                                      // 0: piece_rows(n, row)
+    std::function<void(size_t c, size_t lo, size_t cnt, hipEvent_t computed)> enqueued;
+};
+
 template <typename Launch>
-int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
+int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const PieceHook* hook = nullptr)
 {
     ThreadState& t = tls();
     C25519_RC(t.ensure());
@@ -80,10 +182,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     if (na > ThreadState::SLOTS) return bad_arg("internal: too many arrays");
     size_t row = 0;
     for (int a = 0; a < na; a++) row += arr[a].elem;
-    static const size_t pieces = [] { const char* e = getenv("C25519_AMD_BATCH_PIECES"); int v = e ? atoi(e) : 0; return (size_t)(v >= 2 && v <= 64 ? v : 8); }();
-    size_t chunk = n >= ((size_t)1 << 17) ? round_up((n + pieces - 1) / pieces, 256) : n;
-    const size_t cap = round_up(((size_t)256 << 20) / (row ? row : 1) + 1, 256);       // <= 256 MiB of staging per buffer set
-    if (chunk > cap) chunk = cap;
+    const size_t chunk = hook && hook->chunk ? hook->chunk : piece_rows(n, row);
     const size_t nchunks = (n + chunk - 1) / chunk;
     const int sets = nchunks < (size_t)ThreadState::SETS ? (int)nchunks : ThreadState::SETS;
     bool direct[ThreadState::SLOTS] = {};                  // the caller's array is pinned: no staging copy either way
@@ -136,6 +235,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
         if (!one_stream) {
             C25519_TRY(hipEventRecord(t.computed[l], kern));
             C25519_TRY(hipStreamWaitEvent(down, t.computed[l], 0));
+            if (hook && hook->enqueued) hook->enqueued(c, lo, cnt, t.computed[l]);
         }
         for (int a = 0; a < na; a++)
             if (arr[a].out && cnt * arr[a].elem)
@@ -167,6 +267,11 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
             int rc = submit(c, true);
             if (!rc) rc = drain(c);
             if (rc) { quiesce(); return rc; }
+            if (hook && hook->enqueued) {                   // (drain waited for the piece's last copy: it has completed)
+                size_t lo, cnt;
+                span(c, lo, cnt);
+                hook->enqueued(c, lo, cnt, nullptr);
+            }
         }
         if (resident_result) quiesce();
         return 0;
@@ -178,16 +283,17 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
     std::vector<char> staged(nchunks, 0), drained(nchunks, 0);
     size_t submitted = 0;
     int failed = 0;                                       // first error of any role; everybody stops
+    std::string failed_text;                              // ... and its text: last_error() is thread-local, helpers have their own
     // helper threads: 4 + 2 on a machine with cores to spare (sign moves 160 B per 1.8 ns of kernel time: one copier
-    // per direction cannot keep up), 2 + 1 on a small one
+    // per direction cannot keep up), 2 + 1 on a small one; parked in the calling thread's pool between calls
     static const bool roomy = std::thread::hardware_concurrency() >= 16;
     static const int STAGERS = env_count("C25519_AMD_STAGERS", roomy ? 4 : 2, MAX_STAGERS);
     static const int DRAINERS = env_count("C25519_AMD_DRAINERS", roomy ? 2 : 1, MAX_DRAINERS);
-    std::thread helpers[MAX_STAGERS + MAX_DRAINERS];
-    int started = 0;
-    try {
-    for (int sidx = 0; sidx < STAGERS; sidx++, started++)
-        helpers[started] = std::thread([&, sidx] {
+    HelperPool& pool = helper_pool(STAGERS + DRAINERS);
+    if (!pool.ok()) return sequential();                  // the process cannot have more threads: do without them
+    auto helper = [&](int idx) {
+        if (idx < STAGERS) {
+            const int sidx = idx;
             for (size_t c = 0; c < nchunks; c++) {        // every stager copies its share of every piece: pieces
                                                           // become ready in order, each in 1/STAGERS of the time
                 {   // the previous piece in this buffer set must have left its pinned buffers
@@ -199,9 +305,8 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
                 { std::lock_guard<std::mutex> lk(mu); staged[c]++; }
                 cv.notify_all();
             }
-        });
-    for (int didx = 0; didx < DRAINERS; didx++, started++)
-        helpers[started] = std::thread([&, didx] {
+        } else {
+            const int didx = idx - STAGERS;
             for (size_t c = didx; c < nchunks; c += DRAINERS) {
                 {
                     std::unique_lock<std::mutex> lk(mu);
@@ -211,18 +316,14 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
                 const int rc = drain(c);
                 {
                     std::lock_guard<std::mutex> lk(mu);
-                    if (rc && !failed) failed = rc;
+                    if (rc && !failed) { failed = rc; failed_text = last_error(); }
                     drained[c] = 1;
                 }
                 cv.notify_all();
             }
-        });
-    } catch (const std::system_error&) {                  // the process cannot have more threads: do without them
-        { std::lock_guard<std::mutex> lk(mu); failed = -1; }
-        cv.notify_all();
-        for (int i = 0; i < started; i++) helpers[i].join();
-        return sequential();
-    }
+        }
+    };
+    pool.run(STAGERS + DRAINERS, helper);
     for (size_t c = 0; c < nchunks; c++) {
         {
             std::unique_lock<std::mutex> lk(mu);
@@ -232,14 +333,15 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch)
         const int rc = submit(c, false);
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (rc && !failed) failed = rc;
+            if (rc && !failed) { failed = rc; failed_text = last_error(); }
             submitted = c + 1;
         }
         cv.notify_all();
         if (rc) break;
     }
-    for (int i = 0; i < started; i++) helpers[i].join();
+    pool.wait();
     if (failed || resident_result) quiesce();
+    if (failed) last_error() = failed_text;               // whichever thread saw it first: the caller gets rc AND text
     return failed;
 }
 

@@ -9,8 +9,14 @@
 //      same pinned, pieced pipeline as the single-GPU *_batch entry points (host_pipeline.hpp: stage-in threads, upload /
 //      kernel / download streams), so every device's uploads run over its own PCIe link at the same time and no copy
 //      ever leaves from or lands in pageable memory.  Gathered results stay on the device (Arr::dev);
-//   3. one grouped ncclGather per output array to devices[0] (rows padded to the largest shard, every rank sends the
-//      same count), then the root's worker streams the gathered slab to the caller through the same pipeline.
+//   3. the one exchange step: a grouped ncclGather of every device's result rows to devices[0] (rows padded to the
+//      largest shard, every rank sends the same count), and a second thread on the root streams the gathered rows to the
+//      caller.  All of it PIECE BY PIECE: every device cuts its shard at the same rows, a piece is gathered as soon
+//      as every device has enqueued its kernels (the gather streams wait for the pieces' events on the device; no worker
+//      ever stops for it) and handed to the caller while the devices compute the next pieces, so only the last
+//      piece's gather and download are not hidden (round 3 ran the three phases strictly one after the other).
+//   c25519_amd_multi_set_gather(handle, 0) leaves the gather out: every device hands its own rows to the caller over
+//   its own PCIe link (no root-link bound for host destinations); the gather mode is what north_star names and the default.
 // RCCL is loaded with dlopen on first use, so single-GPU users of the library do not pay for (or need) it; without its
 // header the few declarations used here are spelled out below, so the library builds on a machine that lacks RCCL.
 #include "capi_common.hpp"
@@ -36,6 +42,7 @@ const char* ncclGetErrorString(ncclResult_t result);
 }
 #endif
 
+#include <deque>
 #include <functional>
 #include <memory>
 
@@ -78,15 +85,18 @@ int load_rccl(Rccl& r)
 
 constexpr int MAX_ARR = 5;
 
-// One per device: a thread bound to that device for the life of the handle (its thread-local ThreadState -- streams,
-// pinned and device staging, work scratch -- is created on first use and reused by every call), fed one job at a time.
+// One per device (plus one more on the root for the gathered rows): a thread bound to that device for the life of the
+// handle (its thread-local ThreadState -- streams, pinned and device staging, work scratch -- is created on first use and
+// reused by every call), fed jobs in FIFO order.  wait() returns once every job submitted so far has run, with the first
+// error among them (later jobs of a failed sequence are skipped).
 struct Worker {
     int device = 0;
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    std::function<int()> job;
-    bool has_job = false, done = false, stop = false;
+    std::deque<std::function<int()>> jobs;
+    size_t submitted = 0, finished = 0;
+    bool stop = false;
     int rc = 0;
     std::string err;
 
@@ -97,19 +107,20 @@ struct Worker {
             (void)hipSetDevice(device);
             for (;;) {
                 std::function<int()> j;
+                bool skip;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return has_job || stop; });
-                    if (stop) break;
-                    j = std::move(job);
-                    has_job = false;
+                    cv.wait(lk, [&] { return !jobs.empty() || stop; });
+                    if (jobs.empty()) break;
+                    j = std::move(jobs.front());
+                    jobs.pop_front();
+                    skip = rc != 0;
                 }
-                const int r = j();
+                const int r = skip ? 0 : j();
                 {
                     std::lock_guard<std::mutex> lk(mu);
-                    rc = r;
-                    err = r ? last_error() : std::string();      // the error text is thread-local: carry it to the caller
-                    done = true;
+                    if (r && !rc) { rc = r; err = last_error(); }     // the error text is thread-local: carry it to the caller
+                    finished++;
                 }
                 cv.notify_all();
             }
@@ -118,15 +129,18 @@ struct Worker {
     }
     void submit(std::function<int()> j)
     {
-        { std::lock_guard<std::mutex> lk(mu); job = std::move(j); has_job = true; done = false; }
+        { std::lock_guard<std::mutex> lk(mu); jobs.push_back(std::move(j)); submitted++; }
         cv.notify_all();
     }
+    // every job submitted so far has run (or was skipped behind a failed one); returns and clears the first error
     int wait()
     {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return done; });
-        if (rc) last_error() = err;
-        return rc;
+        cv.wait(lk, [&] { return finished == submitted; });
+        const int r = rc;
+        if (r) last_error() = err;
+        rc = 0;
+        return r;
     }
     void shutdown()
     {
@@ -145,6 +159,18 @@ struct c25519_amd_multi {
     std::vector<hipStream_t> stream;          // the gather's stream on each device
     std::vector<ncclComm_t> comm;
     std::vector<std::unique_ptr<Worker>> worker;
+    // the root's hand-over of gathered pieces to the caller, beside worker[0]'s compute: `drain` enqueues a piece's
+    // device-to-host copy on drain_stream (into a pinned slot, or straight into a page-locked destination), `copier`
+    // waits for the slot and copies it out to the caller's pageable rows with copy_pool's threads
+    std::unique_ptr<Worker> drain, copier;
+    std::unique_ptr<c25519_host::HelperPool> copy_pool;
+    hipStream_t drain_stream = nullptr;
+    static constexpr int SLOTS = 4;
+    struct Slot { void* pinned = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; } slot[SLOTS];
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
+    std::vector<hipEvent_t> gathered_ev;      // on devices[0]: piece c has arrived in `gathered`
+    bool gather = true;                       // c25519_amd_multi_set_gather
     std::vector<void*> buf[MAX_ARR];          // per device: the shard's rows of gathered output array a (grow-only)
     std::vector<size_t> cap[MAX_ARR];
     void* gathered[MAX_ARR] = {};             // on devices[0]: D x (largest shard) rows of output array a
@@ -185,85 +211,204 @@ struct MArr {
     bool gather;         // output travels through the RCCL gather to the root (else it is read back from its own device)
 };
 
-// shard; per device (worker thread): pipeline(upload, launch(d, device pointers, count, stream)), results resident;
-// gather; the root's worker downloads the slab
+// shard; per device (worker thread): ONE pipeline over the shard (upload, launch(d, device pointers, count, stream)),
+// gathered outputs resident; the calling thread gathers piece c as soon as every device has enqueued it and hands it to
+// the root's drain thread, which streams it to the caller while the devices compute the following pieces
 template <typename Launch>
 int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch launch)
 {
     const int D = (int)m->dev.size();
     // C25519_AMD_MULTI_FORCE_GATHER=1: a one-device handle takes the gather path too (how the tests run the N > 1 code --
-    // resident results, grouped ncclGather, slab download -- on a one-GPU box)
-    const bool gathers = D > 1 || getenv("C25519_AMD_MULTI_FORCE_GATHER") != nullptr;
+    // resident results, piece-wise grouped ncclGather, hand-over -- on a one-GPU box)
+    const bool gathers = m->gather && (D > 1 || getenv("C25519_AMD_MULTI_FORCE_GATHER") != nullptr);
     int prev = 0;
     C25519_TRY(hipGetDevice(&prev));
     std::vector<size_t> lo(D + 1);
-    size_t rows = 0;                                                  // largest shard
+    size_t rows = 0, row_bytes = 0;                                   // largest shard; bytes per element over all arrays
     for (int d = 0; d <= D; d++) lo[d] = n * (size_t)d / (size_t)D;
     for (int d = 0; d < D; d++) rows = lo[d + 1] - lo[d] > rows ? lo[d + 1] - lo[d] : rows;
+    for (int a = 0; a < na; a++) row_bytes += arr[a].elem;
+    // every device cuts its shard at the same rows: piece c = local rows [c * chunk, min((c + 1) * chunk, shard))
+    const size_t chunk = c25519_host::piece_rows(rows, row_bytes);
+    const size_t P = (rows + chunk - 1) / chunk;
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<size_t> enq(D, 0);                                    // pieces device d has enqueued so far
+    std::vector<std::vector<hipEvent_t>> piece_ev(D, std::vector<hipEvent_t>(P, nullptr));
+    bool any_failed = false;
+
     auto body = [&]() -> int {
-        // 1. every device at once: its worker pipelines the shard's pieces (pinned staging, upload / kernel / download
-        //    streams) and leaves the gathered outputs in buf[a][d]
+        // 1. every device at once: its worker pipelines the shard (pinned staging, upload / kernel / download streams)
+        //    and leaves the gathered outputs in buf[a][d]
         for (int d = 0; d < D; d++) {
             const size_t cnt = lo[d + 1] - lo[d], off = lo[d];
-            m->worker[d]->submit([=, &launch]() -> int {
-                Arr pa[MAX_ARR];
-                for (int a = 0; a < na; a++) {
-                    pa[a] = Arr{ arr[a].in ? (const char*)arr[a].in + off * arr[a].elem : nullptr,
-                                 arr[a].out && !arr[a].gather ? (char*)arr[a].out + off * arr[a].elem : nullptr, arr[a].elem };
-                    if (arr[a].out && arr[a].gather && gathers) {
-                        C25519_RC(reserve(m->buf[a][d], m->cap[a][d], arr[a].elem * rows));
-                        pa[a].dev = m->buf[a][d];
-                    } else if (arr[a].out && arr[a].gather) {
-                        // a handle of ONE device: the gather would hand the device its own rows back, so they leave
-                        // through the worker's pipeline like any output (piece by piece, under the next piece's kernels)
-                        pa[a].out = (char*)arr[a].out + off * arr[a].elem;
+            m->worker[d]->submit([&, d, cnt, off]() -> int {
+                auto run = [&]() -> int {
+                    Arr pa[MAX_ARR];
+                    for (int a = 0; a < na; a++) {
+                        pa[a] = Arr{ arr[a].in ? (const char*)arr[a].in + off * arr[a].elem : nullptr,
+                                     arr[a].out && !arr[a].gather ? (char*)arr[a].out + off * arr[a].elem : nullptr, arr[a].elem };
+                        if (arr[a].out && arr[a].gather && gathers) {
+                            C25519_RC(reserve(m->buf[a][d], m->cap[a][d], arr[a].elem * rows));
+                            pa[a].dev = m->buf[a][d];
+                        } else if (arr[a].out && arr[a].gather) {
+                            // no gather (one device, or switched off): the rows leave through the worker's pipeline like any
+                            // output (piece by piece, under the next piece's kernels, over this device's own link)
+                            pa[a].out = (char*)arr[a].out + off * arr[a].elem;
+                        }
                     }
-                }
-                if (!cnt) return 0;
-                auto piece = [&](void** ptr, size_t c, size_t, hipStream_t st) -> int { return launch(d, ptr, c, st); };
-                switch (na) {
-                    case 2: return run_batch(cnt, { pa[0], pa[1] }, piece);
-                    case 3: return run_batch(cnt, { pa[0], pa[1], pa[2] }, piece);
-                    case 4: return run_batch(cnt, { pa[0], pa[1], pa[2], pa[3] }, piece);
-                    default: return bad_arg("internal: unsupported array count");
-                }
+                    if (!cnt) return 0;
+                    c25519_host::PieceHook hook;
+                    hook.chunk = chunk;
+                    if (gathers)
+                        hook.enqueued = [&, d](size_t c, size_t, size_t, hipEvent_t ev) {
+                            { std::lock_guard<std::mutex> lk(mu); piece_ev[d][c] = ev; enq[d] = c + 1; }
+                            cv.notify_all();
+                        };
+                    auto piece = [&](void** ptr, size_t c, size_t, hipStream_t st) -> int { return launch(d, ptr, c, st); };
+                    switch (na) {
+                        case 2: return run_batch(cnt, { pa[0], pa[1] }, piece, &hook);
+                        case 3: return run_batch(cnt, { pa[0], pa[1], pa[2] }, piece, &hook);
+                        case 4: return run_batch(cnt, { pa[0], pa[1], pa[2], pa[3] }, piece, &hook);
+                        default: return bad_arg("internal: unsupported array count");
+                    }
+                };
+                const int rc = run();
+                // whatever happened, the calling thread must not wait for pieces that will not come (a short shard has
+                // one piece fewer than the largest; a failed pipeline stops early)
+                { std::lock_guard<std::mutex> lk(mu); enq[d] = P; any_failed = any_failed || rc != 0; }
+                cv.notify_all();
+                return rc;
             });
         }
         int rc = 0;
-        for (int d = 0; d < D; d++) { const int r = m->worker[d]->wait(); if (r && !rc) rc = r; }
-        if (rc || !gathers) return rc;
-        // 2. the one exchange step: every device's rows of each gathered output -> devices[0]
-        for (int a = 0; a < na; a++) {
-            if (!arr[a].out || !arr[a].gather || !rows) continue;
+        bool pinned_out[MAX_ARR] = {};
+        if (gathers) {
             C25519_TRY(hipSetDevice(m->dev[0]));
-            C25519_RC(reserve(m->gathered[a], m->gcap[a], arr[a].elem * rows * D));
-            NCCL_TRY(m, m->rccl.GroupStart());
-            for (int d = 0; d < D; d++) {
-                C25519_TRY(hipSetDevice(m->dev[d]));
-                NCCL_TRY(m, m->rccl.Gather(m->buf[a][d], d == 0 ? m->gathered[a] : nullptr, arr[a].elem * rows, ncclUint8, 0,
-                                            m->comm[d], m->stream[d]));
+            while (m->gathered_ev.size() < P) {
+                hipEvent_t e = nullptr;
+                C25519_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                m->gathered_ev.push_back(e);
             }
-            NCCL_TRY(m, m->rccl.GroupEnd());
-        }
-        for (int d = 0; d < D; d++) {
-            C25519_TRY(hipSetDevice(m->dev[d]));
-            C25519_TRY(hipStreamSynchronize(m->stream[d]));
-        }
-        // 3. the root's worker streams the gathered slab to the caller: shard d's rows sit at d * rows
-        m->worker[0]->submit([=]() -> int {
-            for (int a = 0; a < na; a++) {
-                if (!arr[a].out || !arr[a].gather) continue;
-                for (int d = 0; d < D; d++) {
-                    const size_t cnt = lo[d + 1] - lo[d];
-                    if (!cnt) continue;
-                    Arr g{ nullptr, (char*)arr[a].out + lo[d] * arr[a].elem, arr[a].elem };
-                    g.dev = (char*)m->gathered[a] + arr[a].elem * rows * d;
-                    C25519_RC(run_batch(cnt, { g }, [](void**, size_t, size_t, hipStream_t) -> int { return 0; }));
+            for (int a = 0; a < na && !rc; a++)
+                if (arr[a].out && arr[a].gather) {
+                    rc = reserve(m->gathered[a], m->gcap[a], arr[a].elem * rows * D);
+                    pinned_out[a] = c25519_host::host_pinned(arr[a].out, n * arr[a].elem);
                 }
+        }
+        for (size_t c = 0; gathers && c < P && !rc; c++) {
+            {   // every device has enqueued piece c: its event says when the rows are there
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { for (int d = 0; d < D; d++) if (enq[d] <= c) return false; return true; });
+                if (any_failed) break;                                 // the workers' wait() below reports it
             }
-            return 0;
-        });
-        return m->worker[0]->wait();
+            const size_t r0 = c * chunk, cnt = rows - r0 < chunk ? rows - r0 : chunk;
+            // 2. the one exchange step, for this piece: every device's rows of each gathered output -> devices[0].
+            //    Block d of piece c lands at gathered + elem * (D * r0 + d * cnt); a short shard sends pad rows.
+            auto gather_piece = [&]() -> int {
+                for (int d = 0; d < D; d++)
+                    if (piece_ev[d][c]) C25519_TRY(hipStreamWaitEvent(m->stream[d], piece_ev[d][c], 0));
+                for (int a = 0; a < na; a++) {
+                    if (!arr[a].out || !arr[a].gather) continue;
+                    NCCL_TRY(m, m->rccl.GroupStart());
+                    for (int d = 0; d < D; d++) {
+                        C25519_TRY(hipSetDevice(m->dev[d]));
+                        NCCL_TRY(m, m->rccl.Gather((char*)m->buf[a][d] + r0 * arr[a].elem,
+                                                    d == 0 ? (char*)m->gathered[a] + arr[a].elem * (size_t)D * r0 : nullptr,
+                                                    arr[a].elem * cnt, ncclUint8, 0, m->comm[d], m->stream[d]));
+                    }
+                    NCCL_TRY(m, m->rccl.GroupEnd());
+                }
+                C25519_TRY(hipSetDevice(m->dev[0]));
+                C25519_TRY(hipEventRecord(m->gathered_ev[c], m->stream[0]));
+                return 0;
+            };
+            rc = gather_piece();
+            if (rc) break;
+            // 3. the root hands the piece to the caller while the devices compute the following ones
+            hipEvent_t ev = m->gathered_ev[c];
+            m->drain->submit([&, r0, cnt, ev]() -> int {
+                C25519_TRY(hipStreamWaitEvent(m->drain_stream, ev, 0));
+                for (int a = 0; a < na; a++) {
+                    if (!arr[a].out || !arr[a].gather) continue;
+                    const size_t elem = arr[a].elem;
+                    const char* src = (const char*)m->gathered[a] + elem * (size_t)D * r0;
+                    auto rows_of = [&](int d) -> size_t {            // real (not pad) rows of block d of this piece
+                        const size_t cnt_d = lo[d + 1] - lo[d];
+                        return r0 >= cnt_d ? 0 : (r0 + cnt < cnt_d ? cnt : cnt_d - r0);
+                    };
+                    if (pinned_out[a]) {                               // page-locked destination: DMA straight into it
+                        for (int d = 0; d < D; d++)
+                            if (rows_of(d))
+                                C25519_TRY(hipMemcpyAsync((char*)arr[a].out + (lo[d] + r0) * elem, src + elem * cnt * d, rows_of(d) * elem,
+                                                          hipMemcpyDeviceToHost, m->drain_stream));
+                        continue;
+                    }
+                    int k = -1;
+                    {   // a free pinned slot (the copier hands them back)
+                        std::unique_lock<std::mutex> lk(m->slot_mu);
+                        m->slot_cv.wait(lk, [&] { for (int i = 0; i < c25519_amd_multi::SLOTS; i++) if (!m->slot[i].busy) { k = i; return true; } return false; });
+                        m->slot[k].busy = true;
+                    }
+                    c25519_amd_multi::Slot& sl = m->slot[k];
+                    auto fill = [&]() -> int {
+                        const size_t bytes = elem * cnt * D;
+                        if (sl.cap < bytes) {
+                            if (sl.pinned) { memset(sl.pinned, 0, sl.cap); C25519_TRY(hipHostFree(sl.pinned)); sl.pinned = nullptr; sl.cap = 0; }
+                            C25519_TRY(hipHostMalloc(&sl.pinned, bytes, hipHostMallocDefault));
+                            sl.cap = bytes;
+                        }
+                        if (!sl.ev) C25519_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+                        C25519_TRY(hipMemcpyAsync(sl.pinned, src, bytes, hipMemcpyDeviceToHost, m->drain_stream));
+                        C25519_TRY(hipEventRecord(sl.ev, m->drain_stream));
+                        return 0;
+                    };
+                    const int r = fill();
+                    if (r) { { std::lock_guard<std::mutex> lk(m->slot_mu); sl.busy = false; } m->slot_cv.notify_all(); return r; }
+                    char* out = (char*)arr[a].out;
+                    m->copier->submit([&, k, out, elem, r0, cnt]() -> int {
+                        c25519_amd_multi::Slot& s2 = m->slot[k];
+                        const hipError_t e = hipEventSynchronize(s2.ev);
+                        if (e == hipSuccess) {
+                            // D blocks, each cut into parts: every copy thread takes its share of every block
+                            const int parts = m->copy_pool->ok() ? m->copy_pool->size() : 1;
+                            auto copy = [&](int part) {
+                                for (int d = 0; d < D; d++) {
+                                    const size_t cnt_d = lo[d + 1] - lo[d];
+                                    const size_t real = r0 >= cnt_d ? 0 : (r0 + cnt < cnt_d ? cnt : cnt_d - r0);
+                                    const size_t a0 = real * part / parts, a1 = real * (part + 1) / parts;
+                                    if (a1 > a0)
+                                        memcpy(out + (lo[d] + r0 + a0) * elem, (const char*)s2.pinned + (cnt * d + a0) * elem, (a1 - a0) * elem);
+                                }
+                            };
+                            if (parts > 1) { m->copy_pool->run(parts, copy); m->copy_pool->wait(); }
+                            else copy(0);
+                        }
+                        { std::lock_guard<std::mutex> lk(m->slot_mu); s2.busy = false; }
+                        m->slot_cv.notify_all();
+                        return e == hipSuccess ? 0 : c25519_host::fail(e, "hipEventSynchronize(gathered piece)", __FILE__, __LINE__);
+                    });
+                }
+                return 0;
+            });
+        }
+        for (int d = 0; d < D; d++) { const int r = m->worker[d]->wait(); if (r && !rc) rc = r; }
+        if (gathers) {
+            int r = m->drain->wait();
+            if (r && !rc) rc = r;
+            r = m->copier->wait();
+            if (r && !rc) rc = r;
+            (void)hipSetDevice(m->dev[0]);
+            hipError_t e = hipStreamSynchronize(m->drain_stream);     // direct copies into a page-locked destination
+            if (e != hipSuccess && !rc) rc = c25519_host::fail(e, "hipStreamSynchronize(drain stream)", __FILE__, __LINE__);
+            for (int d = 0; d < D; d++) {                              // the senders' side of the gathers: buf is free again
+                (void)hipSetDevice(m->dev[d]);
+                e = hipStreamSynchronize(m->stream[d]);
+                if (e != hipSuccess && !rc) rc = c25519_host::fail(e, "hipStreamSynchronize(gather stream)", __FILE__, __LINE__);
+            }
+        }
+        return rc;
     };
     const int rc = body();
     (void)hipSetDevice(prev);
@@ -299,6 +444,13 @@ int c25519_amd_multi_create(c25519_amd_multi** out, const int* devices, int n_de
             m->worker.emplace_back(new Worker());
             m->worker.back()->start(devices[d]);
         }
+        C25519_TRY(hipSetDevice(devices[0]));
+        C25519_TRY(hipStreamCreateWithFlags(&m->drain_stream, hipStreamNonBlocking));
+        m->drain.reset(new Worker());
+        m->drain->start(devices[0]);
+        m->copier.reset(new Worker());
+        m->copier->start(devices[0]);
+        m->copy_pool.reset(new c25519_host::HelperPool(std::thread::hardware_concurrency() >= 16 ? 4 : 2));
         return 0;
     };
     int rc = 0;
@@ -315,6 +467,18 @@ void c25519_amd_multi_destroy(c25519_amd_multi* m)
     int prev = 0;
     (void)hipGetDevice(&prev);
     for (auto& w : m->worker) w->shutdown();
+    if (m->drain) m->drain->shutdown();
+    if (m->copier) m->copier->shutdown();
+    m->copy_pool.reset();
+    if (!m->dev.empty()) {
+        (void)hipSetDevice(m->dev[0]);
+        for (hipEvent_t e : m->gathered_ev) (void)hipEventDestroy(e);
+        for (auto& sl : m->slot) {                                    // results passed through the pinned slots
+            if (sl.pinned) { memset(sl.pinned, 0, sl.cap); (void)hipHostFree(sl.pinned); }
+            if (sl.ev) (void)hipEventDestroy(sl.ev);
+        }
+        if (m->drain_stream) { (void)hipStreamSynchronize(m->drain_stream); (void)hipStreamDestroy(m->drain_stream); }
+    }
     for (size_t d = 0; d < m->dev.size(); d++) {
         (void)hipSetDevice(m->dev[d]);
         if (m->stream[d]) (void)hipStreamSynchronize(m->stream[d]);
@@ -331,6 +495,13 @@ void c25519_amd_multi_destroy(c25519_amd_multi* m)
 }
 
 int c25519_amd_multi_device_count(const c25519_amd_multi* m) { return m ? (int)m->dev.size() : 0; }
+
+int c25519_amd_multi_set_gather(c25519_amd_multi* m, int on)
+{
+    if (!m) return bad_arg("null handle");
+    m->gather = on != 0;
+    return 0;
+}
 
 int curve25519_dh_CreateSharedKey_multi(c25519_amd_multi* m, unsigned char* shared, const unsigned char* pk,
                                         unsigned char* sk, size_t n)

@@ -142,15 +142,21 @@ int ed25519_Verify_Check_dev(void *verdict, const void *ctx, const void *sig, co
  * A handle owns ONE WORKER THREAD PER DEVICE.  A call cuts the batch into contiguous shards (device d owns elements
  * [n*d/n_dev, n*(d+1)/n_dev)); every worker runs its shard through the same pinned, pieced pipeline as the single-GPU
  * *_batch functions (all devices upload over their own PCIe links at the same time, nothing is copied from or to
- * pageable memory), results stay resident on the device, each result array is gathered to devices[0] with ONE grouped
- * ncclGather (RCCL, /opt/rocm/include/rccl/rccl.h:745; loaded with dlopen on first use) and the root's worker streams
- * the gathered slab to the caller.  A handle of one device skips the gather.  Host pointers, synchronous, same byte
- * layouts and results as the *_batch functions.  The handle also owns one stream and one RCCL communicator per device and
- * grow-only result buffers (zeroed before they are freed); it is not thread-safe (one call at a time per handle). */
+ * pageable memory), results stay resident on the device and are gathered to devices[0] with a grouped ncclGather (RCCL,
+ * /opt/rocm/include/rccl/rccl.h:745; loaded with dlopen on first use) while a second thread on the root streams the
+ * gathered rows to the caller -- piece by piece: every device cuts its shard at the same rows, a piece is gathered as soon
+ * as every device has computed it and handed over while the devices compute the next ones, so only the last piece's
+ * gather and download are exposed.  A handle of one device skips the gather.  With host destinations every result row of the gather mode crosses the ROOT's
+ * PCIe link; c25519_amd_multi_set_gather(m, 0) leaves the gather out and lets every device hand its own rows to the
+ * caller over its own link (same results; the gather is what BASELINE.json's north_star names, and the default).
+ * Host pointers, synchronous, same byte layouts and results as the *_batch functions.  The handle also owns one stream and
+ * one RCCL communicator per device and grow-only result buffers (zeroed before they are freed); it is not thread-safe
+ * (one call at a time per handle). */
 typedef struct c25519_amd_multi c25519_amd_multi;
 int  c25519_amd_multi_create(c25519_amd_multi **m, const int *devices, int n_dev);
 void c25519_amd_multi_destroy(c25519_amd_multi *m);
 int  c25519_amd_multi_device_count(const c25519_amd_multi *m);
+int  c25519_amd_multi_set_gather(c25519_amd_multi *m, int on);   /* 1 (default): gather to devices[0]; 0: per-device downloads */
 int curve25519_dh_CreateSharedKey_multi(c25519_amd_multi *m, unsigned char *shared, const unsigned char *pk,
                                         unsigned char *sk, size_t n);
 int ed25519_SignMessage_multi(c25519_amd_multi *m, unsigned char *sig, const unsigned char *priv,

@@ -724,14 +724,15 @@ def test_reference_openssl_harness_runs_on_this_library():
     assert "Mismatched" not in p.stdout and p.stdout.count("ratio") == 4
 
 
-@pytest.mark.parametrize("force_gather", [False, True])
-def test_c_abi_multi_device_entry_points(api, force_gather, monkeypatch):
-    """The C-level multi-GPU entry points (one worker thread and pinned pipeline per device, one grouped ncclGather per
-    output to devices[0]) with EVERY device this box has: on a multi-GPU node that is a real RCCL communicator over xGMI,
-    on a one-GPU box a communicator of one rank -- the shard / worker / gather / slab-download code is the same for any
-    count.  Results are the fixture's (the reference's) bytes; sizes that do not divide by the device count included.
-    A one-device handle normally skips the gather (its own rows would come back); force_gather makes it take the N > 1
-    path anyway."""
+@pytest.mark.parametrize("force_gather,gather_mode", [(False, 1), (True, 1), (True, 0)])
+def test_c_abi_multi_device_entry_points(api, force_gather, gather_mode, monkeypatch):
+    """The C-level multi-GPU entry points (one worker thread and pinned pipeline per device, grouped ncclGather of the
+    result rows to devices[0], segment by segment, a drain thread on the root) with EVERY device this box has: on a
+    multi-GPU node that is a real RCCL communicator over xGMI, on a one-GPU box a communicator of one rank -- the shard /
+    worker / segment / gather / hand-over code is the same for any count.  Results are the fixture's (the reference's)
+    bytes; sizes that do not divide by the device count included.  A one-device handle normally skips the gather (its own
+    rows would come back); force_gather makes it take the N > 1 path anyway (two segments for the big batch), and
+    c25519_amd_multi_set_gather(h, 0) switches the gather off again: every device downloads its own rows."""
     from curve25519_amd import _lib
     if force_gather:
         monkeypatch.setenv("C25519_AMD_MULTI_FORCE_GATHER", "1")
@@ -742,6 +743,7 @@ def test_c_abi_multi_device_entry_points(api, force_gather, monkeypatch):
     _lib.check(L.c25519_amd_multi_create(C.byref(h), devs, ndev), "c25519_amd_multi_create")
     try:
         assert L.c25519_amd_multi_device_count(h) == ndev
+        _lib.check(L.c25519_amd_multi_set_gather(h, gather_mode), "c25519_amd_multi_set_gather")
         g = {k: np.ascontiguousarray(R1024[k]) for k in R1024.files}     # materialise once: ctypes gets raw pointers
         for n in (1024, 1000, 1023, ndev, 1):
             sk, pk = g["x_sk"][:n].copy(), g["x_pk"][:n].copy()
@@ -766,6 +768,17 @@ def test_c_abi_multi_device_entry_points(api, force_gather, monkeypatch):
         _lib.check(L.curve25519_dh_CreateSharedKey_multi(h, a.ctypes.data, pk.ctypes.data, sk.ctypes.data, n), "x25519 multi (big)")
         _lib.check(L.curve25519_dh_CreateSharedKey_batch(b.ctypes.data, pk.ctypes.data, sk2.ctypes.data, n), "x25519 batch (big)")
         assert np.array_equal(a, b) and np.array_equal(sk, sk2)
+        # ... and the two Ed25519 operations at that size (64-byte rows and int32 verdicts through the segments)
+        esk, msg = synth.ed25519_inputs(n)
+        pub, priv = api.ed25519_CreateKeyPair(esk)
+        s1, s2 = np.empty((n, 64), np.uint8), np.empty((n, 64), np.uint8)
+        _lib.check(L.ed25519_SignMessage_multi(h, s1.ctypes.data, priv.ctypes.data, msg.ctypes.data, 32, n), "sign multi (big)")
+        _lib.check(L.ed25519_SignMessage_batch(s2.ctypes.data, priv.ctypes.data, msg.ctypes.data, 32, n), "sign batch (big)")
+        assert np.array_equal(s1, s2)
+        vsig, vmsg, bad = synth.corrupt_for_verify(s1, msg)
+        ok = np.full(n, -1, np.int32)
+        _lib.check(L.ed25519_VerifySignature_multi(h, ok.ctypes.data, vsig.ctypes.data, pub.ctypes.data, vmsg.ctypes.data, 32, n), "verify multi (big)")
+        assert np.array_equal(ok == 0, bad) and set(np.unique(ok)) <= {0, 1}
     finally:
         L.c25519_amd_multi_destroy(h)
     bad = (C.c_int * 1)(63)
@@ -809,22 +822,27 @@ def test_host_pointer_api_keeps_up_with_the_device_rate(api):
     assert ratio >= 0.8, best                 # measured 0.85-0.90; round 1 was 0.48
 
 
-def test_bench_self_launches_two_ranks():
-    """`python bench.py --gpus 2` exactly as the driver invokes it, on a box with ONE GPU: C25519_BENCH_SHARE_GPU lets the
-    two ranks share it (gloo gather, since RCCL refuses a duplicate device), so the self-launch under
+@pytest.mark.parametrize("ranks,batch", [(2, 1 << 16), (8, 1 << 14)])
+def test_bench_self_launches_two_ranks(ranks, batch):
+    """`python bench.py --gpus N` exactly as the driver invokes it, on a box with ONE GPU: C25519_BENCH_SHARE_GPU lets the
+    N ranks share it (gloo gather, since RCCL refuses a duplicate device), so the self-launch under
     torch.distributed.run, the rank / seed / gather bookkeeping and the single JSON line from rank 0 are exercised
-    for real.  (The RCCL gather itself runs in --dist-selftest with a world of one.)"""
+    for real -- with 2 ranks and with the 8 of the node the scaling bench runs on.  (The RCCL gather itself runs in
+    --dist-selftest with a world of one.)"""
     import torch
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    if torch.cuda.device_count() < 2:
+    if torch.cuda.device_count() < ranks:
         env["C25519_BENCH_SHARE_GPU"] = "1"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--batch", str(1 << 16), "--no-cpu"], capture_output=True, text=True, timeout=900, env=env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
+                        "--batch", str(batch), "--no-cpu"], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     assert len(p.stdout.strip().splitlines()) == 1, p.stdout
     line = json.loads(p.stdout)
-    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2 << 16 and line["value"] > 0
-    assert line["verify"]["n_gpus"] == 2 and line["verify"]["rejects_exactly_the_corrupted"] is True
+    assert line["n_gpus"] == ranks and line["config"]["global_batch"] == ranks * batch and line["value"] > 0
+    assert sorted(r["rank"] for r in line["per_rank"]) == list(range(ranks))
+    assert all(r["kernel_ms"] > 0 and r["step_ms"] > 0 for r in line["per_rank"])
+    assert line["verify"]["n_gpus"] == ranks and line["verify"]["rejects_exactly_the_corrupted"] is True
+    assert len(line["verify"]["per_rank"]) == ranks
 
 
 def test_lattice_fast_path_and_reference_order_agree(api, oracle):

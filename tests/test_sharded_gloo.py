@@ -1,4 +1,5 @@
-"""CPU suite, part 4: the N > 1 path.  world_size-2 (and 3) gloo groups run the sharding + gather layer of
+"""CPU suite, part 4: the N > 1 path.  world_size-2, -3 and -8 gloo groups (8 = the node the scaling bench runs on: n = 8k + 5,
+a 2^23-shaped mixed split with equal thirds, and more ranks than elements) run the sharding + gather layer of
 curve25519_amd/sharded.py with an oracle-backed engine standing in for the HIP engine (tests may use the
 oracle; the product never does).  Checks: contiguous shards, one gather to the root, uneven shard sizes,
 empty shards, result == the unsharded oracle result."""
@@ -97,7 +98,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,n", [(2, 96), (2, 7), (3, 10), (2, 1)])
+@pytest.mark.parametrize("world,n", [(2, 96), (2, 7), (3, 10), (2, 1), (8, 45), (8, 48), (8, 5)])
 def test_sharded_matches_unsharded(world, n, oracle):
     from curve25519_amd import synth
     ctx = mp.get_context("spawn")

@@ -110,20 +110,33 @@ ndev = min(api.device_count(), 8)
 mh = C.c_void_p()
 assert L.c25519_amd_multi_create(C.byref(mh), (C.c_int * ndev)(*range(ndev)), ndev) == 0
 m32, m64, mok = np.zeros((n, 32), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32)
-for name, mfn, bfn in (("x25519", lambda: L.curve25519_dh_CreateSharedKey_multi(mh, P(m32), P(pk), P(sk), n),
-                        lambda: L.curve25519_dh_CreateSharedKey_batch(P(h32), P(pk), P(sk), n)),
-                       ("sign", lambda: L.ed25519_SignMessage_multi(mh, P(m64), P(priv), P(msg), 32, n),
-                        lambda: L.ed25519_SignMessage_batch(P(h64), P(priv), P(msg), 32, n)),
-                       ("verify", lambda: L.ed25519_VerifySignature_multi(mh, P(mok), P(sig), P(pub), P(msg), 32, n),
-                        lambda: L.ed25519_VerifySignature_batch(P(hok), P(sig), P(pub), P(msg), 32, n))):
-    assert mfn() == 0
-    tm, tb = host_rate_pair(mfn, bfn)                 # alternating calls, medians
-    rows[name].update(multi_devices=ndev, multi_ms=round(tm * 1e3, 3), multi_Mops=round(n / tm / 1e6, 2),
-                      batch_ms_interleaved=round(tb * 1e3, 3), multi_over_batch=round(tb / tm, 3))
-    print(f"{name:7s} *_multi over {ndev} device(s) {tm * 1e3:8.2f} ms = {n / tm / 1e6:7.1f} M ops/s | *_batch alternating with it "
-          f"{tb * 1e3:8.2f} ms | ratio to *_batch {tb / tm:.2f}")
+# three shapes of the same call: as shipped (a one-device handle skips the gather), the N > 1 path forced on the devices
+# that exist (resident results, piece-wise grouped ncclGather, the root's drain and copy threads), and the gather switched off
+# (every device downloads its own rows: c25519_amd_multi_set_gather(h, 0))
+for label, force, gather in (("as shipped", False, 1), ("gather path forced", True, 1), ("gather off", True, 0)):
+    if force:
+        os.environ["C25519_AMD_MULTI_FORCE_GATHER"] = "1"
+    else:
+        os.environ.pop("C25519_AMD_MULTI_FORCE_GATHER", None)
+    assert L.c25519_amd_multi_set_gather(mh, gather) == 0
+    for name, mfn, bfn in (("x25519", lambda: L.curve25519_dh_CreateSharedKey_multi(mh, P(m32), P(pk), P(sk), n),
+                            lambda: L.curve25519_dh_CreateSharedKey_batch(P(h32), P(pk), P(sk), n)),
+                           ("sign", lambda: L.ed25519_SignMessage_multi(mh, P(m64), P(priv), P(msg), 32, n),
+                            lambda: L.ed25519_SignMessage_batch(P(h64), P(priv), P(msg), 32, n)),
+                           ("verify", lambda: L.ed25519_VerifySignature_multi(mh, P(mok), P(sig), P(pub), P(msg), 32, n),
+                            lambda: L.ed25519_VerifySignature_batch(P(hok), P(sig), P(pub), P(msg), 32, n))):
+        m32[:] = 0; m64[:] = 0; mok[:] = -1
+        assert mfn() == 0
+        assert np.array_equal(m32 if name == "x25519" else m64 if name == "sign" else mok,
+                              h32 if name == "x25519" else h64 if name == "sign" else hok), (label, name)
+        tm, tb = host_rate_pair(mfn, bfn)                 # alternating calls, medians
+        key = {"as shipped": "multi", "gather path forced": "multi_forced_gather", "gather off": "multi_gather_off"}[label]
+        rows[name].update({"multi_devices": ndev, key + "_ms": round(tm * 1e3, 3), key + "_Mops": round(n / tm / 1e6, 2),
+                           key + "_batch_ms_interleaved": round(tb * 1e3, 3), key + "_over_batch": round(tb / tm, 3)})
+        print(f"{name:7s} *_multi over {ndev} device(s), {label:18s} {tm * 1e3:8.2f} ms = {n / tm / 1e6:7.1f} M ops/s | *_batch "
+              f"alternating with it {tb * 1e3:8.2f} ms | ratio to *_batch {tb / tm:.2f}")
+os.environ.pop("C25519_AMD_MULTI_FORCE_GATHER", None)
 L.c25519_amd_multi_destroy(mh)
-assert np.array_equal(m32, h32) and np.array_equal(m64, h64) and np.array_equal(mok, hok)
 assert np.array_equal(hok, np.ones(n, np.int32)) and np.array_equal(reg["hok"], hok)
 assert np.array_equal(reg["h32"], h32) and np.array_equal(reg["h64"], h64)
 for v in reg.values():
