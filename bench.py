@@ -20,7 +20,9 @@ BOTH, each with its own W warm-up + K timed steps bracketed by barrier + synchro
 roofline.verify / roofline.sign repeat the two side results inside the contract's roofline object.
 --workload mixed times BASELINE.json configs[4]: X25519 + sign + verify by contiguous thirds of each GPU's 2^20,
 one gather per output type.  Each roofline carries the HBM fraction the contract asks for (tiny by construction)
-and `valu`: algorithmic 32x32 MACs against the measured v_mad_u64_u32 issue peak, the roof that binds.
+and `valu`: algorithmic 32x32 MACs against the measured v_mad_u64_u32 issue peak, the roof that binds, plus -- measured
+live on an un-profiled launch of the probe build (s_memtime inside the kernel) -- the SIMD cycles one ladder step costs
+against the issue model of its instruction stream (`issue_model_frac`) and the shader clock it ran at.
 cpu_baseline: the reference's portable-C path (oracle/_ref) or the oracle port on this host's cores.
 """
 import argparse
@@ -49,7 +51,7 @@ EXECUTED_MACS_PER_OP = {"x25519": 191400, "sign": 25100, "verify": 186400}
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md
 
 PASS_KERNELS = {
-    "x25519": ("k_x25519_fused",),
+    "x25519": ("k_x25519_ladder", "k_batch_invert<FinishX25519>"),     # batches above 2^18 (k_x25519_fused below)
     "sign": ("k_ed25519_sign_mult", "k_batch_invert<FinishPack>", "k_ed25519_sign_finish"),
     "verify": ("k_ed25519_verify_fast_scalars", "k_ed25519_verify_fast_points", "k_ed25519_verify_fast_walk",
                "k_ed25519_verify_slow"),                # (the slow list is empty for on-curve keys: a ~10 us launch)
@@ -113,50 +115,68 @@ def measured_traffic(kernels):
         return None, None
 
 
-def measured_valu_busy(kernels):
-    """Fraction of SIMD cycles in which a VALU instruction was executing, over the pass's kernels, from the committed PMC
-    pass: sum(SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs) / sum(GRBM_GUI_ACTIVE / 8 XCDs) -- the gfx9 VALUBusy formula, the two
-    counters taken in the same rocprofv3 pass.  Near 1.0 means the pass is bound by VALU issue at the clock the chip
-    sustained under it, whatever share of those instructions are multiplies."""
-    try:
-        path = latest_profile("r[0-9][0-9]_pmc.json")
-        with open(path) as f:
-            d = json.load(f)
-        def rec(name):
-            hits = [v for k, v in d.items() if name.rstrip(">") in k and "<true>" not in k]
-            return hits[0]
-        act = sum(rec(k)["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024 for k in kernels)
-        gui = sum(rec(k)["GRBM_GUI_ACTIVE_same_pass"] / 8.0 for k in kernels)
-        return round(act / gui, 4), os.path.basename(path)
-    except Exception:
-        return None, None
+def issue_model(n, live):
+    """SIMD cycles per ladder step of the X25519 ladder kernel, measured by the s_memtime stamps of the probe build
+    (curve25519_amd/libcurve25519_amd_probe.so, `python -m curve25519_amd.build --probe`) on an un-profiled launch of
+    this very batch, against the issue model of the step's instruction stream: sum over instruction classes of count x
+    cycle cost (tools/cycle_probe.py; class costs measured by tools/ubench/mad_peak).  live=False, or no probe build:
+    the committed measurement of the round."""
+    from curve25519_amd import build as _b
+    if live and os.path.exists(_b.PROBE_LIB):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import cycle_probe
+            ms, rec = cycle_probe.measure(_b.PROBE_LIB, n, fused=n <= (1 << 18), reps=3)
+            out = cycle_probe.summary(ms, rec)[0]
+            out["source"] = "live: s_memtime stamps of libcurve25519_amd_probe.so, this run"
+            return out
+        except Exception as e:                                   # a measurement leg must not take the bench line down
+            print(f"bench.py: cycle probe failed ({e!r}); falling back to the committed measurement", file=sys.stderr)
+    path = latest_profile("r[0-9][0-9]_cycle_probe.json")
+    if not path:
+        return None
+    with open(path) as f:
+        out = json.load(f)
+    out["source"] = f"profiles/{os.path.basename(path)} (committed measurement, not this run)"
+    return out
 
 
-def roofline_for(wl, n, kernel_ms):
-    """The contract's roofline object for one pass of workload `wl` (n operations, mean kernel time kernel_ms)."""
+def roofline_for(wl, n, kernel_ms, probe=None):
+    """The contract's roofline object for one pass of workload `wl` (n operations, mean kernel time kernel_ms).
+    probe: issue_model()'s result for the X25519 pass."""
     kernel_s = kernel_ms * 1e-3
     achieved_gbs = BYTES_PER_OP[wl] * n / kernel_s / 1e9
     peak_mac, peak_src = measured_mad_peak()
-    traffic, traffic_src = measured_traffic(PASS_KERNELS[wl])
+    kernels = PASS_KERNELS[wl] if wl != "x25519" or n > (1 << 18) else ("k_x25519_fused",)
+    traffic, traffic_src = measured_traffic(kernels)
     achieved_mac = MACS_PER_OP[wl] * n / kernel_s
-    valu_busy, busy_src = measured_valu_busy(PASS_KERNELS[wl])
+    valu = {"bound": "valu v_mad_u64_u32 issue", "achieved": round(achieved_mac / 1e12, 4),
+            "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s",
+            "frac": round(achieved_mac / peak_mac, 4) if peak_mac else None,
+            "algorithmic_macs_per_op": MACS_PER_OP[wl],
+            "executed_macs_per_op": EXECUTED_MACS_PER_OP[wl],
+            "frac_executed": round(EXECUTED_MACS_PER_OP[wl] * n / kernel_s / peak_mac, 4) if peak_mac else None,
+            "peak_source": f"profiles/{peak_src}" if peak_src else None,
+            "peak_policy": "the fastest box's 8-waves-per-SIMD v_mad_u64_u32 stream of all committed rounds (wall-clock rate)"}
+    if probe:
+        # the fraction that says how close the kernel is to what its instruction stream allows: class-cost cycles of
+        # one ladder step / SIMD cycles measured per step (un-profiled, in-kernel).  Headline = measured class costs with
+        # every VOP2 instruction finding a partner from another wave (the best this stream can do at four waves).
+        valu.update({"issue_model_frac": probe.get("issue_model_frac_measured_vop2_paired"),
+                     "issue_model_frac_nominal_4_4_2": probe.get("issue_model_frac_nominal"),
+                     "simd_cycles_per_ladder_step": probe.get("simd_cycles_per_ladder_step"),
+                     "ladder_step_instructions": probe.get("ladder_step_instructions"),
+                     "vop2_cycles_implied": probe.get("vop2_cycles_implied"),
+                     "shader_clock_GHz": probe.get("shader_clock_GHz"),
+                     "issue_model_source": probe.get("source")})
     return {
         "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
         "traffic_source": f"profiles/{traffic_src}: (2*FETCH_SIZE + WRITE_SIZE) KiB per pass" if traffic_src else None,
-        "kernel": " + ".join(PASS_KERNELS[wl]), "kernel_ms": round(kernel_ms, 4),
+        "kernel": " + ".join(kernels), "kernel_ms": round(kernel_ms, 4),
         "algorithmic_bytes_per_launch": BYTES_PER_OP[wl] * n,
         "note": "VALU-integer bound path: the HBM fraction is tiny by construction, `valu` is the roof that binds",
-        "valu": {"bound": "valu v_mad_u64_u32 issue", "achieved": round(achieved_mac / 1e12, 4),
-                 "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s",
-                 "frac": round(achieved_mac / peak_mac, 4) if peak_mac else None,
-                 "algorithmic_macs_per_op": MACS_PER_OP[wl],
-                 "executed_macs_per_op": EXECUTED_MACS_PER_OP[wl],
-                 "frac_executed": round(EXECUTED_MACS_PER_OP[wl] * n / kernel_s / peak_mac, 4) if peak_mac else None,
-                 "peak_source": f"profiles/{peak_src}" if peak_src else None,
-                 "valu_busy": valu_busy,
-                 "valu_busy_source": f"profiles/{busy_src}: SQ_ACTIVE_INST_VALU*4/1024 over GRBM_GUI_ACTIVE/8, same PMC pass"
-                                     if busy_src else None},
+        "valu": valu,
     }
 
 
@@ -195,6 +215,10 @@ def cpu_baseline(quick=False):
         sign = lambda t: orc.ed25519_sign(priv, msg, threads=t)               # noqa: E731
         verify = lambda sg, t: orc.ed25519_verify(sg, pub, msg, threads=t)    # noqa: E731
 
+    def np_equal(a, b):
+        import numpy as np
+        return np.array_equal(a, b)
+
     def rate(fn, count):
         t0 = time.perf_counter()
         out = fn()
@@ -210,6 +234,18 @@ def cpu_baseline(quick=False):
     multi, n = done / (time.perf_counter() - t0), done
     sign_rate, sig = rate(lambda: sign(cores), n_ed)
     verify_rate, ok = rate(lambda: verify(sig, cores), n_ed)
+    asm = None
+    if Reference.available(asm=True):                  # the reference's x86-64 assembly back-end (its README's headline path)
+        ra = Reference(asm=True)
+        a1, _ = rate(lambda: ra.x25519_shared_threaded(pk[:n1], sk[:n1], 1), n1)
+        na = min(n, 4096 * cores)
+        am, _ = rate(lambda: ra.x25519_shared_threaded(pk[:na], sk[:na], cores), na)
+        asig_rate, asig = rate(lambda: ra.ed25519_sign_threaded(priv, msg, cores), n_ed)
+        aver_rate, aok = rate(lambda: ra.ed25519_verify_threaded(asig, pub, msg, cores), n_ed)
+        asm = {"kind": "reference, x86-64 assembly back-end (source/asm64; oracle/_ref/libcurve25519_ref_asm.so)",
+               "value": round(am, 1), "unit": "X25519 shared-key ops/s", "cores": cores,
+               "single_core_ops_per_s": round(a1, 1), "ed25519_sign_per_s": round(asig_rate, 1),
+               "ed25519_verify_per_s": round(aver_rate, 1), "outputs_equal_portable_c": bool(np_equal(asig, sig) and aok.all())}
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -222,7 +258,7 @@ def cpu_baseline(quick=False):
             "single_core_ops_per_s": round(single, 1), "ed25519_sign_per_s": round(sign_rate, 1),
             "ed25519_verify_per_s": round(verify_rate, 1), "ed25519_verify_all_valid": bool(ok.all()),
             "host_logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
-            "cpu_model": model}
+            "cpu_model": model, "asm_backend": asm}
 
 
 def free_port():
@@ -356,7 +392,12 @@ def main():
         # empty wave of workgroups fills up with the next operation's instead of draining alone
         streams = [torch.cuda.Stream(dev) for _ in passes] if len(passes) > 1 and not args.one_stream else None
 
-        def step(evs=None):
+        def step(evs=None, origin=None):
+            if origin is not None:
+                origin.record()                  # on the current stream, ahead of every pass of the step
+                if streams:
+                    for st in streams:
+                        st.wait_event(origin)
             for j, p in enumerate(passes):
                 with torch.cuda.stream(streams[j]) if streams else contextlib.nullcontext():
                     dst = ogs[j].next_buffer() if ogs[j] else outs[j]
@@ -379,15 +420,21 @@ def main():
         finish()
         events = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in passes]
                   for _ in range(args.steps)]
+        origins = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         barrier()
         t0 = time.perf_counter()
         for k in range(args.steps):
-            step(events[k])
+            step(events[k], origins[k])
         finish()                             # every gather of the timed steps has completed inside the timed region
         barrier()
         elapsed = time.perf_counter() - t0
         kms = [sum(events[k][j][0].elapsed_time(events[k][j][1]) for k in range(args.steps)) / max(1, args.steps)
                for j in range(len(passes))]
+        # device-side span of a step over all its streams: earliest start to latest end of its passes (for one pass per
+        # step this is the pass's own kernel time)
+        run_timed.span_ms = sum(max(origins[k].elapsed_time(events[k][j][1]) for j in range(len(passes)))
+                                - min(origins[k].elapsed_time(events[k][j][0]) for j in range(len(passes)))
+                                for k in range(args.steps)) / max(1, args.steps)
         attribution = None
         if use_dist:
             local_ms = elapsed / max(1, args.steps) * 1e3
@@ -414,10 +461,11 @@ def main():
         return elapsed, kms, outs, attribution
 
     def summarize(p, elapsed, kernel_ms, out, attribution=None, j=0):
+        probe = issue_model(p["n"], live=rank == 0 and not args.no_side) if p["wl"] == "x25519" else None
         r = {"value": round(world * p["n"] * args.steps / elapsed, 1), "unit": "ops/s",
              "ms_per_step": round(elapsed / args.steps * 1e3, 4), "steps": args.steps, "warmup": args.warmup,
              "n_gpus": world, "batch_per_gpu": p["n"], "workload": WORKLOAD_NAME[p["wl"]],
-             "roofline": roofline_for(p["wl"], p["n"], kernel_ms)}
+             "roofline": roofline_for(p["wl"], p["n"], kernel_ms, probe)}
         if attribution:
             r["per_rank"] = [{"rank": a["rank"], "kernel_ms": a["kernel_ms"][j], "step_ms": a["step_ms"],
                               "gather_ms_alone": a["gather_ms_alone"]} for a in attribution]
@@ -434,8 +482,10 @@ def main():
         passes = [make_x25519(x1 - x0, x0), make_sign(s1 - s0, s0), make_verify(v1 - v0, v0)]
         elapsed, kms, outs, attr = run_timed(passes)
         parts = [summarize(p, elapsed, k, o, attr, j) for j, (p, k, o) in enumerate(zip(passes, kms, outs))]
-        # on three streams the passes' event spans overlap: the step's wall time is what the kernels took together
-        kernel_ms = sum(kms) if args.one_stream else elapsed / args.steps * 1e3
+        # on three streams the passes' event spans overlap: the device-side span of the step (earliest start event to latest
+        # end event over the three streams) is what the kernels took together -- not the wall time, which also holds the
+        # gather submissions and the host's launch overhead
+        kernel_ms = sum(kms) if args.one_stream else run_timed.span_ms
         bytes_per_launch = sum(BYTES_PER_OP[p["wl"]] * p["n"] for p in passes)
         macs = sum(MACS_PER_OP[p["wl"]] * p["n"] for p in passes)
         peak_mac, peak_src = measured_mad_peak()
@@ -448,6 +498,7 @@ def main():
                          "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s",
                          "frac": round(macs / (kernel_ms * 1e-3) / peak_mac, 4) if peak_mac else None},
                 "streams": 1 if args.one_stream else len(passes),
+                "kernel_ms_is": "sum of the passes' event times" if args.one_stream else "device-side span over the streams (events)",
                 "parts": {p["wl"]: {"n": p["n"], ("kernel_ms" if args.one_stream else "span_ms_overlapping"): round(k, 4)}
                           for p, k in zip(passes, kms)}}
         primary = {"value": round(world * n * args.steps / elapsed, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -475,7 +526,11 @@ def main():
                               "kernel_ms": s["roofline"]["kernel_ms"], "hbm_frac": s["roofline"]["frac"],
                               "achieved_GBps": s["roofline"]["achieved"], "traffic": s["roofline"]["traffic"],
                               "algorithmic_bytes_per_launch": s["roofline"]["algorithmic_bytes_per_launch"],
-                              "valu_frac": s["roofline"]["valu"]["frac"], "kernel": s["roofline"]["kernel"]}
+                              # two fractions of the MAD roof: the reference's operation count / time (a speed-up where the
+                              # device does less work than the reference) and what the kernels really issue / time
+                              "valu_frac_algorithmic": s["roofline"]["valu"]["frac"],
+                              "valu_frac_executed": s["roofline"]["valu"]["frac_executed"],
+                              "kernel": s["roofline"]["kernel"]}
         result = {
             "metric": METRIC_NAME[wl],
             "value": primary["value"], "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1,6 +1,9 @@
 """Builds the gfx950 shared library (hipcc cross-compiles without a GPU).
 
     python -m curve25519_amd.build          # -> curve25519_amd/libcurve25519_amd.so
+    python -m curve25519_amd.build --probe  # -> curve25519_amd/libcurve25519_amd_probe.so, the measurement build
+                                            #    (-DC25519_CYCLE_PROBE=1: s_memtime stamps in the X25519 kernels, read by
+                                            #    tools/cycle_probe.py and bench.py; never loaded by the product)
 
 The .so is git-ignored but travels with gpurun snapshots; it is rebuilt when any source under
 csrc/ or include/ is newer.
@@ -14,6 +17,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libcurve25519_amd.so")
+PROBE_LIB = os.path.join(PKG, "libcurve25519_amd_probe.so")
 ARCH = "gfx950"
 
 
@@ -48,5 +52,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_probe(force: bool = False, level: int = 1) -> str:
+    """the engine alone with the in-kernel cycle probe compiled in (engine.hip: C25519_CYCLE_PROBE)"""
+    if not force and os.path.exists(PROBE_LIB) and all(os.path.getmtime(s) <= os.path.getmtime(PROBE_LIB) for s in _sources()):
+        return PROBE_LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: the gfx950 library cannot be built on this machine")
+    subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
+                           "-pragma-unroll-threshold=131072", f"-DC25519_CYCLE_PROBE={level}",
+                           os.path.join(CSRC, "engine.hip"), "-o", PROBE_LIB + ".tmp"])
+    os.replace(PROBE_LIB + ".tmp", PROBE_LIB)
+    return PROBE_LIB
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--probe" in sys.argv:
+        print(build_probe(force="--force" in sys.argv))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

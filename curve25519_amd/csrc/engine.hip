@@ -66,6 +66,14 @@ C25519_DEV unsigned long long probe_now()
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
     return t;
 }
+// the constant 100 MHz counter: (shader cycles) / (these ticks) * 100 MHz is the shader clock the wave ran at, with no
+// host-side timing involved
+C25519_DEV unsigned long long probe_realtime()
+{
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
 struct SectionTimer {
     unsigned long long *last, *acc;
     C25519_DEV void operator()(int id) const
@@ -126,6 +134,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1
     const bool active = i < n;
 #ifdef C25519_CYCLE_PROBE
     unsigned long long probe_t[6] = {}, probe_sec[10] = {}, probe_last = 0;
+    const unsigned long long probe_rt0 = probe_realtime();
 #endif
     C25519_PROBE_STAMP(0);
     {
@@ -204,6 +213,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1
         // HW_ID (wave / SIMD / CU / SH / SE slot) and XCC_ID of the wave
         rec[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
         for (int q = 0; q < 10; q++) rec[7 + q] = probe_sec[q];
+        rec[17] = probe_rt0;
+        rec[18] = probe_realtime();
     }
 #endif
 }
@@ -220,6 +231,7 @@ __global__ void __launch_bounds__(XL_BLOCK, C25519_XF_WAVES) k_x25519_ladder(u32
     if (i >= n) return;
 #ifdef C25519_CYCLE_PROBE
     unsigned long long probe_t[6] = {};
+    const unsigned long long probe_rt0 = probe_realtime();
 #endif
     C25519_PROBE_STAMP(0);
     u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8];
@@ -239,6 +251,8 @@ __global__ void __launch_bounds__(XL_BLOCK, C25519_XF_WAVES) k_x25519_ladder(u32
         probe_t[2] = probe_t[3] = probe_t[4] = probe_t[1];
         for (int q = 0; q < 6; q++) rec[q] = probe_t[q];
         rec[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        rec[17] = probe_rt0;
+        rec[18] = probe_realtime();
     }
 #endif
 }

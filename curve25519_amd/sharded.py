@@ -146,6 +146,8 @@ class HipEngine:
                 t.record_stream(st)                    # torch's allocator: these blocks are in use on st
         for st in self._side:
             cur.wait_stream(st)
+        for o in outs:
+            o.record_stream(cur)                       # allocated on a side stream, consumed on `cur` (the gathers)
         return tuple(outs)
 
 

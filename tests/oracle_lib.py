@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORC_DIR = os.path.join(ROOT, "oracle")
 ORC_SO = os.path.join(ORC_DIR, "liborc25519.so")
 REF_SO = os.path.join(ORC_DIR, "_ref", "libcurve25519_ref.so")
+REF_ASM_SO = os.path.join(os.path.dirname(REF_SO), "libcurve25519_ref_asm.so")   # the x86-64 assembly back-end (make -C oracle ref-asm)
 
 u8p = C.POINTER(C.c_uint8)
 
@@ -158,14 +159,15 @@ class Oracle:
 
 
 class Reference:
-    """Single-call loops over the real reference library (portable-C back-end)."""
+    """Single-call loops over the real reference library (portable-C back-end; asm=True: its x86-64 assembly back-end)."""
 
     @staticmethod
-    def available():
-        return os.path.exists(REF_SO)
+    def available(asm=False):
+        return os.path.exists(REF_ASM_SO if asm else REF_SO)
 
-    def __init__(self):
-        self.lib = C.CDLL(REF_SO)
+    def __init__(self, asm=False):
+        self.so = REF_ASM_SO if asm else REF_SO
+        self.lib = C.CDLL(self.so)
         L = self.lib
         L.curve25519_dh_CreateSharedKey.argtypes = [u8p, u8p, u8p]
         L.curve25519_dh_CalculatePublicKey.argtypes = [u8p, u8p]
@@ -249,7 +251,7 @@ class Reference:
         pk = np.ascontiguousarray(pk, dtype=np.uint8)
         sk = np.array(sk, dtype=np.uint8, copy=True, order="C")
         out = np.empty_like(pk)
-        rc = self._drv().orc_ref_x25519_shared_batch(REF_SO.encode(), _p(out), _p(pk), _p(sk), pk.shape[0], threads)
+        rc = self._drv().orc_ref_x25519_shared_batch(self.so.encode(), _p(out), _p(pk), _p(sk), pk.shape[0], threads)
         assert rc == 0
         return out, sk
 
@@ -258,7 +260,7 @@ class Reference:
         n = priv.shape[0]
         msg = _rows(np.ascontiguousarray(msg, dtype=np.uint8), n)
         sig = np.empty((n, 64), np.uint8)
-        assert self._drv().orc_ref_ed25519_sign_batch(REF_SO.encode(), _p(sig), _p(priv), _p(msg), msg.shape[1], n, threads) == 0
+        assert self._drv().orc_ref_ed25519_sign_batch(self.so.encode(), _p(sig), _p(priv), _p(msg), msg.shape[1], n, threads) == 0
         return sig
 
     def ed25519_verify_threaded(self, sig, pk, msg, threads):
@@ -267,7 +269,7 @@ class Reference:
         n = sig.shape[0]
         msg = _rows(np.ascontiguousarray(msg, dtype=np.uint8), n)
         ok = np.empty(n, np.int32)
-        assert self._drv().orc_ref_ed25519_verify_batch(REF_SO.encode(), ok.ctypes.data_as(C.POINTER(C.c_int32)), _p(sig),
+        assert self._drv().orc_ref_ed25519_verify_batch(self.so.encode(), ok.ctypes.data_as(C.POINTER(C.c_int32)), _p(sig),
                                                         _p(pk), _p(msg), msg.shape[1], n, threads) == 0
         return ok
 

@@ -25,6 +25,7 @@ HOT = {
     "k_x25519_fused<false, 512>": 128, "k_x25519_fused<true, 512>": 128,
     "k_x25519_fused<false, 256>": 128, "k_x25519_fused<false, 128>": 128, "k_x25519_fused<false, 64>": 128,   # small batches
     "k_x25519_fused<true, 256>": 128, "k_x25519_fused<true, 128>": 128, "k_x25519_fused<true, 64>": 128,
+    "k_x25519_ladder<false>": 128, "k_x25519_ladder<true>": 128,                                          # full batches
     "k_ed25519_verify_fast_scalars": 128, "k_ed25519_verify_fast_points": 168, "k_ed25519_verify_fast_walk": 256,
     "k_ed25519_verify_slow": 256,
     "k_ed25519_sign_mult<false>": 128, "k_ed25519_sign_mult<true>": 128,

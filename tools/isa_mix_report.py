@@ -60,11 +60,13 @@ def show(title, sym, pick):
 
 
 print("# Instruction mix of the hot loops, from hipcc -S of curve25519_amd/csrc/engine.hip (gfx950, the product's flags), tools/isa_mix_report.py.")
-print("# Issue classes as measured by tools/ubench/mad_peak (profiles/r03_mad_peak.txt): v_mad_u64_u32 4 cycles per wave-instruction")
-print("# per SIMD, the other VOP3 / 64-bit / multiply instructions (\"half-rate\") 4, VOP2 adds / ands / subs / moves (\"full-rate\") 2.")
+print("# Issue classes, nominal: v_mad_u64_u32 4 cycles per wave-instruction per SIMD, the other VOP3 / 64-bit / multiply instructions")
+print("# (\"half-rate\") 4, VOP2 adds / ands / subs / moves (\"full-rate\") 2.  Measured in shader cycles at the kernels' four waves per SIMD")
+print("# (tools/ubench/mad_peak with s_memtime, profiles/r04_mad_peak.txt): 4.26 for both 4-cycle classes; a VOP2 instruction 2.13 in a")
+print("# run of its own kind on all waves and ~4 alone between another wave's MADs (2.7 on average inside the ladder, r04_cycle_probe.txt).")
 print("# mad_cycle_share = 4*mad / (4*mad + 4*half + 2*full): the most a VALU-bound kernel can reach of the v_mad_u64_u32 roof")
-print("# with this instruction stream; the kernels are VALU-bound (valu_busy 0.96-1.00, r03_pmc.txt).\n")
-show("X25519 ladder step (5 M + 4 S + a24 + 8 add/sub + select): one trip = one scalar bit", "k_x25519_fusedILb0ELi512", lambda m: 1200 < m['n'] < 1400)
+print("# with this instruction stream.\n")
+show("X25519 ladder step (5 M + 4 S + a24 + 8 add/sub + select): one trip = one scalar bit", "k_x25519_ladderILb0E", lambda m: 1200 < m['n'] < 1400)
 show("verification walk: digit rounds (the biggest loop is one round: 4 doublings or 4 x (doubling + LDS-row addition), then two table-row "
      "additions from prefetched packed rows; inside it the 3-doubling loop and the 4-step sigma loop)", "k_ed25519_verify_fast_walk", lambda m: m['n'] > 800)
 show("verification points kernel: the squaring loops of the square root (99-101 instructions per squaring) and the table-build loop",

@@ -287,7 +287,7 @@ int main(int argc, char** argv)
     FILE* cj = argc > 2 ? fopen(argv[2], "w") : nullptr;
     bool cfirst = true;
     if (cj) fprintf(cj, "{\"unit\": \"SIMD cycles per wave-instruction\", \"cycles\": {\n");
-    printf("device %s, %d CUs; 8 waves per SIMD, ~65536 instructions per wave, best of 5\n", prop.name, cus);
+    printf("device %s, %d CUs; 8 waves per SIMD launched (6 resident at a time: 74 VGPRs), ~65536 instructions per wave, best of 5\n", prop.name, cus);
     bool first = true;
     for (const Row& r : rows) {
         const int trips = 65536 / r.per_trip;
@@ -303,10 +303,11 @@ int main(int argc, char** argv)
             if (rep && ms < best) { best = ms; cycles = longest_wave(blocks); }
         }
         const double rate = r.scale * (double)blocks * 4 * (double)trips * r.per_trip * 64 / (best * 1e-3);
-        const double cpi = cycles / (8.0 * trips * r.per_trip);             // SIMD cycles per wave-instruction
-        printf("%-78s %8.3f ms  %7.2f T lane-op/s  %5.2f cycles/instr  %5.3f GHz\n", r.name, best, rate / 1e12, cpi, cycles / (best * 1e6));
+        // (no cycle figure for these rows: the loops hold 74 VGPRs, so six of a SIMD's eight waves are resident and the other
+        // two queue behind them -- the longest wave is not the launch.  The by-occupancy blocks below launch what fits.)
+        (void)cycles;
+        printf("%-78s %8.3f ms  %7.2f T lane-op/s\n", r.name, best, rate / 1e12);
         if (jf) { fprintf(jf, "%s  \"%s\": %.4e", first ? "" : ",\n", r.key, rate); first = false; }
-        if (cj) { fprintf(cj, "%s  \"%s\": %.4f", cfirst ? "" : ",\n", r.key, cpi); cfirst = false; }
     }
     if (jf) fprintf(jf, "\n},\n\"by_occupancy\": {\n");
     first = true;
