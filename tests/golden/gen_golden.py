@@ -5,6 +5,7 @@ are data (inputs + the reference's outputs), never reference source.
 
     python tests/golden/gen_golden.py            # kat.json, random_1024.npz, digests.json
     python tests/golden/gen_golden.py --no-big   # skip the 2^20 digests (minutes of CPU)
+    python tests/golden/gen_golden.py --degenerate-only   # only degenerate_verify.npz (seconds)
 
 Known-answer inputs come from RFC 7748 5.2, RFC 8032 7.1 and from the reference's own tests
 (test/curve25519_test.c:412-445, test/openssl_test.c:20,97,138); the expected outputs are whatever the
@@ -211,9 +212,27 @@ def seeded(n, pool, chunks=64):
                                                      bsig=bsig, bmsg=bmsg, ok=ok.astype(np.int32))
 
 
+def degenerate(ref):
+    """degenerate_verify.npz: the inputs tests/vectors.py builds -- small-order keys and R's in every encoding the
+    reference decodes, S in {0, L, 2L, 15L, 1}, mixed-order keys with small-order R, S and S + L -- with the verdicts of
+    the REAL reference (ed25519_verify.c:179-197, :287-313).  Both back-ends of the reference must agree on them."""
+    import vectors
+    sig, pk, msg, label = vectors.degenerate_signature_cases()
+    verdict = ref.ed25519_verify(sig, pk, msg).astype(np.int32)
+    if Reference.available(asm=True):
+        assert np.array_equal(verdict, Reference(asm=True).ed25519_verify(sig, pk, msg)), "portable C and asm64 disagree"
+    assert 0 < verdict.sum() < len(verdict)
+    np.savez_compressed(os.path.join(HERE, "degenerate_verify.npz"), sig=sig, pk=pk, msg=msg, label=label, verdict=verdict)
+    print(f"wrote degenerate_verify.npz: {len(verdict)} cases, {int(verdict.sum())} accepted by the reference; by class "
+          + ", ".join(f"{c}: {int(verdict[label == c].sum())}/{int((label == c).sum())}" for c in sorted(set(label.tolist()))))
+
+
 def main():
     assert Reference.available(), "build oracle/_ref first: make -C oracle ref"
     ref = Reference()
+    degenerate(ref)
+    if "--degenerate-only" in sys.argv:
+        return
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(kat(ref), f, indent=1)
     print("wrote kat.json")

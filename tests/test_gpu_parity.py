@@ -845,6 +845,36 @@ def test_bench_self_launches_two_ranks(ranks, batch):
     assert len(line["verify"]["per_rank"]) == ranks
 
 
+def test_degenerate_but_valid_signatures_on_both_paths(api):
+    """tests/golden/degenerate_verify.npz through ed25519_VerifySignature on the device: the default pass (lattice path +
+    slow list) and, in a second process, C25519_AMD_VERIFY_REFERENCE_ORDER=1 (every element through the reference-order
+    kernels).  Expected verdicts are the real reference's: 336 of these 1024 signatures over small-order / mixed-order
+    keys, small-order R in every encoding and S in {0, L, 2L, 15L} are VALID for it."""
+    d = np.load(os.path.join(GOLD, "degenerate_verify.npz"))
+    sig, pk, msg, exp = (np.ascontiguousarray(d[k]) for k in ("sig", "pk", "msg", "verdict"))
+    assert np.array_equal(api.ed25519_VerifySignature(sig, pk, msg), exp)
+    # inside a big batch of ordinary signatures too (other workgroup shapes, sorted walk order)
+    n = 1 << 14
+    sk, m8 = synth.random_bytes((n, 32), 0x411), synth.random_bytes((n, 8), 0x422)
+    pub, priv = api.ed25519_CreateKeyPair(sk)
+    s2 = api.ed25519_SignMessage(priv, m8)
+    at = np.arange(len(exp)) * 13 + 5
+    s2[at], pub[at], m8[at] = sig, pk, msg
+    want = np.ones(n, np.int32)
+    want[at] = exp
+    assert np.array_equal(api.ed25519_VerifySignature(s2, pub, m8), want)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from curve25519_amd import api, _lib\n"
+        "d = np.load(sys.argv[1])\n"
+        "ok = api.ed25519_VerifySignature(d['sig'], d['pk'], d['msg'])\n"
+        "assert _lib.load().c25519_amd_verify_last_slow_elements() == -1\n"
+        "assert np.array_equal(ok, d['verdict']), int((ok != d['verdict']).sum())\n") % ROOT
+    p = subprocess.run([sys.executable, "-c", code, os.path.join(GOLD, "degenerate_verify.npz")], capture_output=True, text=True,
+                       timeout=600, env={**os.environ, "C25519_AMD_VERIFY_REFERENCE_ORDER": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+
+
 def test_lattice_fast_path_and_reference_order_agree(api, oracle):
     """ed25519_VerifySignature's default path decides every element whose key is on the curve with the exact lattice-shortened walk
     (csrc/verify_fast.cuh) and runs the reference's operation order for the rest.  Every class of input where the two

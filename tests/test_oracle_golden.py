@@ -73,6 +73,20 @@ def test_ed25519_verify_kat(oracle, rec):
     assert int(oracle.ed25519_verify(h2a(rec["sig"]), h2a(rec["pk"]), msg)[0]) == rec["verify"]
 
 
+def test_degenerate_signatures(oracle):
+    """tests/golden/degenerate_verify.npz: small-order keys and R's in every encoding the reference decodes (canonical, x = 0
+    with the sign bit, y + p), S in {0, L, 2L, 15L, 1}, messages searched so that the group equation holds, mixed-order keys
+    with small-order R and S / S + L -- 336 of the 1024 are ACCEPTED by the reference, which validates nothing
+    (ed25519_verify.c:179-197, :287-313).  The oracle's verdicts are the fixture's, and the fixture's inputs are what
+    tests/vectors.py builds."""
+    import vectors
+    d = np.load(os.path.join(GOLD, "degenerate_verify.npz"))
+    sig, pk, msg, label = vectors.degenerate_signature_cases()
+    assert np.array_equal(sig, d["sig"]) and np.array_equal(pk, d["pk"]) and np.array_equal(msg, d["msg"]) and np.array_equal(label, d["label"])
+    assert np.array_equal(oracle.ed25519_verify(d["sig"], d["pk"], d["msg"]), d["verdict"])
+    assert d["verdict"].sum() == 336 and all(d["verdict"][d["label"] == c].any() for c in (0, 3, 4))
+
+
 def test_random_1024(oracle):
     g = R1024
     shared, clamped = oracle.x25519_shared(g["x_pk"], g["x_sk"], threads=THREADS)

@@ -241,3 +241,20 @@ def test_fast_path_on_torsion(emul, oracle):
     gs, gm = synth.random_bytes((8, 64), 41), synth.random_bytes((8, 32), 42)
     v, s = run_fast(emul, gs, lo, gm)
     assert not s.any() and np.array_equal(v, oracle.ed25519_verify(gs, lo, gm))
+
+
+def test_degenerate_but_valid_signatures(emul):
+    """The committed degenerate vectors (tests/golden/degenerate_verify.npz; expected verdicts = the real reference's):
+    valid signatures whose key and R are small-order points in every encoding the reference decodes, S in {0, L, 2L, 15L},
+    mixed-order keys with small-order R.  The device source of the lattice path decides what it can; what it hands to the
+    slow list goes through the device source of the reference-order path; the combined verdicts are the reference's."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "degenerate_verify.npz"))
+    sig, pk, msg, exp = (np.ascontiguousarray(d[k]) for k in ("sig", "pk", "msg", "verdict"))
+    v, s = run_fast(emul, sig, pk, msg)
+    n = sig.shape[0]
+    vs, pt = np.empty(n, np.int32), np.empty((n, 32), np.uint8)
+    emul.emul_ed25519_verify_slow(C.c_void_p(vs.ctypes.data), C.c_void_p(pt.ctypes.data), C.c_void_p(sig.ctypes.data),
+                                  C.c_void_p(pk.ctypes.data), C.c_void_p(msg.ctypes.data), C.c_size_t(msg.shape[1]), C.c_size_t(n))
+    assert np.array_equal(vs, exp)                                   # the reference-order path alone, on everything
+    assert np.array_equal(np.where(s == 0, v, vs), exp)              # what a verification pass returns
+    assert (s == 0).sum() > n // 2 and exp[s == 0].sum() > 100       # the fast path decided most of them, accepts included

@@ -208,3 +208,86 @@ def lattice_inputs():
     hs += [rnd.getrandbits(k) for k in range(1, 253)]
     hs += [(N8L * a // b) % L for a in range(1, 20) for b in range(a + 1, 21)]
     return hs
+
+
+def small_order_encodings():
+    """Every 32-byte string the reference decodes to one of the eight small-order points: the canonical encodings, x = 0
+    with the sign bit set, and y + p where that still fits 255 bits (y = 0, 1), with either sign bit.  [(bytes, k)] with
+    the point being k * T8."""
+    T8 = ed_order8_point()
+    out = []
+    for k in range(8):
+        x, y = ed_mul(k, T8)
+        encs = [y | ((x & 1) << 255)]
+        if x == 0:
+            encs.append(y | (1 << 255))
+        if y + P < 2**255:
+            encs.append((y + P) | ((x & 1) << 255))
+            if x == 0:
+                encs.append((y + P) | (1 << 255))
+        out += [(e.to_bytes(32, "little"), k) for e in encs]
+    return out
+
+
+def degenerate_signature_cases():
+    """Inputs (sig[n,64], pk[n,32], msg[n,8], label[n]) on which a verifier that validates its inputs and the reference --
+    which does not (ed25519_verify.c:179-197, :287-313: no key / R validation, S taken as a 256-bit integer, byte compare
+    of enc(T) with R) -- may differ: small-order keys in every encoding the reference decodes, R a small-order point in
+    every encoding, S in {0, L, 2L, 15L, 1}, the message searched so that the group equation S*B = R + h*A holds (and
+    one where it does not); and mixed-order keys a*B + t*T8 with small-order R and S = h*a, S + L.  Expected verdicts
+    are the REFERENCE's (tests/golden/degenerate_verify.npz, written by gen_golden.py); nothing here decides them."""
+    import hashlib
+    T8 = ed_order8_point()
+    encs = small_order_encodings()
+    sigs, pks, msgs, labels = [], [], [], []
+
+    def hash_mod_l(Rb, Ab, m):
+        return int.from_bytes(hashlib.sha512(Rb + Ab + m).digest(), "little") % L
+
+    def find_msg(Rb, Ab, want, tag):
+        """first 8-byte counter message for which want(h) holds (None after 256 tries: unsolvable residue)"""
+        for c in range(256):
+            m = (tag * 65536 + c).to_bytes(8, "little")
+            if want(hash_mod_l(Rb, Ab, m)):
+                return m
+        return None
+
+    def put(Rb, S, Ab, m, label):
+        sigs.append(Rb + S.to_bytes(32, "little"))
+        pks.append(Ab)
+        msgs.append(m)
+        labels.append(label)
+
+    tag = 0
+    for Ab, a in encs:
+        for Rb, r in encs:
+            tag += 1
+            # the reference checks S*B + h*(-A) == R: with S = 0 mod L that is h*a + r = 0 mod 8 for A = a*T8, R = r*T8
+            sat = find_msg(Rb, Ab, lambda h: (h * a + r) % 8 == 0, tag)
+            unsat = find_msg(Rb, Ab, lambda h: (h * a + r) % 8 != 0, tag)
+            if sat is not None:
+                for S in (0, L, 2 * L, 15 * L):
+                    put(Rb, S, Ab, sat, 0)
+            if unsat is not None:
+                put(Rb, 0, Ab, unsat, 1)
+            if r == 0 or a == 0:
+                put(Rb, 1, Ab, sat if sat is not None else unsat, 2)         # S = 1: never a torsion point
+    import random
+    rnd = random.Random(11)
+    for t in range(1, 8):
+        a = rnd.getrandbits(252) % L
+        Ab = ed_enc(ed_add(ed_mul(a, ED_B), ed_mul(t, T8)))
+        for j in range(8):
+            tag += 1
+            Rb = ed_enc(ed_mul(j, T8))
+            # S*B = R + h*A with R = j*T8, A = a*B + t*T8:  S = h*a mod L and j + h*t = 0 mod 8
+            # (the reference negates A when it decodes it: the sign convention is settled by its verdicts, both residues go in)
+            for sign, lab in ((1, 3), (-1, 4)):
+                m = find_msg(Rb, Ab, lambda h: (j + sign * h * t) % 8 == 0, tag)
+                if m is None:
+                    continue
+                h = hash_mod_l(Rb, Ab, m)
+                for S in ((h * a) % L, (h * a) % L + L, (-h * a) % L):
+                    put(Rb, S, Ab, m, lab)
+    f = lambda rows: np.stack([np.frombuffer(x, np.uint8) for x in rows])  # noqa: E731
+    return f(sigs), f(pks), f(msgs), np.array(labels, np.int32)
