@@ -1,0 +1,284 @@
+// curve25519_amd/csrc/coop25519.cuh -- ONE operation per wave: the latency shape of the path.
+//
+// The batch kernels give every lane its own operation, so a call of one (the reference's own prototypes,
+// include/curve25519_dh.h) waits for one lane to walk the whole 255-step dependent chain alone: 0.75 ms for
+// curve25519_dh_CreateSharedKey against 93 us for the reference on one host core (profiles/r03_hostapi.txt).  Here the 64
+// lanes of a wave share ONE operation: a field element lives limb-per-lane in a 16-lane row (lane c of the row holds limb
+// c, ten of the sixteen lanes used), the four rows compute four field products at the same time, and a product is ten
+// v_mad_u64_u32 per lane (its column) instead of a hundred.  A ladder step (curve25519_dh.c:57-84) is three such product
+// levels -- {(x1-z1)(x2+z2), (x2-z2)(x1+z1), (x+z)^2, (x-z)^2}, {x3, (..)^2, x4, z4}, {z3 = (..)^2 * xb} -- with the
+// additions between them done in registers after a row exchange (v_permlane16_swap / v_permlane32_swap).
+//
+// Operands travel through LDS (a wave's LDS operations execute in order: no barrier, no s_waitcnt between a lane's
+// store and another lane's load): a value is stored once in the two forms a product reads it in,
+//   A-form   a[0..9]                        -- the multiplicand, every lane of a row reads all ten (broadcast reads)
+//   Y-forms  yo[s], ye[s], s = 0..19        -- the multiplier b pre-scaled and laid out so that column k's ten terms
+//            yo = [19 b_0 .. 19 b_9 | b_0 .. b_9],  ye = the same with the odd limbs doubled
+//            are the ten CONSECUTIVE entries s = k+1 .. k+10: term t pairs a_(9-t) with yo[k+1+t] (t odd: a's limb is
+//            even) or ye[k+1+t] (t even: a's limb is odd, so an odd b limb takes the factor 2 of radix 2^25.5); entries
+//            below 10 are the wrapped ones (2^255 = 19).
+// Column sums are carried across lanes with DPP row shifts: S = l0 + 2^w l1 + 2^51 l2, limb_c = l0_c + l1_(c-1) + l2_(c-2)
+// (lanes 9 / 8,9 wrap into lanes 0 / 0,1 times 19), then one more single-bit pass -- the result is "reduced" in the sense
+// of fe25519.cuh's bound contract, so the formulas' bounds are those tools/fe_bounds.py checks for the batch kernels.
+//
+// Constant time like the batch kernels: no secret-dependent branch or address (the ladder's per-bit choice is a
+// v_cndmask on register values).  Results are the reference's bytes (the final inversion, multiplication and
+// canonical encoding are the batch kernels' own code, run by every lane redundantly).
+#pragma once
+#include "fe25519.cuh"
+
+namespace c25519 {
+namespace coop {
+
+// LDS words of one value in operand form: A-form at 0 (12 words), yo at 16 (32 words), ye at 48 (32 words)
+constexpr int SLOT_WORDS = 80;
+constexpr int A_OFF = 0, YO_OFF = 16, YE_OFF = 48;
+// slots: 0-3 / 4-7 the two values a row may publish per phase, 8 the base point's x (stays for the whole ladder),
+// 9 the constant 1, 10 a dump for the six idle lanes of a row, 11 where a whole element is laid down for my_limb
+constexpr int SLOT_X1 = 8, SLOT_ONE = 9, SLOT_DUMP = 10, SLOT_TMP = 11, NSLOTS = 12;
+
+struct Lane {
+    u32 c, row;                    // column within the row (0..15; 0..9 hold limbs), row (0..3)
+    u32 w, mask, mask_next;        // bits of limb c, its mask, the mask of limb c + 1
+    u32 sh;                        // c & 1: odd limbs are doubled in the ye form
+    u32 m1, m2;                    // 19 in lane 0 / in lanes 0 and 1, else 0: the carry's wrap-around
+    u32 p2;                        // limb c of 2p (biased subtraction)
+    u32 wr;                        // LDS word offset a lane adds to what it stores: 0, or the way to the dump slot
+    bool odd_row, upper;           // row & 1, row >= 2
+};
+
+C25519_DEV Lane make_lane(u32 lane)
+{
+    Lane L;
+    L.c = lane & 15;
+    L.row = lane >> 4;
+    const bool active = L.c < 10;
+    L.sh = L.c & 1;
+    L.w = L.sh ? 25 : 26;
+    L.mask = L.sh ? M25 : M26;
+    L.mask_next = L.sh ? M26 : M25;
+    L.m1 = L.c == 0 ? 19u : 0u;
+    L.m2 = L.c < 2 ? 19u : 0u;
+    L.p2 = L.c == 0 ? 0x7ffffdau : (L.sh ? 0x3fffffeu : 0x7fffffeu);
+    L.wr = active ? 0u : 0x80000000u;                     // flag: stores of idle lanes go to the dump slot
+    L.odd_row = (L.row & 1) != 0;
+    L.upper = L.row >= 2;
+    return L;
+}
+
+// DPP moves within a 16-lane row (zero where nothing arrives)
+C25519_DEV u32 row_shr1(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); }
+C25519_DEV u32 row_shr2(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); }
+C25519_DEV u32 row_ror7(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x127, 0xf, 0xf, true); }   // lane 0 <- lane 9
+C25519_DEV u32 row_ror8(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true); }   // lanes 0, 1 <- lanes 8, 9
+
+// the value of the even row of each row pair in `even`, of the odd row in `odd`, in both rows of the pair
+C25519_DEV void pair_exchange(u32& even, u32& odd, u32 v)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    even = r[0];
+    odd = r[1];
+}
+// the value of rows 0, 1 in `lower`, of rows 2, 3 in `upper` (row r and row r + 2 see the pair (row r mod 2)'s values)
+C25519_DEV void half_exchange(u32& lower, u32& upper, u32 v)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    lower = r[0];
+    upper = r[1];
+}
+
+// nothing moves across this point (the compiler sees one thread; the LDS traffic below is between lanes)
+C25519_DEV void wave_fence()
+{
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// column sum -> reduced limb
+C25519_DEV u32 carry(const Lane& L, u64 S)
+{
+    const u32 l0 = (u32)S & L.mask;
+    const u32 l1 = (u32)(S >> L.w) & L.mask_next;
+    const u32 l2 = (u32)(S >> 51);
+    u32 limb = l0 + row_shr1(l1) + row_shr2(l2) + row_ror7(l1) * L.m1 + row_ror8(l2) * L.m2;
+    const u32 e = limb >> L.w;
+    limb = (limb & L.mask) + row_shr1(e) + row_ror7(e) * L.m1;
+    return limb;
+}
+
+// the same for a small sum (S < 2^46: a limb-wise sum, difference or a24 step): one piece moves up, limbs < 2^w + 2^25
+C25519_DEV u32 carry_small(const Lane& L, u64 S)
+{
+    const u32 l1 = (u32)(S >> L.w);
+    return ((u32)S & L.mask) + row_shr1(l1) + row_ror7(l1) * L.m1;
+}
+
+// a value's word offset in LDS for this lane's stores (idle lanes: the dump slot)
+C25519_DEV u32 store_base(const Lane& L, u32 slot) { return ((L.wr ? (u32)SLOT_DUMP : slot)) * SLOT_WORDS; }
+
+C25519_DEV void put_a(u32* lds, const Lane& L, u32 slot, u32 v) { lds[store_base(L, slot) + A_OFF + L.c] = v; }
+C25519_DEV void put_y(u32* lds, const Lane& L, u32 slot, u32 v)
+{
+    u32* s = lds + store_base(L, slot);
+    const u32 v19 = v * 19u, d = v << L.sh, d19 = v19 << L.sh;
+    s[YO_OFF + L.c] = v19;
+    s[YO_OFF + L.c + 10] = v;
+    s[YE_OFF + L.c] = d19;
+    s[YE_OFF + L.c + 10] = d;
+}
+C25519_DEV void put(u32* lds, const Lane& L, u32 slot, u32 v)
+{
+    put_a(lds, L, slot, v);
+    put_y(lds, L, slot, v);
+}
+
+// column L.c of (value in slot xs) * (value in slot ys)
+C25519_DEV u64 column(const u32* lds, const Lane& L, u32 xs, u32 ys)
+{
+    const u32* a = lds + xs * SLOT_WORDS + A_OFF;
+    const u32* yo = lds + ys * SLOT_WORDS + YO_OFF + L.c + 1;
+    const u32* ye = lds + ys * SLOT_WORDS + YE_OFF + L.c + 1;
+    u64 acc = 0;
+#pragma unroll
+    for (int t = 0; t < 10; t++) acc += (u64)a[9 - t] * ((t & 1) ? yo[t] : ye[t]);
+    return acc;
+}
+
+// one product level: every row multiplies the values of the two slots it names
+C25519_DEV u32 mul_level(const u32* lds, const Lane& L, u32 xs, u32 ys)
+{
+    wave_fence();
+    const u64 S = column(lds, L, xs, ys);
+    wave_fence();
+    return carry(L, S);
+}
+
+// per-row choice of a small constant: rows 0..3 take k0..k3
+C25519_DEV u32 by_row(const Lane& L, u32 k0, u32 k1, u32 k2, u32 k3)
+{
+    return L.upper ? (L.odd_row ? k3 : k2) : (L.odd_row ? k1 : k0);
+}
+
+// limb L.c of a field element every lane holds whole: through LDS (lane 0 lays the ten limbs down, every lane picks
+// its own), because a chain of ten selects on the lane's column is turned into a scratch array by the compiler
+C25519_DEV u32 my_limb(u32* lds, const Lane& L, const fe& f)
+{
+    wave_fence();
+    if (L.c == 0 && L.row == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) lds[SLOT_TMP * SLOT_WORDS + i] = f.v[i];
+    }
+    wave_fence();
+    const u32 v = lds[SLOT_TMP * SLOT_WORDS + (L.c < 10 ? L.c : 0)];
+    wave_fence();
+    return v;
+}
+
+// every lane reads the ten limbs slot `s` holds in A-form
+C25519_DEV void get_fe(fe& f, const u32* lds, u32 s)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) f.v[i] = lds[s * SLOT_WORDS + A_OFF + i];
+}
+
+// v <- v^2 in every row (each row on its own copy: slot = row), n times
+C25519_DEV u32 sqr_n(u32* lds, const Lane& L, u32 v, int n)
+{
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        put(lds, L, L.row, v);
+        v = mul_level(lds, L, L.row, L.row);
+    }
+    return v;
+}
+// v * w in every row (slots row and 4 + row)
+C25519_DEV u32 mul2(u32* lds, const Lane& L, u32 v, u32 w)
+{
+    put_a(lds, L, L.row, v);
+    put_y(lds, L, 4 + L.row, w);
+    return mul_level(lds, L, L.row, 4 + L.row);
+}
+
+// z^(p-2) limb-per-lane: the 254 S + 11 M chain of fe_invert (ecp_Inverse, curve25519_mehdi.c:340-409); 0 -> 0
+C25519_DEV u32 invert(u32* lds, const Lane& L, u32 z)
+{
+    const u32 x2 = sqr_n(lds, L, z, 1);
+    u32 t = sqr_n(lds, L, x2, 2);
+    const u32 x9 = mul2(lds, L, t, z);
+    const u32 x11 = mul2(lds, L, x9, x2);
+    t = sqr_n(lds, L, x11, 1);
+    const u32 x5 = mul2(lds, L, t, x9);                   // z^(2^5 - 1)
+    t = sqr_n(lds, L, x5, 5);
+    const u32 x10 = mul2(lds, L, t, x5);
+    t = sqr_n(lds, L, x10, 10);
+    const u32 x20 = mul2(lds, L, t, x10);
+    t = sqr_n(lds, L, x20, 20);
+    t = mul2(lds, L, t, x20);
+    t = sqr_n(lds, L, t, 10);
+    const u32 x50 = mul2(lds, L, t, x10);
+    t = sqr_n(lds, L, x50, 50);
+    const u32 x100 = mul2(lds, L, t, x50);
+    t = sqr_n(lds, L, x100, 100);
+    t = mul2(lds, L, t, x100);
+    t = sqr_n(lds, L, t, 50);
+    t = mul2(lds, L, t, x50);                             // z^(2^250 - 1)
+    t = sqr_n(lds, L, t, 5);
+    return mul2(lds, L, t, x11);
+}
+
+// (X : Z) <- 2 (X : Z) for a point held x in the even rows, z in the odd rows (both row pairs may hold one): two product
+// levels, {(x+z)^2, (x-z)^2} and {x' = AA * BB, z' = E * (AA + 121665 E)}   (ecp_MontDouble, curve25519_dh.c:40-54)
+C25519_DEV u32 mont_double(u32* lds, const Lane& L, u32 v)
+{
+    u32 ev, od;
+    pair_exchange(ev, od, v);
+    const u32 val = L.odd_row ? ev + L.p2 - od : ev + od;
+    put(lds, L, L.row, val);
+    v = mul_level(lds, L, L.row, L.row);                   // even rows AA, odd rows BB
+    pair_exchange(ev, od, v);
+    const u32 E = ev + L.p2 - od;
+    const u32 F = carry_small(L, (u64)E * 121665u + ev);
+    put_a(lds, L, L.row, L.odd_row ? E : ev);
+    put_y(lds, L, L.row, L.odd_row ? F : od);
+    return mul_level(lds, L, L.row, L.row);
+}
+
+// One ladder step on the state (row 0: x of the sum, row 1: its z, row 2: x of the double, row 3: its z), limb per lane.
+// eq: all-ones when this bit equals the previous one (the doubling then continues from the double, else from the sum).
+template <bool BASE9>
+C25519_DEV u32 ladder_step(u32* lds, const Lane& L, u32 v, u32 eq)
+{
+    // phase 0: B = x1+z1 (row 0), A = x1-z1 (row 1), Dp = x2+z2 (row 2), C = x2-z2 (row 3); the doubling's inputs
+    u32 ev, od;
+    pair_exchange(ev, od, v);
+    const u32 sum = ev + od, diff = ev + L.p2 - od;
+    const u32 val = L.odd_row ? diff : sum;
+    u32 lo, hi;
+    half_exchange(lo, hi, val);                            // rows 2, 3 see (B, A) in lo and their own (Dp, C) in hi
+    const u32 sel = lo ^ ((lo ^ hi) & eq);                 // P = x+z (row 2) and M = x-z (row 3) of the point to double
+    put(lds, L, L.row, val);
+    put(lds, L, 4 + L.row, sel);
+    // level 1: row 0 A*Dp, row 1 C*B, row 2 P^2, row 3 M^2
+    v = mul_level(lds, L, by_row(L, 1, 3, 6, 7), by_row(L, 2, 0, 6, 7));
+    // phase 1.5: DA+CB (row 0), DA-CB (row 1), F = AA + 121665 E (row 2), E = AA-BB (row 3) -- all through one small carry
+    pair_exchange(ev, od, v);
+    const u32 d2 = ev + L.p2 - od;
+    const u32 base = L.upper ? (L.odd_row ? d2 : ev) : (L.odd_row ? d2 : ev + od);
+    const u32 k = (L.upper && !L.odd_row) ? 121665u : 0u;
+    const u32 w = carry_small(L, (u64)d2 * k + base);
+    put(lds, L, L.row, v);                                 // slots 2, 3: AA, BB
+    put(lds, L, 4 + L.row, w);                             // slots 4..7: DA+CB, DA-CB, F, E
+    // level 2: row 0 (DA+CB)^2 = x3, row 1 (DA-CB)^2, row 2 AA*BB = x4, row 3 E*F = z4
+    v = mul_level(lds, L, by_row(L, 4, 5, 2, 7), by_row(L, 4, 5, 3, 6));
+    // level 3: row 1 times the base point's x (times 9: a small constant), the other rows times one
+    put_a(lds, L, L.row, v);
+    if (BASE9) {
+        wave_fence();
+        const u32 k9 = (!L.upper && L.odd_row) ? 9u : 1u;
+        return carry(L, (u64)v * k9);
+    }
+    return mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_X1, SLOT_ONE, SLOT_ONE));
+}
+
+}  // namespace coop
+}  // namespace c25519

@@ -16,6 +16,7 @@
 #include "host_pipeline.hpp"
 #include "lanes.cuh"
 #include "verify_fast.cuh"
+#include "coop25519.cuh"
 
 #include "../../include/curve25519_amd.h"
 #include "../../include/curve25519_dh.h"
@@ -255,6 +256,72 @@ __global__ void __launch_bounds__(XL_BLOCK, C25519_XF_WAVES) k_x25519_ladder(u32
         rec[18] = probe_realtime();
     }
 #endif
+}
+
+// One operation per WAVE (coop25519.cuh): what a call of a few elements runs -- the reference's own single-call
+// prototypes above all.  Ladder, doublings, inversion and the last multiplication are cooperative (a field element
+// limb-per-lane, up to four products at a time); only the decoding of the inputs and the canonical encoding of the result
+// are the batch kernels' per-lane code, run by every lane on the same values.
+template <bool BASE9>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop(void* out, const void* pk, void* sk, size_t n)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds[coop::NSLOTS * coop::SLOT_WORDS];
+    const coop::Lane L = coop::make_lane(threadIdx.x);
+    const size_t e = blockIdx.x;
+    if (e >= n) return;
+    u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8];
+    if (!BASE9) load32(u, pk, e);
+    load32(k, sk, e);
+    clamp_words(k);
+    if (threadIdx.x == 0) store32(sk, e, k);            // the reference clamps in the caller's buffer
+    fe X1, one;
+    fe_from_words(X1, u);
+    fe_set_u32(one, 1);
+    const u32 x1 = coop::my_limb(lds, L, X1), o1 = coop::my_limb(lds, L, one);
+    coop::put_y(lds, L, coop::SLOT_X1, x1);
+    coop::put_y(lds, L, coop::SLOT_ONE, o1);
+    // P = (X1 : 1) in rows 0, 1 and Q = 2P in rows 2, 3; bit 254 is the leading one (curve25519_dh.c:123-125 with zr = 1)
+    u32 v = L.odd_row ? o1 : x1;
+    {
+        const u32 q = coop::mont_double(lds, L, v);
+        v = L.upper ? q : v;
+    }
+    u32 prev = 1;
+#pragma unroll 1
+    for (int w = 7; w >= 0; w--) {
+        u32 kw = k[0];
+#pragma unroll
+        for (int t = 1; t < 8; t++) kw = (w == t) ? k[t] : kw;
+        const int top = (w == 7) ? 29 : 31, bottom = (w == 0) ? 3 : 0;
+        kw <<= (31 - top);
+#pragma unroll 1
+        for (int b = top; b >= bottom; b--) {
+            const u32 bit = kw >> 31;
+            kw <<= 1;
+            v = coop::ladder_step<BASE9>(lds, L, v, (u32)0 - (u32)(bit == prev));
+            prev = bit;
+        }
+    }
+    // P = the sum if the last bit was one, else the double (curve25519_dh.c:148-150): into both row pairs, x in the even
+    // rows, z in the odd; then the three clamped-away low bits -- three doublings of P
+    u32 lo, hi;
+    coop::half_exchange(lo, hi, v);
+    u32 p = hi ^ ((hi ^ lo) & ((u32)0 - prev));
+#pragma unroll 1
+    for (int i = 0; i < 3; i++) p = coop::mont_double(lds, L, p);
+    // x / z: the odd rows' inverse times the even rows' x, in every row; canonical bytes by every lane
+    const u32 zi = coop::invert(lds, L, p);
+    u32 px, pz, ix, iz;
+    coop::pair_exchange(px, pz, p);
+    coop::pair_exchange(ix, iz, zi);
+    const u32 r = coop::mul2(lds, L, px, iz);
+    coop::put_a(lds, L, L.row, r);
+    coop::wave_fence();
+    fe R;
+    coop::get_fe(R, lds, 0);
+    u32 wds[8];
+    fe_to_words(wds, R);
+    if (threadIdx.x == 0) store32(out, e, wds);         // written last: `out` may alias `pk`
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1040,6 +1107,16 @@ int x25519_block_for(size_t n)
     return XF_BLOCK;
 }
 
+// a call of a few elements -- the reference's single-call prototypes are a batch of one -- runs ONE operation per wave
+// (k_x25519_coop): ~5 x less latency than one operation per lane, at ~12 x the instructions per operation, so only while
+// the waves still find idle SIMDs.  C25519_AMD_COOP_MAX = the largest such batch (A/B knob, read per call; 0 = never).
+bool x25519_coop_for(size_t n)
+{
+    size_t max = 1024;
+    if (const char* e = getenv("C25519_AMD_COOP_MAX")) max = (size_t)atol(e);
+    return n <= max && c25519_host::batch_shape_hint() <= max;
+}
+
 // a batch that fills the chip runs the ladder and the shared inversion as two launches (k_x25519_ladder's comment);
 // C25519_AMD_XF_SPLIT=0/1 forces either shape (A/B knob, read per call)
 bool x25519_split_for(size_t n)
@@ -1113,6 +1190,12 @@ void c25519_amd_thread_release(void)
 
 static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t stream)
 {
+    if (x25519_coop_for(n)) {
+        if (pk) k_x25519_coop<false><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n);
+        else    k_x25519_coop<true><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n);
+        C25519_TRY(hipGetLastError());
+        return 0;
+    }
     if (x25519_split_for(n)) {
         void* w = nullptr;
         c25519_host::WorkLease lease;
