@@ -26,6 +26,7 @@
 // canonical encoding are the batch kernels' own code, run by every lane redundantly).
 #pragma once
 #include "fe25519.cuh"
+#include "ge25519.cuh"
 
 namespace c25519 {
 namespace coop {
@@ -34,8 +35,11 @@ namespace coop {
 constexpr int SLOT_WORDS = 80;
 constexpr int A_OFF = 0, YO_OFF = 16, YE_OFF = 48;
 // slots: 0-3 / 4-7 the two values a row may publish per phase, 8 the base point's x (stays for the whole ladder),
-// 9 the constant 1, 10 a dump for the six idle lanes of a row, 11 where a whole element is laid down for my_limb
-constexpr int SLOT_X1 = 8, SLOT_ONE = 9, SLOT_DUMP = 10, SLOT_TMP = 11, NSLOTS = 12;
+// 9 the constant 1, 10 a dump for the six idle lanes of a row, 11 where a whole element is laid down for my_limb,
+// 12 the constant 1 / (2d) of the fixed-base walk's starting point
+constexpr int SLOT_X1 = 8, SLOT_ONE = 9, SLOT_DUMP = 10, SLOT_TMP = 11, SLOT_KDI = 12, NSLOTS = 13;
+// ... and, behind the slots, the 32 table-row limbs a lane has fetched for the fixed-base walk (word j of lane l at j * 64 + l)
+constexpr int ROWQ_OFF = NSLOTS * SLOT_WORDS, LDS_WORDS = ROWQ_OFF + 32 * 64;
 
 struct Lane {
     u32 c, row;                    // column within the row (0..15; 0..9 hold limbs), row (0..3)
@@ -278,6 +282,112 @@ C25519_DEV u32 ladder_step(u32* lds, const Lane& L, u32 v, u32 eq)
         return carry(L, (u64)v * k9);
     }
     return mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_X1, SLOT_ONE, SLOT_ONE));
+}
+
+// ---- the fixed-base Edwards walk, one operation per wave ------------------------------------------------------------
+// A point (X : Y : Z : T) lives in the four rows (row 0 X ... row 3 T), limb per lane; an addition of a precomputed affine
+// row (edp_AddAffinePoint, ed25519_sign.c:97-115) and a doubling (edp_DoublePoint, :122-143) are two product levels each:
+// {(Y-X) ymx, (Y+X) ypx, 2Z, T t2d} then {F E, G H, F G, E H}, and {X^2, Y^2, (X+Y)^2, Z^2} then {E Fn, G Hn, G Fn, E Hn}
+// with ge25519.cuh's sign conventions (Hn = A + B, Fn = 2 Z^2 + A - B: all four outputs negated, the same point).
+// The walk is ge_base_mult's: eight signed comb tables, 3 doublings, 31 additions -- the same point as the reference's
+// 31-doubling walk (edp_BasePointMult, ed25519_sign.c:215-244), hence the same bytes after the inversion.
+
+// limb L.c of field `f` (0 ypx, 1 ymx, 2 t2d) of the row a column byte selects in one signed comb table (limb-major
+// [30][128] in device memory); a negative column swaps ypx / ymx and negates t2d (ge25519.cuh: lds_load_pa_signed)
+C25519_DEV u32 row_limb(const u32* __restrict__ tbl, const Lane& L, u32 colbyte, u32 f)
+{
+    const u32 neg = ((colbyte >> 7) & 1u) - 1u;           // all-ones: negative column
+    const u32 row = (colbyte ^ neg) & 127u;
+    const u32 ff = (f < 2 && neg) ? 1u - f : f;
+    const u32 c = L.c < 10 ? L.c : 9;
+    const u32 wd = tbl[(ff * 10 + c) * BASE_ROWS + row];
+    return (f == 2 && neg) ? L.p2 - wd : wd;
+}
+// ... of the field an addition's first level multiplies THIS row by: row 0 ymx, row 1 ypx, row 3 t2d (row 2: unused)
+C25519_DEV u32 row_limb_for_add(const u32* __restrict__ tbl, const Lane& L, u32 colbyte)
+{
+    return row_limb(tbl, L, colbyte, by_row(L, 1, 0, 2, 2));
+}
+
+// p += q, q a table row given as the limb each lane multiplies by (row_limb_for_add)
+C25519_DEV u32 ge_add(u32* lds, const Lane& L, u32 v, u32 qlimb)
+{
+    u32 ev, od;
+    pair_exchange(ev, od, v);                             // lower pair: X, Y; upper pair: Z, T
+    const u32 op = L.upper ? (L.odd_row ? od : ev + ev) : (L.odd_row ? ev + od : od + L.p2 - ev);
+    put_a(lds, L, L.row, op);                             // Y-X, Y+X, 2Z, T
+    put_y(lds, L, 4 + L.row, qlimb);
+    v = mul_level(lds, L, L.row, by_row(L, 4, 5, SLOT_ONE, 7));      // A, B, D, C
+    pair_exchange(ev, od, v);
+    const u32 w = L.odd_row ? ev + od : (L.upper ? ev + L.p2 - od : od + L.p2 - ev);   // E = B-A, H = B+A, F = D-C, G = D+C
+    put(lds, L, L.row, w);
+    return mul_level(lds, L, by_row(L, 2, 3, 2, 0), by_row(L, 0, 1, 3, 1));          // F E, G H, F G, E H
+}
+
+// p = 2p
+C25519_DEV u32 ge_dbl(u32* lds, const Lane& L, u32 v)
+{
+    u32 ev, od, lo, hi;
+    pair_exchange(ev, od, v);
+    half_exchange(lo, hi, ev + od);                       // lo: X + Y, in every row
+    put(lds, L, L.row, L.upper ? (L.odd_row ? ev : lo) : v);          // X, Y, X+Y, Z
+    v = mul_level(lds, L, L.row, L.row);                  // A, B, (X+Y)^2, Z^2
+    pair_exchange(ev, od, v);
+    const u32 hg = L.odd_row ? od + L.p2 - ev : ev + od;  // rows 0, 1: Hn = A + B, G = B - A
+    half_exchange(lo, hi, hg);                            // lo: Hn in the even rows, G in the odd rows
+    const u32 k = L.odd_row ? 2u : 1u;
+    const u32 w = carry_small(L, L.upper ? v * k + 2 * L.p2 - lo : hg);   // Hn, G, E = (X+Y)^2 - Hn, Fn = 2 Z^2 - G
+    put(lds, L, L.row, w);
+    return mul_level(lds, L, by_row(L, 2, 1, 1, 2), by_row(L, 3, 0, 3, 0));           // E Fn, G Hn, G Fn, E Hn
+}
+
+// S = k * B for a scalar below 2^255 + 2^254 (clamped, or reduced mod L), tbl = the eight signed comb tables in device
+// memory.  SLOT_ONE must hold the constant one.  Every row fetch is issued before the walk starts (the addresses depend on
+// the scalar alone), so the walk itself never waits for memory.
+C25519_DEV u32 ge_base_mult(u32* lds, const Lane& L, const u32 (&k)[8], const u32* __restrict__ tbl)
+{
+    u32 w[8];
+    sc_signed_comb(w, k);
+    const u32 lane = L.row * 16 + L.c;
+#pragma unroll
+    for (int m = 0; m < BASE_STEP; m++)
+#pragma unroll
+        for (int t = 0; t < BASE_NT; t++)
+            lds[ROWQ_OFF + (m * BASE_NT + t) * 64 + lane] = row_limb_for_add(tbl + t * BASE_TBL_WORDS, L, fold8_at(w, t * BASE_STEP + m));
+    // the start: (2x, 2y, 2, 2xy) of table 0's row (ed25519_sign.c:226-230 with R = 1): ypx - ymx, ypx + ymx, 2, t2d / (2d)
+    const u32 c0 = fold8_at(w, 0);
+    const u32 ypx = row_limb(tbl, L, c0, 0), ymx = row_limb(tbl, L, c0, 1), t2d = row_limb(tbl, L, c0, 2);
+    put_y(lds, L, SLOT_KDI, my_limb(lds, L, fe_const(K_DI)));
+    const u32 two = L.c == 0 ? 2u : 0u;
+    put_a(lds, L, L.row, L.upper ? (L.odd_row ? t2d : two) : (L.odd_row ? ypx + ymx : ypx + L.p2 - ymx));
+    u32 v = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, SLOT_KDI));
+#pragma unroll 1
+    for (int m = 0; m < BASE_STEP; m++) {
+        if (m) v = ge_dbl(lds, L, v);
+#pragma unroll 1
+        for (int t = m ? 0 : 1; t < BASE_NT; t++) {
+            v = ge_add(lds, L, v, lds[ROWQ_OFF + (m * BASE_NT + t) * 64 + lane]);
+        }
+    }
+    return v;
+}
+
+// canonical (x, y) words of the point in the rows: one inversion of Z, two products, the batch kernels' encoding
+C25519_DEV void ge_affine_words(u32 (&xw)[8], u32 (&yw)[8], u32* lds, const Lane& L, u32 v)
+{
+    u32 ev, od, lo, hi;
+    pair_exchange(ev, od, v);
+    half_exchange(lo, hi, ev);                            // hi: Z in every row
+    const u32 zi = invert(lds, L, hi);
+    const u32 r = mul2(lds, L, v, zi);                    // row 0 x, row 1 y
+    put_a(lds, L, L.row, r);
+    wave_fence();
+    fe x, y;
+    get_fe(x, lds, 0);
+    get_fe(y, lds, 1);
+    wave_fence();
+    fe_to_words(xw, x);
+    fe_to_words(yw, y);
 }
 
 }  // namespace coop

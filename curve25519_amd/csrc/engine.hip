@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(XL_BLOCK, C25519_XF_WAVES) k_x25519_ladder(u32
 template <bool BASE9>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop(void* out, const void* pk, void* sk, size_t n)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds[coop::NSLOTS * coop::SLOT_WORDS];
+    __shared__ __attribute__((aligned(16))) u32 lds[coop::ROWQ_OFF];
     const coop::Lane L = coop::make_lane(threadIdx.x);
     const size_t e = blockIdx.x;
     if (e >= n) return;
@@ -503,6 +503,88 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_finish(void* sig, 
     soa_store8(r_in, n, i, zero);
     ed_sign_s(s, encR, pkw, msgs.ptr(i), msgs.len(i), a, r);
     store32(sig, 2 * i + 1, s);
+}
+
+// The same three operations for a call of a few elements, ONE operation per wave (coop25519.cuh): hashing and scalar
+// arithmetic by every lane on the same values, the fixed-base walk, the inversion and the affine conversion cooperative.
+// (No blinding here: a blinded call runs the batch kernels.)
+C25519_DEV void coop_setup_one(u32* lds, const coop::Lane& L)
+{
+    fe one;
+    fe_set_u32(one, 1);
+    coop::put_y(lds, L, coop::SLOT_ONE, coop::my_limb(lds, L, one));
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
+k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u32* __restrict__ g_tbl)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
+    const coop::Lane L = coop::make_lane(threadIdx.x);
+    const size_t e = blockIdx.x;
+    if (e >= n) return;
+    u32 seed[8], a[8], xw[8], yw[8], enc[8];
+    u64 b_words[4];
+    load32(seed, sk, e);
+    ed_expand_seed(a, b_words, seed);
+    coop_setup_one(lds, L);
+    const u32 v = coop::ge_base_mult(lds, L, a, g_tbl);
+    coop::ge_affine_words(xw, yw, lds, L, v);
+    ge_pack(enc, xw, yw);
+    if (threadIdx.x == 0) {
+        store32(priv, 2 * e, seed);
+        store32(priv, 2 * e + 1, enc);
+        store32(pub, e, enc);
+    }
+}
+
+// curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189): S = clamp(sk) * B on the Edwards side, u = (Z + Y) / (Z - Y)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
+k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ g_tbl)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
+    const coop::Lane L = coop::make_lane(threadIdx.x);
+    const size_t e = blockIdx.x;
+    if (e >= n) return;
+    u32 k[8], wds[8];
+    load32(k, sk, e);
+    clamp_words(k);
+    if (threadIdx.x == 0) store32(sk, e, k);
+    coop_setup_one(lds, L);
+    const u32 v = coop::ge_base_mult(lds, L, k, g_tbl);
+    u32 ev, od, y, z, t;
+    coop::pair_exchange(ev, od, v);                       // lower pair: X, Y; upper pair: Z, T
+    coop::half_exchange(y, t, od);                        // y: Y in every row
+    coop::half_exchange(t, z, ev);                        // z: Z in every row
+    const u32 zi = coop::invert(lds, L, z + L.p2 - y);
+    const u32 r = coop::mul2(lds, L, z + y, zi);
+    coop::put_a(lds, L, L.row, r);
+    coop::wave_fence();
+    fe R;
+    coop::get_fe(R, lds, 0);
+    fe_to_words(wds, R);
+    if (threadIdx.x == 0) store32(pk, e, wds);
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
+k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32* __restrict__ g_tbl)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
+    const coop::Lane L = coop::make_lane(threadIdx.x);
+    const size_t e = blockIdx.x;
+    if (e >= n) return;
+    u32 seed[8], pkw[8], a[8], r[8], xw[8], yw[8], enc[8], s[8];
+    load32(seed, priv, 2 * e);
+    load32(pkw, priv, 2 * e + 1);
+    ed_sign_nonce(a, r, seed, msgs.ptr(e), msgs.len(e));
+    coop_setup_one(lds, L);
+    const u32 v = coop::ge_base_mult(lds, L, r, g_tbl);
+    coop::ge_affine_words(xw, yw, lds, L, v);
+    ge_pack(enc, xw, yw);
+    ed_sign_s(s, enc, pkw, msgs.ptr(e), msgs.len(e), a, r);
+    if (threadIdx.x == 0) {
+        store32(sig, 2 * e, enc);
+        store32(sig, 2 * e + 1, s);
+    }
 }
 
 // ed25519_Blinding_Init (ed25519_sign.c:289-331) for one context: digest = SHA-512(domain || seed),
@@ -1110,12 +1192,16 @@ int x25519_block_for(size_t n)
 // a call of a few elements -- the reference's single-call prototypes are a batch of one -- runs ONE operation per wave
 // (k_x25519_coop): ~5 x less latency than one operation per lane, at ~12 x the instructions per operation, so only while
 // the waves still find idle SIMDs.  C25519_AMD_COOP_MAX = the largest such batch (A/B knob, read per call; 0 = never).
-bool x25519_coop_for(size_t n)
+bool coop_for(size_t n, size_t dflt)
 {
-    size_t max = 1024;
+    size_t max = dflt;
     if (const char* e = getenv("C25519_AMD_COOP_MAX")) max = (size_t)atol(e);
     return n <= max && c25519_host::batch_shape_hint() <= max;
 }
+// crossovers measured on MI355X (tools/small_batch_sweep.py, profiles/r04_small_batch_sweep.txt): the ladder one per wave
+// wins up to 4096 elements (0.49 against 0.66 ms), the fixed-base operations up to 2048 (0.10-0.16 against 0.15-0.19 ms)
+bool x25519_coop_for(size_t n) { return coop_for(n, 4096); }
+bool fixed_base_coop_for(size_t n) { return coop_for(n, 2048); }
 
 // a batch that fills the chip runs the ladder and the shared inversion as two launches (k_x25519_ladder's comment);
 // C25519_AMD_XF_SPLIT=0/1 forces either shape (A/B knob, read per call)
@@ -1241,6 +1327,11 @@ int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void
     hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
+    if (fixed_base_coop_for(n)) {                             // a few elements: one operation per wave
+        k_x25519_public_fast_coop<<<(unsigned)n, 64, 0, stream>>>(pk, sk, n, tbl);
+        C25519_TRY(hipGetLastError());
+        return 0;
+    }
     void* w = nullptr;
     c25519_host::WorkLease lease;
     C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
@@ -1258,6 +1349,11 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
     if (n == 0) return 0;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
+    if (!blinding && fixed_base_coop_for(n)) {                // a few elements: one operation per wave
+        k_ed25519_keypair_coop<<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, tbl);
+        C25519_TRY(hipGetLastError());
+        return 0;
+    }
     void* w = nullptr;
     c25519_host::WorkLease lease;
     C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
@@ -1289,6 +1385,11 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
     if (n == 0) return 0;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
+    if (!blinding && fixed_base_coop_for(n)) {                // a few elements: one operation per wave
+        k_ed25519_sign_coop<<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, tbl);
+        C25519_TRY(hipGetLastError());
+        return 0;
+    }
     void* w = nullptr;
     const size_t sc_words = round_up(8 * n, 4);
     c25519_host::WorkLease lease;

@@ -11,11 +11,14 @@
  *     MI355X (gfx950) through HIP and ABORTS the process with a message on stderr if no usable
  *     device is present -- it never falls back to a CPU implementation.
  *
- * A single call is executed as a device batch of one: a whole kernel pass for one lane, about 0.75 ms
- * (profiles/r03_batch_sweep.txt) against 93 us for the reference on one host core -- the literal drop-in call is
- * correct, not fast.  Throughput comes from the batch entry points in curve25519_amd.h: a call of ~10 operations
- * already beats one host core, ~130 beat sixteen cores; batches that do not fill the chip run in narrower workgroups
- * (2^14 per call: 25 M/s, 2^16: 90 M/s), and the quoted rates need 2^17 and more per call (2^17: 99 M/s, 2^20: 122 M/s).
+ * A single call is a device batch of one.  Calls of up to a few thousand elements run ONE operation per wave
+ * (csrc/coop25519.cuh: a field element limb-per-lane, four field products at a time): 0.19 ms for
+ * curve25519_dh_CreateSharedKey, 0.17 ms for curve25519_dh_CalculatePublicKey, 0.06 ms for _fast, end to end
+ * (profiles/r04_single_call.txt; round 3's one-operation-per-lane pass took 0.76 ms) against 93 us for the reference on
+ * one host core -- the literal drop-in call is correct and four times faster than it was, still not faster than a host
+ * core.  Throughput comes from the batch entry points in curve25519_amd.h: a call of 2 operations already beats one host
+ * core, ~40 beat sixteen cores (a call of 1024 takes 0.22 ms: profiles/r04_small_batch_sweep.txt); the quoted rates need
+ * 2^17 and more per call (2^17: 99 M/s, 2^20: 123 M/s).
  */
 #ifndef CURVE25519_AMD_DH_H
 #define CURVE25519_AMD_DH_H

@@ -15,13 +15,14 @@
  * :289-331).  It is output-neutral, in the reference and here: signatures and public keys are
  * byte-identical with and without a context.
  *
- * Cost of ONE call: these are the reference's single-operation prototypes, and each call runs as a device
- * batch of one -- a whole kernel pass for one lane, about 0.2 ms per signature, 0.7 ms per verification,
- * 0.75 ms per X25519 (profiles/r03_batch_sweep.txt), i.e. SLOWER than the reference on one host core (43 us,
- * 190 us and 93 us there).  The device pays off through the *_batch / *_dev forms in curve25519_amd.h: from
- * about 10 operations per call a batch beats one host core, from a hundred or two it beats sixteen (small
- * batches run in narrower workgroups on more CUs: 2^14 signatures per call are 93 M/s, 2^16 330 M/s), and the
- * quoted throughput needs 2^17 and more per call.
+ * Cost of ONE call: these are the reference's single-operation prototypes, and each call runs as a device batch of
+ * one.  Key generation and signing of up to 2048 elements run ONE operation per wave (csrc/coop25519.cuh): 84 us per
+ * ed25519_CreateKeyPair, 110 us per ed25519_SignMessage end to end (profiles/r04_single_call.txt; 0.18 / 0.21 ms in
+ * round 3); a verification is still a whole one-operation-per-lane pass, 0.65 ms.  The reference on one host core of the
+ * same box: 43 us per signature, 190 us per verification, 93 us per X25519 -- a single call here is slower than there.
+ * The device pays off through the *_batch / *_dev forms in curve25519_amd.h: from 3 signatures per call a batch beats one
+ * host core (1024 signatures take 0.12 ms), from a few dozen it beats sixteen, and the quoted throughput needs 2^17 and
+ * more per call.
  */
 #ifndef CURVE25519_AMD_ED25519_SIGNATURE_H
 #define CURVE25519_AMD_ED25519_SIGNATURE_H

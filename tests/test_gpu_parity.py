@@ -845,6 +845,44 @@ def test_bench_self_launches_two_ranks(ranks, batch):
     assert len(line["verify"]["per_rank"]) == ranks
 
 
+def test_small_calls_run_one_operation_per_wave_and_agree_with_the_batch_kernels(api, oracle, monkeypatch):
+    """Calls of a few elements -- the reference's own single-call prototypes are calls of one -- run ONE operation per wave
+    (csrc/coop25519.cuh: a field element limb-per-lane, four products at a time; 4-5 x less latency), larger ones one
+    operation per lane.  Both shapes against the oracle and against each other around the switch, for every operation
+    that has both (C25519_AMD_COOP_MAX is read per call: 0 forces the batch kernels, a large value the per-wave ones)."""
+    import vectors
+    for n in (1, 2, 63, 64, 65, 300):
+        sk, pk = synth.random_bytes((n, 32), 0x7001 + n), synth.random_bytes((n, 32), 0x7101 + n)
+        sk[0], pk[0] = 0xff, 0xff                                     # all-ones key and peer (bit 255 set, >= p)
+        if n > 2:
+            pk[1] = vectors.le(2**255 - 19, 32)                       # p itself: a zero point, zero bytes out
+            pk[2] = 0                                                 # low order
+        esk, msg = synth.random_bytes((n, 32), 0x7201 + n), synth.random_bytes((n, 37), 0x7301 + n)
+        got = {}
+        for mode, knob in (("per wave", str(1 << 20)), ("per lane", "0")):
+            monkeypatch.setenv("C25519_AMD_COOP_MAX", knob)
+            shared, clamped = api.curve25519_dh_CreateSharedKey(pk, sk)
+            base, _ = api.curve25519_dh_CalculatePublicKey(sk)
+            fast, _ = api.curve25519_dh_CalculatePublicKey(sk, fast=True)
+            pub, priv = api.ed25519_CreateKeyPair(esk)
+            sig = api.ed25519_SignMessage(priv, msg)
+            got[mode] = (shared, clamped, base, fast, pub, priv, sig)
+        monkeypatch.delenv("C25519_AMD_COOP_MAX")
+        for a, b in zip(got["per wave"], got["per lane"]):
+            assert np.array_equal(a, b), n
+        shared, clamped, base, fast, pub, priv, sig = got["per wave"]
+        exp_shared, exp_clamped = oracle.x25519_shared(pk, sk)
+        assert np.array_equal(shared, exp_shared) and np.array_equal(clamped, exp_clamped)
+        assert np.array_equal(base, fast) and np.array_equal(base, oracle.x25519_shared(np.tile(vectors.le(9, 32), (n, 1)), sk)[0])
+        epub, epriv = oracle.ed25519_keypair(esk)
+        assert np.array_equal(pub, epub) and np.array_equal(priv, epriv) and np.array_equal(sig, oracle.ed25519_sign(epriv, msg))
+    # messages of other lengths through the per-wave signing kernel (the hashing is the batch kernels' code, run by every lane)
+    for mlen in (0, 1, 111, 112, 200):
+        esk, msg = synth.random_bytes((5, 32), 0x7401 + mlen), synth.random_bytes((5, mlen), 0x7501 + mlen)
+        pub, priv = api.ed25519_CreateKeyPair(esk)
+        assert np.array_equal(api.ed25519_SignMessage(priv, msg), oracle.ed25519_sign(priv, msg))
+
+
 def test_degenerate_but_valid_signatures_on_both_paths(api):
     """tests/golden/degenerate_verify.npz through ed25519_VerifySignature on the device: the default pass (lattice path +
     slow list) and, in a second process, C25519_AMD_VERIFY_REFERENCE_ORDER=1 (every element through the reference-order

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""tools/small_batch_sweep.py -- latency of a call of n device-resident elements, one operation per wave (coop25519.cuh)
+against one operation per lane (the batch kernels' narrow shapes), around the crossover C25519_AMD_COOP_MAX sets."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from curve25519_amd import api, synth  # noqa: E402
+
+dev = torch.device("cuda", 0)
+N = 1 << 14
+up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+sk, pk = (up(a) for a in synth.x25519_inputs(N))
+esk, msg = synth.ed25519_inputs(N)
+pub, priv = api.ed25519_CreateKeyPair(esk)
+desk, dpriv, dmsg = up(esk), up(priv), up(msg)
+o32, o64, p32, p64 = (torch.empty((N, w), dtype=torch.uint8, device=dev) for w in (32, 64, 32, 64))
+ops = {
+    "x25519": lambda n: api.curve25519_dh_CreateSharedKey_dev(o32[:n], pk[:n], sk[:n]),
+    "public_fast": lambda n: api.curve25519_dh_CalculatePublicKey_dev(o32[:n], sk[:n], fast=True),
+    "keypair": lambda n: api.ed25519_CreateKeyPair_dev(p32[:n], p64[:n], desk[:n]),
+    "sign": lambda n: api.ed25519_SignMessage_dev(o64[:n], dpriv[:n], dmsg[:n]),
+}
+
+
+def us(fn, n, reps=12):
+    fn(n); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(n); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+
+print(f"{'op':12s} {'n':>6s} {'one per wave [us]':>18s} {'one per lane [us]':>18s}")
+for name, fn in ops.items():
+    for n in (1, 16, 64, 256, 1024, 2048, 4096, 8192, 16384):
+        os.environ["C25519_AMD_COOP_MAX"] = str(1 << 20)
+        c = us(fn, n)
+        os.environ["C25519_AMD_COOP_MAX"] = "0"
+        b = us(fn, n)
+        print(f"{name:12s} {n:6d} {c:18.1f} {b:18.1f}", flush=True)
+os.environ.pop("C25519_AMD_COOP_MAX", None)
