@@ -430,11 +430,12 @@ def main():
         elapsed = time.perf_counter() - t0
         kms = [sum(events[k][j][0].elapsed_time(events[k][j][1]) for k in range(args.steps)) / max(1, args.steps)
                for j in range(len(passes))]
-        # device-side span of a step over all its streams: earliest start to latest end of its passes (for one pass per
-        # step this is the pass's own kernel time)
-        run_timed.span_ms = sum(max(origins[k].elapsed_time(events[k][j][1]) for j in range(len(passes)))
-                                - min(origins[k].elapsed_time(events[k][j][0]) for j in range(len(passes)))
-                                for k in range(args.steps)) / max(1, args.steps)
+        # device-side span of the timed steps over all their streams: the first pass's start to the last pass's end (HIP
+        # events against one origin), per step -- with one pass per step this is that pass's mean kernel time plus the gaps
+        # between steps; with three streams it is what the overlapping kernels took together
+        first = min(origins[0].elapsed_time(events[0][j][0]) for j in range(len(passes)))
+        last = max(origins[0].elapsed_time(events[args.steps - 1][j][1]) for j in range(len(passes)))
+        run_timed.span_ms = (last - first) / max(1, args.steps)
         attribution = None
         if use_dist:
             local_ms = elapsed / max(1, args.steps) * 1e3

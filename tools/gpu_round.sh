@@ -1,10 +1,10 @@
 #!/bin/bash
 # tools/gpu_round.sh -- one gpurun call's worth of work: the GPU test suite, bench lines, the instruction-rate
-# microbenchmark, the host-API rates and the rocprofv3 passes.  Everything lands under gpurun_out/$ROUND/ (default r03).
+# microbenchmark, the host-API rates and the rocprofv3 passes.  Everything lands under gpurun_out/$ROUND/ (default r04).
 #   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tests|bench|ubench|prof|all ...]'
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/${ROUND:-r03}
+OUT=$REPO/gpurun_out/${ROUND:-r04}
 mkdir -p $OUT
 cd $REPO
 WHAT=${*:-all}
@@ -25,8 +25,15 @@ if has bench; then
 fi
 if has ubench; then
   timeout 300 tools/ubench/valu_rates $OUT/valu_rates.json > $OUT/valu_rates.txt 2>&1; echo "ubench rc=$?"
-  timeout 300 tools/ubench/mad_peak $OUT/mad_peak.json > $OUT/mad_peak.txt 2>&1; echo "mad_peak rc=$?"; cat $OUT/mad_peak.txt
+  timeout 300 tools/ubench/mad_peak $OUT/mad_peak.json $OUT/mad_cycles.json > $OUT/mad_peak.txt 2>&1; echo "mad_peak rc=$?"; cat $OUT/mad_peak.txt
   [ -x tools/ubench/field_ab ] && { timeout 300 tools/ubench/field_ab > $OUT/field_ab.txt 2>&1; echo "field_ab rc=$?"; cat $OUT/field_ab.txt; }
+fi
+if has probe; then                                     # in-kernel s_memtime probe of the X25519 kernels (un-profiled launches)
+  P=curve25519_amd/libcurve25519_amd_probe.so
+  timeout 300 python tools/cycle_probe.py $P --json $OUT/cycle_probe.json > $OUT/cycle_probe.txt 2>&1; echo "probe rc=$?"
+  timeout 300 python tools/cycle_probe.py $P --fused >> $OUT/cycle_probe.txt 2>&1; echo "probe fused rc=$?"
+  timeout 300 python tools/single_call_latency.py > $OUT/single_call.txt 2>&1; timeout 300 python tools/single_call_breakdown.py >> $OUT/single_call.txt 2>&1
+  timeout 600 python tools/small_batch_sweep.py > $OUT/small_batch_sweep.txt 2>&1; echo "sweep rc=$?"
 fi
 if has ab && ls build_ab/*.so >/dev/null 2>&1; then
   timeout 900 python tools/ab_bench.py curve25519_amd/libcurve25519_amd.so build_ab/*.so ${AB_EXTRA:-} --ops ${AB_OPS:-x25519,sign,verify,keypair} --rounds ${AB_ROUNDS:-4} > $OUT/ab_bench.txt 2>&1
