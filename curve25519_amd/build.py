@@ -40,15 +40,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: the gfx950 library cannot be built on this machine")
+    tmp = f"{LIB}.tmp.{os.getpid()}"       # several ranks of one node may find the library stale at the same time: each
+                                            # builds into a file of its own and the rename is atomic
     # -pragma-unroll-threshold: k_batch_invert keeps 16 elements and their prefix products in registers, which needs its
     # three 16-trip loops fully unrolled; the default threshold refuses the third one and the arrays land in scratch
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-pragma-unroll-threshold=131072",
-           os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "multi_device.hip"), "-ldl", "-o", LIB + ".tmp"]
+           os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "multi_device.hip"), "-ldl", "-o", tmp]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 
@@ -59,10 +65,15 @@ def build_probe(force: bool = False, level: int = 1) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: the gfx950 library cannot be built on this machine")
-    subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
-                           "-pragma-unroll-threshold=131072", f"-DC25519_CYCLE_PROBE={level}",
-                           os.path.join(CSRC, "engine.hip"), "-o", PROBE_LIB + ".tmp"])
-    os.replace(PROBE_LIB + ".tmp", PROBE_LIB)
+    tmp = f"{PROBE_LIB}.tmp.{os.getpid()}"
+    try:
+        subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
+                               "-pragma-unroll-threshold=131072", f"-DC25519_CYCLE_PROBE={level}",
+                               os.path.join(CSRC, "engine.hip"), "-o", tmp])
+        os.replace(tmp, PROBE_LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return PROBE_LIB
 
 

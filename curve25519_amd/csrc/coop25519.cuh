@@ -27,6 +27,7 @@
 #pragma once
 #include "fe25519.cuh"
 #include "ge25519.cuh"
+#include "verify_fast.cuh"
 
 namespace c25519 {
 namespace coop {
@@ -309,6 +310,16 @@ C25519_DEV u32 row_limb_for_add(const u32* __restrict__ tbl, const Lane& L, u32 
     return row_limb(tbl, L, colbyte, by_row(L, 1, 0, 2, 2));
 }
 
+// second half of every addition: from (A, B, D, C) in the rows to the sum
+C25519_DEV u32 ge_add_finish(u32* lds, const Lane& L, u32 v)
+{
+    u32 ev, od;
+    pair_exchange(ev, od, v);
+    const u32 w = L.odd_row ? ev + od : (L.upper ? ev + L.p2 - od : od + L.p2 - ev);   // E = B-A, H = B+A, F = D-C, G = D+C
+    put(lds, L, L.row, w);
+    return mul_level(lds, L, by_row(L, 2, 3, 2, 0), by_row(L, 0, 1, 3, 1));          // F E, G H, F G, E H
+}
+
 // p += q, q a table row given as the limb each lane multiplies by (row_limb_for_add)
 C25519_DEV u32 ge_add(u32* lds, const Lane& L, u32 v, u32 qlimb)
 {
@@ -318,10 +329,22 @@ C25519_DEV u32 ge_add(u32* lds, const Lane& L, u32 v, u32 qlimb)
     put_a(lds, L, L.row, op);                             // Y-X, Y+X, 2Z, T
     put_y(lds, L, 4 + L.row, qlimb);
     v = mul_level(lds, L, L.row, by_row(L, 4, 5, SLOT_ONE, 7));      // A, B, D, C
+    return ge_add_finish(lds, L, v);
+}
+
+// p += q (or p -= q), q a projective precomputed row (Y+X, Y-X, 2dT, 2Z: edp_AddPoint, ed25519_verify.c:142-161) whose four
+// fields already sit in LDS in multiplier form, slots s_ypx .. s_ypx + 3.  -q swaps the first two and negates 2dT, which
+// costs nothing here: the two rows read each other's slot and row 3 multiplies -T instead.
+C25519_DEV u32 ge_add_pe(u32* lds, const Lane& L, u32 v, u32 s_ypx, u32 neg)
+{
+    u32 ev, od;
     pair_exchange(ev, od, v);
-    const u32 w = L.odd_row ? ev + od : (L.upper ? ev + L.p2 - od : od + L.p2 - ev);   // E = B-A, H = B+A, F = D-C, G = D+C
-    put(lds, L, L.row, w);
-    return mul_level(lds, L, by_row(L, 2, 3, 2, 0), by_row(L, 0, 1, 3, 1));          // F E, G H, F G, E H
+    const u32 t = neg ? L.p2 - od : od;
+    const u32 op = L.upper ? (L.odd_row ? t : ev) : (L.odd_row ? ev + od : od + L.p2 - ev);
+    put_a(lds, L, L.row, op);                             // Y-X, Y+X, Z, +-T
+    const u32 sw = neg ? 1u : 0u;
+    v = mul_level(lds, L, L.row, s_ypx + by_row(L, 1 ^ sw, 0 ^ sw, 3, 2));           // A, B, D, C
+    return ge_add_finish(lds, L, v);
 }
 
 // p = 2p
@@ -388,6 +411,115 @@ C25519_DEV void ge_affine_words(u32 (&xw)[8], u32 (&yw)[8], u32* lds, const Lane
     wave_fence();
     fe_to_words(xw, x);
     fe_to_words(yw, y);
+}
+
+// ---- verification: the lattice walk, one element per wave --------------------------------------------------------------
+// W = sigma*B + tau*Q + rho*Rn (verify_fast.cuh: ge_walk_is_neutral) for ONE element: the two 9-row window tables the points
+// kernel left in the element's scratch (packed rows), the biased scalars and sigma's comb columns the scalar kernel left
+// there, the walk's signed comb table in device memory.  All 72 table fields are unpacked limb-per-lane into LDS
+// multiplier forms first, all comb rows fetched, then the walk runs from LDS alone: two product levels per point
+// operation instead of ~800 instructions of one lane.
+constexpr int VSLOT0 = NSLOTS;                            // slot of field f of row r of table t: VSLOT0 + (t * 9 + r) * 4 + f
+constexpr int V_ROWQ_OFF = (VSLOT0 + 2 * WTABLE_ROWS * 4) * SLOT_WORDS;
+constexpr int V_LDS_WORDS = V_ROWQ_OFF + SC_ROUNDS * 4 * 64;
+
+// limb L.c of the 255-bit integer at p[0..7] (fe_from_words: bit 255 counts 19)
+C25519_DEV u32 packed_limb(const u32* __restrict__ p, const Lane& L)
+{
+    const u32 c = L.c < 10 ? L.c : 9;
+    const u32 pos = 26 * c - (c >> 1);                     // 0, 26, 51, 77, 102, 128, 153, 179, 204, 230
+    const u32 idx = pos >> 5;
+    const u64 two = (u64)p[idx] | ((u64)p[idx < 7 ? idx + 1 : 7] << 32);
+    u32 limb = (u32)(two >> (pos & 31)) & L.mask;
+    limb += (L.c == 0) ? 19u * (p[7] >> 31) : 0u;
+    return limb;
+}
+
+// limb of the field THIS row multiplies by in an addition of column byte c of the walk's signed comb (sign = bit
+// SC_TEETH - 1 clear, ge_add_pa_comb): row 0 ymx, row 1 ypx, row 3 2dxy, swapped / negated for a negative column
+C25519_DEV u32 comb_limb_for_add(const u32* __restrict__ tbl, const Lane& L, u32 c)
+{
+    const u32 neg = ((c >> (SC_TEETH - 1)) & 1u) - 1u;
+    const u32 r = (c ^ neg) & (u32)(SC_ROWS - 1);
+    const u32 f = by_row(L, 1, 0, 2, 2);
+    const u32 ff = (f < 2 && neg) ? 1u - f : f;
+    const u32 lc = L.c < 10 ? L.c : 9;
+    const u32 wd = tbl[(ff * 10 + lc) * SC_ROWS + r];
+    return (f == 2 && neg) ? L.p2 - wd : wd;
+}
+
+// all-ones iff sigma*B + tau*Q + rho*Rn is the neutral element.  tq / tr: the element's packed window tables;
+// sigma_w(w), tau_w(w), rho_w(w): words of its scalars; sc_tbl: the walk's comb table; top: first digit (>= SC_ROUNDS).
+template <typename Words>
+C25519_DEV u32 walk_is_neutral(u32* lds, const Lane& L, const Words& sc, const u32* __restrict__ tq, const u32* __restrict__ tr,
+                               const u32* __restrict__ sc_tbl, int top)
+{
+    const u32 lane = L.row * 16 + L.c;
+    // tables -> LDS multiplier forms
+#pragma unroll 1
+    for (int t = 0; t < 2; t++)
+#pragma unroll 1
+        for (int r = 0; r < WTABLE_ROWS; r++)
+#pragma unroll
+            for (int f = 0; f < 4; f++)
+                put_y(lds, L, VSLOT0 + (t * WTABLE_ROWS + r) * 4 + f, packed_limb((t ? tr : tq) + r * ROW_WORDS + 8 * f, L));
+    // sigma's comb rows, in the order the walk meets them: round i, step j -> column 4i + 3 - j
+#pragma unroll 1
+    for (int i = 0; i < SC_ROUNDS; i++) {
+        u64 cols = (u64)sc.sigma_word(2 * i) | ((u64)sc.sigma_word(2 * i + 1) << 32);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (4 * i + 3 - j < SC_COLS) lds[V_ROWQ_OFF + (i * 4 + j) * 64 + lane] = comb_limb_for_add(sc_tbl, L, (u32)cols & 0xffffu);
+            cols >>= 16;
+        }
+    }
+    put_y(lds, L, SLOT_KDI, my_limb(lds, L, fe_const(K_DI)));
+    auto digit = [&](u32 word, int i, u32& neg) -> u32 { return signed16_of(neg, word, i & 7); };
+    u32 v;
+    {   // the first digit: S = +-TQ[m] as an extended point (ge_from_pe), then += +-TR[m2]
+        u32 neg, neg2;
+        const u32 m = digit(sc.tau_word(top >> 3), top, neg), m2 = digit(sc.rho_word(top >> 3), top, neg2);
+        const u32* row = lds + (VSLOT0 + m * 4) * SLOT_WORDS + YO_OFF + 10 + (L.c < 10 ? L.c : 9);      // plain limbs of a field
+        const u32 a = row[(neg ? 1 : 0) * SLOT_WORDS], b = row[(neg ? 0 : 1) * SLOT_WORDS];             // Y+X, Y-X of +-row
+        const u32 t2d = row[2 * SLOT_WORDS], z2 = row[3 * SLOT_WORDS];
+        wave_fence();
+        put_a(lds, L, L.row, L.upper ? (L.odd_row ? (neg ? L.p2 - t2d : t2d) : z2) : (L.odd_row ? a + b : a + L.p2 - b));
+        v = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, SLOT_KDI));                 // 2x, 2y, 2z, 2xy
+        v = ge_add_pe(lds, L, v, VSLOT0 + (WTABLE_ROWS + m2) * 4, neg2);
+    }
+#pragma unroll 1
+    for (int i = top - 1; i >= 0; i--) {
+        if (i >= SC_ROUNDS) {
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) v = ge_dbl(lds, L, v);
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                v = ge_dbl(lds, L, v);
+                if (4 * i + 3 - j < SC_COLS) v = ge_add(lds, L, v, lds[V_ROWQ_OFF + (i * 4 + j) * 64 + lane]);
+            }
+        }
+        u32 neg;
+        const u32 mq = digit(sc.tau_word(i >> 3), i, neg);
+        v = ge_add_pe(lds, L, v, VSLOT0 + mq * 4, neg);
+        const u32 mr = digit(sc.rho_word(i >> 3), i, neg);
+        v = ge_add_pe(lds, L, v, VSLOT0 + (WTABLE_ROWS + mr) * 4, neg);
+    }
+    // neutral element: X == 0 and Y == Z
+    put_a(lds, L, L.row, v);
+    wave_fence();
+    fe X, Y, Z, d;
+    get_fe(X, lds, 0);
+    get_fe(Y, lds, 1);
+    get_fe(Z, lds, 2);
+    wave_fence();
+    fe_sub(d, Y, Z);
+    u32 xw[8], dw[8], acc = 0;
+    fe_to_words(xw, X);
+    fe_to_words(dw, d);
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc |= xw[i] | dw[i];
+    return acc == 0 ? 0xffffffffu : 0u;
 }
 
 }  // namespace coop
