@@ -1222,10 +1222,11 @@ bool coop_for(size_t n, size_t dflt)
     return n <= max && c25519_host::batch_shape_hint() <= max;
 }
 // crossovers measured on MI355X (tools/small_batch_sweep.py, profiles/r04_small_batch_sweep.txt): the ladder one per wave
-// wins up to 4096 elements (0.49 against 0.66 ms), the fixed-base operations up to 2048 (0.10-0.16 against 0.15-0.19 ms)
+// wins up to 4096 elements (0.49 against 0.66 ms), the fixed-base operations and verification's walk up to 2048
+// (0.10-0.16 against 0.15-0.19 ms; 0.38 against 0.60 ms)
 bool x25519_coop_for(size_t n) { return coop_for(n, 4096); }
 bool fixed_base_coop_for(size_t n) { return coop_for(n, 2048); }
-bool verify_coop_for(size_t n) { return coop_for(n, 1024); }
+bool verify_coop_for(size_t n) { return coop_for(n, 2048); }       // the walk alone: 0.25-0.38 against 0.60 ms
 
 // a batch that fills the chip runs the ladder and the shared inversion as two launches (k_x25519_ladder's comment);
 // C25519_AMD_XF_SPLIT=0/1 forces either shape (A/B knob, read per call)

@@ -16,9 +16,9 @@
  * byte-identical with and without a context.
  *
  * Cost of ONE call: these are the reference's single-operation prototypes, and each call runs as a device batch of
- * one.  Key generation and signing of up to 2048 elements run ONE operation per wave (csrc/coop25519.cuh): 84 us per
- * ed25519_CreateKeyPair, 110 us per ed25519_SignMessage end to end (profiles/r04_single_call.txt; 0.18 / 0.21 ms in
- * round 3); a verification is still a whole one-operation-per-lane pass, 0.65 ms.  The reference on one host core of the
+ * one.  Calls of up to 2048 elements run ONE operation per wave (csrc/coop25519.cuh): 84 us per ed25519_CreateKeyPair,
+ * 110 us per ed25519_SignMessage, 0.26 ms per ed25519_VerifySignature (its walk; decoding and hashing are still one lane's
+ * work) end to end (profiles/r04_single_call.txt; 0.18 / 0.21 / 0.65 ms in round 3).  The reference on one host core of the
  * same box: 43 us per signature, 190 us per verification, 93 us per X25519 -- a single call here is slower than there.
  * The device pays off through the *_batch / *_dev forms in curve25519_amd.h: from 3 signatures per call a batch beats one
  * host core (1024 signatures take 0.12 ms), from a few dozen it beats sixteen, and the quoted throughput needs 2^17 and

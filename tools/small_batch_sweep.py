@@ -18,11 +18,14 @@ esk, msg = synth.ed25519_inputs(N)
 pub, priv = api.ed25519_CreateKeyPair(esk)
 desk, dpriv, dmsg = up(esk), up(priv), up(msg)
 o32, o64, p32, p64 = (torch.empty((N, w), dtype=torch.uint8, device=dev) for w in (32, 64, 32, 64))
+dsig, dpub = up(api.ed25519_SignMessage(priv, msg)), up(pub)
+ok = torch.empty((N, 1), dtype=torch.int32, device=dev)
 ops = {
     "x25519": lambda n: api.curve25519_dh_CreateSharedKey_dev(o32[:n], pk[:n], sk[:n]),
     "public_fast": lambda n: api.curve25519_dh_CalculatePublicKey_dev(o32[:n], sk[:n], fast=True),
     "keypair": lambda n: api.ed25519_CreateKeyPair_dev(p32[:n], p64[:n], desk[:n]),
     "sign": lambda n: api.ed25519_SignMessage_dev(o64[:n], dpriv[:n], dmsg[:n]),
+    "verify": lambda n: api.ed25519_VerifySignature_dev(ok[:n], dsig[:n], dpub[:n], dmsg[:n]),
 }
 
 
