@@ -2,7 +2,8 @@
 """tests/long_differential.py -- opt-in long run (not collected by pytest): the HIP path against the REAL reference
 (oracle/_ref, the reference's own C files compiled by oracle/Makefile) on fresh random inputs at volume, with the edge
 encodings of tests/vectors.py sprinkled through every batch.  Every round: 2^20 X25519 shared keys, 2^18 key pairs +
-signatures, 2^18 verifications with corrupted entries, garbage keys and S + L rewrites.
+signatures, 2^18 verifications with corrupted entries, garbage keys and S + L rewrites; and, for the one-operation-per-wave
+kernels small calls run (csrc/coop25519.cuh), --small-calls calls of 1..2048 elements of every operation built the same way.
 
     python tests/long_differential.py [--rounds 8] [--seed 1]
 """
@@ -24,6 +25,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--threads", type=int, default=16)
+ap.add_argument("--small-calls", type=int, default=12, help="calls of a few elements per round and operation")
 args = ap.parse_args()
 assert Reference.available(), "oracle/_ref is not built (make -C oracle ref)"
 ref = Reference()
@@ -83,5 +85,20 @@ for r in range(args.rounds):
     rok = ref.ed25519_verify_threaded(bsig, vpk, bmsg, T)
     assert np.array_equal(ok, rok), f"round {r}: verdicts differ at rows {np.nonzero(ok != rok)[0][:5]}"
     total["verify"] += m
+    # calls of a few elements: other kernels (one operation per wave), same inputs' distribution
+    for c in range(args.small_calls):
+        k = int(rng.integers(1, 2049))
+        lo = int(rng.integers(0, m - k))
+        a, b = api.curve25519_dh_CreateSharedKey(pk[lo:lo + k], sk[lo:lo + k])
+        assert np.array_equal(a, want[lo:lo + k]) and np.array_equal(b, want_sk[lo:lo + k]), f"round {r}: small X25519 call {c} (n = {k}) differs"
+        fast, _ = api.curve25519_dh_CalculatePublicKey(sk[lo:lo + k], fast=True)
+        slow, _ = api.curve25519_dh_CalculatePublicKey(sk[lo:lo + min(k, 64)])
+        assert np.array_equal(fast[:len(slow)], slow) and np.array_equal(fast, ref.x25519_public(sk[lo:lo + k], fast=True)[0]), f"round {r}: small public-key call {c}"
+        p2, q2 = api.ed25519_CreateKeyPair(esk[lo:lo + k])
+        assert np.array_equal(p2, pub[lo:lo + k]) and np.array_equal(q2, priv[lo:lo + k]), f"round {r}: small keypair call {c} (n = {k}) differs"
+        assert np.array_equal(api.ed25519_SignMessage(priv[lo:lo + k], msg[lo:lo + k]), rsig[lo:lo + k]), f"round {r}: small sign call {c} (n = {k}) differs"
+        assert np.array_equal(api.ed25519_VerifySignature(bsig[lo:lo + k], vpk[lo:lo + k], bmsg[lo:lo + k]), rok[lo:lo + k]), f"round {r}: small verify call {c} (n = {k}) differs"
+        for key in ("x25519", "keypair", "sign", "verify"):
+            total["small " + key] = total.get("small " + key, 0) + k
     print(f"round {r}: ok (msg {mlen} B, accepted {int(ok.sum())} of {m})   {time.time() - t0:.0f} s", flush=True)
 print("long differential ok:", total)
