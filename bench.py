@@ -160,9 +160,11 @@ def roofline_for(wl, n, kernel_ms, probe=None):
             "peak_policy": "the fastest box's 8-waves-per-SIMD v_mad_u64_u32 stream of all committed rounds (wall-clock rate)"}
     if probe:
         # the fraction that says how close the kernel is to what its instruction stream allows: class-cost cycles of
-        # one ladder step / SIMD cycles measured per step (un-profiled, in-kernel).  Headline = measured class costs with
-        # every VOP2 instruction finding a partner from another wave (the best this stream can do at four waves).
-        valu.update({"issue_model_frac": probe.get("issue_model_frac_measured_vop2_paired"),
+        # one ladder step / SIMD cycles measured per step (un-profiled, in-kernel).  Headline = the floor of this stream at
+        # four waves: 4.26 cycles per 4-cycle-class instruction, every VOP2 instruction paired with another wave's and
+        # executed inside the former's issue bubbles as far as those reach (tools/cycle_probe.py: model_cycles("floor")).
+        valu.update({"issue_model_frac": probe.get("issue_model_frac_floor", probe.get("issue_model_frac_measured_vop2_paired")),
+                     "issue_model_cycles_per_step": probe.get("issue_model_cycles_floor"),
                      "issue_model_frac_nominal_4_4_2": probe.get("issue_model_frac_nominal"),
                      "simd_cycles_per_ladder_step": probe.get("simd_cycles_per_ladder_step"),
                      "ladder_step_instructions": probe.get("ladder_step_instructions"),

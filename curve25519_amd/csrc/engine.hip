@@ -124,7 +124,7 @@ C25519_DEV u32 fe_zero_to_one(fe& z)
 // of 256 CUs, two waves per SIMD -- but 256 of 64, one wave on a SIMD of its own, which finishes in little more than half
 // the time; the price, an inversion per 1 / 2 / 4 elements instead of 8, is 2-8 % more instructions.
 template <bool BASE9, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, BLOCK == XF_BLOCK ? C25519_XF_WAVES : 1) k_x25519_fused(void* out, const void* pk, void* sk, size_t n)
+__global__ void __launch_bounds__(BLOCK, C25519_XF_WAVES) k_x25519_fused(void* out, const void* pk, void* sk, size_t n)
 {
     constexpr int K = BLOCK / 64;            // elements per lane of the inverting wave
     __shared__ u32 zbuf[10 * BLOCK];      // PZ, later 1/PZ
@@ -289,16 +289,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
     u32 prev = 1;
 #pragma unroll 1
     for (int w = 7; w >= 0; w--) {
-        u32 kw = k[0];
+        u32 kw = k[7];                                   // the scalar's words as a queue (x25519.cuh)
 #pragma unroll
-        for (int t = 1; t < 8; t++) kw = (w == t) ? k[t] : kw;
+        for (int t = 7; t > 0; t--) k[t] = k[t - 1];
         const int top = (w == 7) ? 29 : 31, bottom = (w == 0) ? 3 : 0;
         kw <<= (31 - top);
 #pragma unroll 1
         for (int b = top; b >= bottom; b--) {
             const u32 bit = kw >> 31;
             kw <<= 1;
+#ifndef C25519_COOP_SKIP_LADDER                           // timing experiments only (tools/build_variants.sh): wrong results
             v = coop::ladder_step<BASE9>(lds, L, v, (u32)0 - (u32)(bit == prev));
+#endif
             prev = bit;
         }
     }
@@ -310,7 +312,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 #pragma unroll 1
     for (int i = 0; i < 3; i++) p = coop::mont_double(lds, L, p);
     // x / z: the odd rows' inverse times the even rows' x, in every row; canonical bytes by every lane
+#ifndef C25519_COOP_SKIP_INVERT
     const u32 zi = coop::invert(lds, L, p);
+#else
+    const u32 zi = p;
+#endif
     u32 px, pz, ix, iz;
     coop::pair_exchange(px, pz, p);
     coop::pair_exchange(ix, iz, zi);

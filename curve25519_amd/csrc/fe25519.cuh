@@ -37,6 +37,30 @@ constexpr u32 M25 = 0x1ffffffu;
 
 struct fe { u32 v[10]; };
 
+// A/B knob: the limb mask behind each product column at low wave priority too (valu_gfx950.cuh: C25519_VOP2_RUN_*)
+// every field addition / subtraction / negation / select is such a run (A/B knob C25519_FE_PRIO, default on); the operand
+// doublings at the head of a product too (C25519_MASK_PRIO >= 1)
+#ifndef C25519_FE_PRIO
+#define C25519_FE_PRIO 1
+#endif
+#if C25519_FE_PRIO
+#define C25519_FE_RUN_BEGIN() C25519_VOP2_RUN_BEGIN()
+#define C25519_FE_RUN_END() C25519_VOP2_RUN_END()
+#else
+#define C25519_FE_RUN_BEGIN() do { } while (0)
+#define C25519_FE_RUN_END() do { } while (0)
+#endif
+#ifndef C25519_MASK_PRIO
+#define C25519_MASK_PRIO 1
+#endif
+#if defined(C25519_MASK_PRIO) && C25519_MASK_PRIO
+#define C25519_MASK_RUN_BEGIN() C25519_VOP2_RUN_BEGIN()
+#define C25519_MASK_RUN_END() C25519_VOP2_RUN_END()
+#else
+#define C25519_MASK_RUN_BEGIN() do { } while (0)
+#define C25519_MASK_RUN_END() do { } while (0)
+#endif
+
 C25519_DEV constexpr int fe_w(int i) { return (i & 1) ? 25 : 26; }
 C25519_DEV constexpr u32 fe_mask(int i) { return (i & 1) ? M25 : M26; }
 // limbs of 2p: every limb stays >= 0 after subtracting a reduced element
@@ -51,29 +75,37 @@ C25519_DEV void fe_set_u32(fe& r, u32 x)
 
 C25519_DEV void fe_add(fe& r, const fe& a, const fe& b)
 {
+    C25519_FE_RUN_BEGIN();
 #pragma unroll
     for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + b.v[i];
+    C25519_FE_RUN_END();
 }
 
 // r = a - b + 2p  (b must be reduced so that no limb goes negative)
 C25519_DEV void fe_sub(fe& r, const fe& a, const fe& b)
 {
+    C25519_FE_RUN_BEGIN();
 #pragma unroll
     for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + fe_2p(i) - b.v[i];
+    C25519_FE_RUN_END();
 }
 
 // r = 2p - a   (the reference negates with _w_maxP - A, ed25519_sign.c:130)
 C25519_DEV void fe_neg(fe& r, const fe& a)
 {
+    C25519_FE_RUN_BEGIN();
 #pragma unroll
     for (int i = 0; i < 10; i++) r.v[i] = fe_2p(i) - a.v[i];
+    C25519_FE_RUN_END();
 }
 
 // branch-free select: r = mask ? a : b, mask is all-ones or zero
 C25519_DEV void fe_select(fe& r, u32 mask, const fe& a, const fe& b)
 {
+    C25519_FE_RUN_BEGIN();
 #pragma unroll
     for (int i = 0; i < 10; i++) r.v[i] = (a.v[i] & mask) | (b.v[i] & ~mask);
+    C25519_FE_RUN_END();
 }
 
 // limbs l[0..9] hold the masked columns, `carry` is what left column 9: fold it back times 19
@@ -89,13 +121,18 @@ C25519_DEV void fe_finish_chain(fe& r, u32 (&l)[10], u64 carry)
     for (int i = 0; i < 10; i++) r.v[i] = l[i];
 }
 
+// RUNS: the operand doublings as a low-priority run and a priority dip behind every column (C25519_VOP2_RUN_*): worth
+// 1.7 % on the X25519 ladder at four waves per SIMD, costs 1.7 % in the verification walk at two (profiles/r04_ab_prio.txt)
+template <bool RUNS = false>
 C25519_DEV void fe_mul_chained(fe& r, const fe& a, const fe& b)
 {
     u32 b19[10], a2[10], l[10];
 #pragma unroll
     for (int j = 1; j < 10; j++) b19[j] = b.v[j] * 19u;
+    if (RUNS) C25519_MASK_RUN_BEGIN();
 #pragma unroll
     for (int i = 1; i < 10; i += 2) a2[i] = dbl32(a.v[i]);
+    if (RUNS) C25519_MASK_RUN_END();
     u64 acc = 0;
 #pragma unroll
     for (int k = 0; k < 10; k++) {
@@ -109,6 +146,7 @@ C25519_DEV void fe_mul_chained(fe& r, const fe& a, const fe& b)
             y[i] = wrap ? b19[j] : b.v[j];
         }
         acc = k == 0 ? mad_chain10_from_zero(x, y) : mad_chain10(acc, x, y);
+        if (RUNS) { C25519_MASK_RUN_BEGIN(); C25519_MASK_RUN_END(); }
         l[k] = (u32)acc & fe_mask(k);
         acc >>= fe_w(k);
     }
@@ -116,12 +154,14 @@ C25519_DEV void fe_mul_chained(fe& r, const fe& a, const fe& b)
 }
 
 // PLAIN: extra(k) is zero for every k (a bare square), so column 0 starts from nothing
-template <bool SCALE2, bool PLAIN = false, typename Extra>
+template <bool SCALE2, bool PLAIN = false, bool RUNS = false, typename Extra>
 C25519_DEV void fe_sqr_chained(fe& r, const fe& a, Extra extra)
 {
     u32 f2[10], f19[10], f38[10], l[10];
+    if (RUNS) C25519_MASK_RUN_BEGIN();
 #pragma unroll
     for (int i = 0; i < 10; i++) f2[i] = dbl32(a.v[i]);
+    if (RUNS) C25519_MASK_RUN_END();
 #pragma unroll
     for (int j = 6; j < 10; j += 2) f19[j] = a.v[j] * 19u;
 #pragma unroll
@@ -157,6 +197,7 @@ C25519_DEV void fe_sqr_chained(fe& r, const fe& a, Extra extra)
             acc = from_zero ? mad_chain6_from_zero(x, y) : mad_chain6(acc, x, y);
         }
         if (SCALE2) acc = 2 * acc + carry + extra(k);
+        if (RUNS) { C25519_MASK_RUN_BEGIN(); C25519_MASK_RUN_END(); }
         l[k] = (u32)acc & fe_mask(k);
         carry = acc >> fe_w(k);
     }
@@ -166,7 +207,16 @@ C25519_DEV void fe_sqr_chained(fe& r, const fe& a, Extra extra)
 // r = a * b.   beta_a <= 5, beta_b <= 3.3; r may alias a or b.   (ecp_MulReduce)
 C25519_DEV void fe_mul(fe& r, const fe& a, const fe& b)
 {
-    fe_mul_chained(r, a, b);
+    fe_mul_chained<false>(r, a, b);
+}
+// ... with the low-priority runs inside (the ladder's products)
+C25519_DEV void fe_mul_runs(fe& r, const fe& a, const fe& b)
+{
+    fe_mul_chained<true>(r, a, b);
+}
+C25519_DEV void fe_sqr_runs(fe& r, const fe& a)
+{
+    fe_sqr_chained<false, true, true>(r, a, [](int) -> u64 { return 0; });
 }
 
 // r = a^2.   beta_a <= 3.3; r may alias a.   (ecp_SqrReduce)

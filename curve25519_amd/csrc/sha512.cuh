@@ -133,7 +133,13 @@ C25519_DEV void sha512_prefixed(u64 (&digest)[8], const u64 (&prefix)[PW], const
             else v = sha512_msg_word(msg, len, g - PW);
             w[j] = v;
         }
+#ifdef C25519_SHA_LOW_PRIO                               // A/B knob: the compression (no multiplies) as a low-priority run
+        C25519_VOP2_RUN_BEGIN();
+#endif
         sha512_compress(st, w);
+#ifdef C25519_SHA_LOW_PRIO
+        C25519_VOP2_RUN_END();
+#endif
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) digest[i] = st[i];

@@ -13,6 +13,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#if defined(C25519_CHAIN_DIP) && C25519_CHAIN_DIP               // A/B knob: a priority dip in the middle of a ten-MAD chain
+#define C25519_MID_DIP "s_setprio 0\n\ts_setprio 1\n\t"
+#else
+#define C25519_MID_DIP ""
+#endif
+#if defined(C25519_MAD_CHAIN_PRIO) && C25519_MAD_CHAIN_PRIO     // A/B knob: only the MAD chains at high wave priority
+#define C25519_CHAIN_HI "s_setprio 1\n\t"
+#define C25519_CHAIN_LO "\n\ts_setprio 0"
+#else
+#define C25519_CHAIN_HI ""
+#define C25519_CHAIN_LO ""
+#endif
+
 namespace c25519 {
 
 typedef uint32_t u32;
@@ -22,6 +35,22 @@ typedef uint64_t u64;
 // nothing is scheduled across this point: keeps the live ranges of two neighbouring field operations apart where the
 // scheduler's interleaving would cost registers the kernel does not have (a no-op in the CPU model)
 #define C25519_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// A run of VOP2 instructions (a field addition / subtraction: ten to twenty 32-bit adds) costs half an issue slot per
+// instruction only when ANOTHER wave's VOP2 instruction shares the slot, and a whole slot -- what a MAD costs -- when it
+// stands alone among the other waves' MADs (tools/ubench/mad_peak, profiles/r04_mad_peak.txt).  A wave that drops its
+// priority for the run is passed over while the others issue MADs and issues its run when a second wave has reached one
+// too (or nobody else can issue): the runs pair up.  Measured on the ladder: profiles/r04_ab_prio.txt.
+#ifndef C25519_VOP2_RUN_PRIO
+#define C25519_VOP2_RUN_PRIO 1        // A/B switch: 0 = no priority changes
+#endif
+#if C25519_VOP2_RUN_PRIO
+#define C25519_VOP2_RUN_BEGIN() __builtin_amdgcn_s_setprio(0)
+#define C25519_VOP2_RUN_END() __builtin_amdgcn_s_setprio(1)
+#else
+#define C25519_VOP2_RUN_BEGIN() do { } while (0)
+#define C25519_VOP2_RUN_END() do { } while (0)
+#endif
 
 // 2x as v_add_u32 x, x: v_add_u32 is full-rate, while v_lshlrev_b32 -- what the compiler picks for x*2 or x+x --
 // is in the half-rate class.
@@ -45,11 +74,11 @@ C25519_DEV u64 mad_chain5(u64 acc, const u32 (&x)[5], const u32 (&y)[5])
 {
     u64 carry_out;
     asm(
-        "v_mad_u64_u32 %0, %1, %2, %7, %0\n\t"
+        C25519_CHAIN_HI "v_mad_u64_u32 %0, %1, %2, %7, %0\n\t"
         "v_mad_u64_u32 %0, %1, %3, %8, %0\n\t"
         "v_mad_u64_u32 %0, %1, %4, %9, %0\n\t"
         "v_mad_u64_u32 %0, %1, %5, %10, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %6, %11, %0"
+        "v_mad_u64_u32 %0, %1, %6, %11, %0" C25519_CHAIN_LO
         : "+v"(acc), "=s"(carry_out)
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]),
           "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]));
@@ -62,11 +91,11 @@ C25519_DEV u64 mad_chain5_from_zero(const u32 (&x)[5], const u32 (&y)[5])
 {
     u64 acc, carry_out;
     asm(
-        "v_mad_u64_u32 %0, %1, %2, %7, 0\n\t"
+        C25519_CHAIN_HI "v_mad_u64_u32 %0, %1, %2, %7, 0\n\t"
         "v_mad_u64_u32 %0, %1, %3, %8, %0\n\t"
         "v_mad_u64_u32 %0, %1, %4, %9, %0\n\t"
         "v_mad_u64_u32 %0, %1, %5, %10, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %6, %11, %0"
+        "v_mad_u64_u32 %0, %1, %6, %11, %0" C25519_CHAIN_LO
         : "=&v"(acc), "=s"(carry_out)
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]),
           "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]));
@@ -77,12 +106,12 @@ C25519_DEV u64 mad_chain6_from_zero(const u32 (&x)[6], const u32 (&y)[6])
 {
     u64 acc, carry_out;
     asm(
-        "v_mad_u64_u32 %0, %1, %2, %8, 0\n\t"
+        C25519_CHAIN_HI "v_mad_u64_u32 %0, %1, %2, %8, 0\n\t"
         "v_mad_u64_u32 %0, %1, %3, %9, %0\n\t"
         "v_mad_u64_u32 %0, %1, %4, %10, %0\n\t"
         "v_mad_u64_u32 %0, %1, %5, %11, %0\n\t"
         "v_mad_u64_u32 %0, %1, %6, %12, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %7, %13, %0"
+        "v_mad_u64_u32 %0, %1, %7, %13, %0" C25519_CHAIN_LO
         : "=&v"(acc), "=s"(carry_out)
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
           "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]));
@@ -93,16 +122,16 @@ C25519_DEV u64 mad_chain10_from_zero(const u32 (&x)[10], const u32 (&y)[10])
 {
     u64 acc, carry_out;
     asm(
-        "v_mad_u64_u32 %0, %1, %2, %12, 0\n\t"
+        C25519_CHAIN_HI "v_mad_u64_u32 %0, %1, %2, %12, 0\n\t"
         "v_mad_u64_u32 %0, %1, %3, %13, %0\n\t"
         "v_mad_u64_u32 %0, %1, %4, %14, %0\n\t"
         "v_mad_u64_u32 %0, %1, %5, %15, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %6, %16, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %16, %0\n\t" C25519_MID_DIP
         "v_mad_u64_u32 %0, %1, %7, %17, %0\n\t"
         "v_mad_u64_u32 %0, %1, %8, %18, %0\n\t"
         "v_mad_u64_u32 %0, %1, %9, %19, %0\n\t"
         "v_mad_u64_u32 %0, %1, %10, %20, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %11, %21, %0"
+        "v_mad_u64_u32 %0, %1, %11, %21, %0" C25519_CHAIN_LO
         : "=&v"(acc), "=s"(carry_out)
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]),
           "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8]), "v"(y[9]));
@@ -113,12 +142,12 @@ C25519_DEV u64 mad_chain6(u64 acc, const u32 (&x)[6], const u32 (&y)[6])
 {
     u64 carry_out;
     asm(
-        "v_mad_u64_u32 %0, %1, %2, %8, %0\n\t"
+        C25519_CHAIN_HI "v_mad_u64_u32 %0, %1, %2, %8, %0\n\t"
         "v_mad_u64_u32 %0, %1, %3, %9, %0\n\t"
         "v_mad_u64_u32 %0, %1, %4, %10, %0\n\t"
         "v_mad_u64_u32 %0, %1, %5, %11, %0\n\t"
         "v_mad_u64_u32 %0, %1, %6, %12, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %7, %13, %0"
+        "v_mad_u64_u32 %0, %1, %7, %13, %0" C25519_CHAIN_LO
         : "+v"(acc), "=s"(carry_out)
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
           "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]));
@@ -129,16 +158,16 @@ C25519_DEV u64 mad_chain10(u64 acc, const u32 (&x)[10], const u32 (&y)[10])
 {
     u64 carry_out;
     asm(
-        "v_mad_u64_u32 %0, %1, %2, %12, %0\n\t"
+        C25519_CHAIN_HI "v_mad_u64_u32 %0, %1, %2, %12, %0\n\t"
         "v_mad_u64_u32 %0, %1, %3, %13, %0\n\t"
         "v_mad_u64_u32 %0, %1, %4, %14, %0\n\t"
         "v_mad_u64_u32 %0, %1, %5, %15, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %6, %16, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %16, %0\n\t" C25519_MID_DIP
         "v_mad_u64_u32 %0, %1, %7, %17, %0\n\t"
         "v_mad_u64_u32 %0, %1, %8, %18, %0\n\t"
         "v_mad_u64_u32 %0, %1, %9, %19, %0\n\t"
         "v_mad_u64_u32 %0, %1, %10, %20, %0\n\t"
-        "v_mad_u64_u32 %0, %1, %11, %21, %0"
+        "v_mad_u64_u32 %0, %1, %11, %21, %0" C25519_CHAIN_LO
         : "+v"(acc), "=s"(carry_out)
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]),
           "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(y[8]), "v"(y[9]));

@@ -26,13 +26,17 @@ C25519_DEV void mont_double(fe& X, fe& Z)
     fe A, B;
     fe_add(A, X, Z);                   // beta 2
     fe_sub(B, X, Z);                   // beta 3
-    fe_sqr(A, A);
-    fe_sqr(B, B);
-    fe_mul(X, A, B);
+    fe_sqr_runs(A, A);
+    fe_sqr_runs(B, B);
+    fe_mul_runs(X, A, B);
     fe_sub(B, A, B);                   // beta 3
     fe_mul121665_add(A, A, B);
-    fe_mul(Z, B, A);
+    fe_mul_runs(Z, B, A);
 }
+
+#ifndef C25519_LADDER_PRIO_SITES
+#define C25519_LADDER_PRIO_SITES 0
+#endif
 
 // no-op section marker of the product build; the opt-in cycle-probe build (engine.hip, -DC25519_CYCLE_PROBE=2) passes
 // one that reads s_memtime, so that the sections of a step can be timed in place (tools/cycle_probe.py)
@@ -44,35 +48,53 @@ template <bool BASE9 = false, typename Mark = NoSectionMark>
 C25519_DEV void ladder_step(fe& SX, fe& SZ, fe& DX, fe& DZ, const fe& base, u32 prev_eq, Mark mark = Mark())
 {
     fe A, B, C, Dp, P, M;
+#if C25519_LADDER_PRIO_SITES >= 1
+    C25519_VOP2_RUN_BEGIN();
+#endif
     fe_sub(A, SX, SZ);                 // beta 3
     fe_add(B, SX, SZ);                 // beta 2
     fe_sub(C, DX, DZ);                 // beta 3
     fe_add(Dp, DX, DZ);                // beta 2
     fe_select(P, prev_eq, Dp, B);      // doubling input, x+z
     fe_select(M, prev_eq, C, A);       // doubling input, x-z
+#if C25519_LADDER_PRIO_SITES >= 1
+    C25519_VOP2_RUN_END();
+#endif
     mark(0);
-    fe_mul(A, A, Dp);                  // (x1-z1)(x2+z2)
+    fe_mul_runs(A, A, Dp);                  // (x1-z1)(x2+z2)
     mark(1);
-    fe_mul(B, C, B);                   // (x2-z2)(x1+z1)
+    fe_mul_runs(B, C, B);                   // (x2-z2)(x1+z1)
     mark(2);
+#if C25519_LADDER_PRIO_SITES >= 2
+    C25519_VOP2_RUN_BEGIN();
+#endif
     fe_add(C, A, B);                   // beta 2
     fe_sub(B, A, B);                   // beta 3
+#if C25519_LADDER_PRIO_SITES >= 2
+    C25519_VOP2_RUN_END();
+#endif
     mark(3);
-    fe_sqr(SX, C);                     // x3
-    fe_sqr(A, B);
+    fe_sqr_runs(SX, C);                     // x3
+    fe_sqr_runs(A, B);
     mark(4);
     if (BASE9) fe_mul_small(SZ, A, 9);  // z3 = (..)^2 * 9
-    else fe_mul(SZ, A, base);          // z3 = (..)^2 * xb
+    else fe_mul_runs(SZ, A, base);          // z3 = (..)^2 * xb
     mark(5);
-    fe_sqr(A, P);                      // (x+z)^2
-    fe_sqr(B, M);                      // (x-z)^2
+    fe_sqr_runs(A, P);                      // (x+z)^2
+    fe_sqr_runs(B, M);                      // (x-z)^2
     mark(6);
-    fe_mul(DX, A, B);                  // x4
+    fe_mul_runs(DX, A, B);                  // x4
     mark(7);
+#if C25519_LADDER_PRIO_SITES >= 3
+    C25519_VOP2_RUN_BEGIN();
+#endif
     fe_sub(B, A, B);                   // beta 3
+#if C25519_LADDER_PRIO_SITES >= 3
+    C25519_VOP2_RUN_END();
+#endif
     fe_mul121665_add(A, A, B);         // (x+z)^2 + 121665*B
     mark(8);
-    fe_mul(DZ, B, A);                  // z4
+    fe_mul_runs(DZ, B, A);                  // z4
     mark(9);
 }
 
@@ -94,11 +116,14 @@ C25519_DEV void x25519_ladder_xz(fe& PX, fe& PZ, const u32 (&u)[8], const u32 (&
 
     // state invariant: previous bit b_prev = 1  <=>  (P,Q) = (S,D); else (P,Q) = (D,S)
     u32 prev = 1;
+    u32 kq[8];                                           // the scalar's words as a queue: the next one is always kq[7] (an index
+#pragma unroll                                           // by the loop counter, or a chain of selects on it, ends up as a
+    for (int t = 0; t < 8; t++) kq[t] = k[t];            // scratch array -- the key would go through memory)
 #pragma unroll 1
     for (int w = 7; w >= 0; w--) {
-        u32 kw = k[0];
+        u32 kw = kq[7];
 #pragma unroll
-        for (int t = 1; t < 8; t++) kw = (w == t) ? k[t] : kw;
+        for (int t = 7; t > 0; t--) kq[t] = kq[t - 1];
         const int top = (w == 7) ? 29 : 31;              // bit 254 consumed above, bit 255 is zero
         const int bottom = (w == 0) ? 3 : 0;             // bits 2..0 are zero after clamping: handled below
         kw <<= (31 - top);

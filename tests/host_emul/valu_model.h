@@ -16,6 +16,8 @@
 #define __restrict__
 #define C25519_DEV inline
 #define C25519_SCHED_FENCE() ((void)0)
+#define C25519_VOP2_RUN_BEGIN() ((void)0)       // wave priority around runs of VOP2 instructions: nothing to model
+#define C25519_VOP2_RUN_END() ((void)0)
 
 struct uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{ x, y, z, w }; }

@@ -33,9 +33,21 @@ STEPS = 251 + 4 * 0.55            # 251 ladder steps + the opening doubling and 
 # the ladder step's instruction stream (profiles/r03_isa_mix.txt): v_mad_u64_u32, other 4-cycle-class VALU, VOP2
 STEP_MAD, STEP_HALF, STEP_FULL = 739, 188, 319
 # class costs in SIMD cycles per wave-instruction: nominal, and as measured in place by tools/ubench/mad_peak at four
-# resident waves (profiles/r04_mad_peak.txt): MAD and the other 4-cycle-class instructions 4.26; a VOP2 instruction 2.13
-# in a run of its own kind on all waves, but ~4 when it stands alone between MADs of the other waves
+# resident waves (profiles/r04_mad_peak.txt): MAD and the other 4-cycle-class instructions 4.26 -- 4.0 of execution and
+# a 0.26 issue bubble --; a VOP2 instruction 2.13 when another wave's VOP2 shares its slot, ~4.2 alone between MADs.
+# "floor": the VOP2 instructions paired AND executed inside the 4-cycle class' bubbles as far as those reach -- what the
+# stream costs when VOP2 runs wait at low wave priority for each other (valu_gfx950.cuh: C25519_VOP2_RUN_*).
 MODELS = {"nominal": (4.0, 2.0), "measured_vop2_paired": (4.26, 2.13), "measured_vop2_unpaired": (4.26, 4.26)}
+BUBBLE = 0.26
+
+
+def model_cycles(name):
+    if name == "floor":
+        c4, c2 = MODELS["measured_vop2_paired"]
+        n4 = STEP_MAD + STEP_HALF
+        return n4 * c4 + max(0.0, STEP_FULL * c2 - n4 * BUBBLE)
+    c4, c2 = MODELS[name]
+    return (STEP_MAD + STEP_HALF) * c4 + STEP_FULL * c2
 WORDS = 20
 
 
@@ -110,17 +122,21 @@ def summary(ms, rec):
     # the number of resident waves.  The cadence (time between consecutive ladder completions on one SIMD, the first
     # four left out) is the SIMD time one ladder costs.
     cad = np.concatenate([np.diff(np.sort(t[simd_key == k, 1]))[4:] for k in np.unique(simd_key)])
-    per_step = float(np.median(cad)) / STEPS if len(cad) else None
+    # SIMD time per ladder: a CU's span over the waves each of its SIMDs served (the cadence says the same while the SIMD
+    # serves its waves strictly one after the other; with priority changes inside the step it no longer does)
+    per_simd = np.bincount(np.unique(simd_key, return_inverse=True)[1])
+    per_step = float(np.median(spans)) / float(np.median(per_simd)) / STEPS if len(per_simd) and np.median(per_simd) >= 8 else None
     out = {"kernel_span_Mcycles": round(float(np.median(spans)) / 1e6, 3), "event_ms": round(ms, 4),
            "shader_clock_GHz": round(clock, 3) if clock else None,
            "shader_clock_GHz_span_over_event_time": round(float(np.median(spans)) / (ms * 1e6), 3),
            "simd_cycles_per_ladder_step": round(per_step, 1) if per_step else None,
            "ladder_step_instructions": {"v_mad_u64_u32": STEP_MAD, "other_4_cycle_class": STEP_HALF, "vop2": STEP_FULL}}
     if per_step:
-        for name, (cm, cf) in MODELS.items():
-            model = (STEP_MAD + STEP_HALF) * cm + STEP_FULL * cf
-            out["issue_model_frac_" + name] = round(model / per_step, 4)
+        for name in list(MODELS) + ["floor"]:
+            out["issue_model_frac_" + name] = round(model_cycles(name) / per_step, 4)
+        out["issue_model_cycles_floor"] = round(model_cycles("floor"), 1)
         out["vop2_cycles_implied"] = round((per_step - (STEP_MAD + STEP_HALF) * MODELS["measured_vop2_paired"][0]) / STEP_FULL, 3)
+        out["ladder_cadence_Mcycles"] = round(float(np.median(cad)) / 1e6, 4) if len(cad) else None
     return out, cad, spans
 
 
@@ -136,11 +152,12 @@ def report_phases(ms, rec, fused):
     ladder, wait1, inv, wait2, fin = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3], t[:, 5] - t[:, 4]
     print(f"ladder phase of a wave (wall): median {np.median(ladder) / 1e6:.3f} M cycles; ladder completions on one SIMD are {np.median(cad) / 1e6:.4f} M cycles apart"
           f" (p10 {np.percentile(cad, 10) / 1e6:.4f}, p90 {np.percentile(cad, 90) / 1e6:.4f})")
-    print(f"SIMD cycles per ladder step per wave: {s['simd_cycles_per_ladder_step']:.0f}" + ("   (fused: includes the inversion's share of the SIMD)" if fused else ""))
+    print(f"SIMD cycles per ladder step per wave: {s['simd_cycles_per_ladder_step']:.0f} (CU span / waves per SIMD / steps)" + ("   (fused: includes the inversion's share of the SIMD)" if fused else ""))
     for mname, (cm, cf) in MODELS.items():
-        model = (STEP_MAD + STEP_HALF) * cm + STEP_FULL * cf
-        print(f"   issue model [{mname}: MAD / 4-cycle class {cm:.2f}, VOP2 {cf:.2f} cycles]: {model:.0f} -> issue_model_frac {s['issue_model_frac_' + mname]:.3f}")
-    print(f"   -> with the 4-cycle class at its measured 4.26, the step's {STEP_FULL} VOP2 instructions cost {s['vop2_cycles_implied']:.2f} cycles each on average (2.13 paired, ~4.2 alone)")
+        print(f"   issue model [{mname}: MAD / 4-cycle class {cm:.2f}, VOP2 {cf:.2f} cycles]: {model_cycles(mname):.0f} -> issue_model_frac {s['issue_model_frac_' + mname]:.3f}")
+    print(f"   issue model [floor: 4.26 per 4-cycle-class instruction, VOP2 paired (2.13) and inside the 0.26-cycle bubbles of the former as far as they reach]: "
+          f"{model_cycles('floor'):.0f} -> issue_model_frac {s['issue_model_frac_floor']:.3f}")
+    print(f"   -> beyond 4.26 per 4-cycle-class instruction the step's {STEP_FULL} VOP2 instructions cost {s['vop2_cycles_implied']:.2f} cycles each on average (2.13 paired, ~4.2 alone)")
     k0 = np.unique(simd_key)[0]
     o = np.where(simd_key == k0)[0]
     o = o[np.argsort(t[o, 0])]

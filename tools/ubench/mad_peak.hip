@@ -213,6 +213,28 @@ __global__ void __launch_bounds__(256) k_loop(unsigned* out, unsigned seed, int 
     if constexpr (ID == 25) LOOP(PAD0, X8(RUN8));
     if constexpr (ID == 26) LOOP(PAD0, X8(RUN1S));
     if constexpr (ID == 27) LOOP(PAD0, X8(RUN1ADD));
+    // two streams on one SIMD: the workgroups alternate between a pure MAD loop and a pure VOP2 loop (a workgroup is four
+    // waves, one per SIMD, so every SIMD holds both kinds); ID 28 at equal wave priority, ID 29 with the VOP2 waves at
+    // priority 0 and the MAD waves at 1 -- can the two classes run side by side?
+    if constexpr (ID == 28 || ID == 29) {
+        if (blockIdx.x & 1) {
+            if (ID == 29) __builtin_amdgcn_s_setprio(1);
+            LOOP(PAD0, X16(MAD8));
+        } else {
+            if (ID == 29) __builtin_amdgcn_s_setprio(0);
+            LOOP(PAD0, X16(AND8));
+        }
+    }
+    // does a wave-priority instruction between MADs change what a MAD costs?  (the ladder with priority dips around its
+    // VOP2 runs costs 4.0 cycles per 4-cycle-class instruction where the plain one costs 4.26: profiles/r04_cycle_probe.txt)
+#define DIP "s_setprio 0\n\ts_setprio 1\n\t"
+#define ONE "s_setprio 1\n\t"
+#define NOP "s_nop 0\n\t"
+    if constexpr (ID == 30) LOOP(PAD0, X16(MAD8 DIP));
+    if constexpr (ID == 31) LOOP(PAD0, X8(MAD8 MAD8 DIP));
+    if constexpr (ID == 32) LOOP(PAD0, X16(MAD8 ONE));
+    if constexpr (ID == 33) LOOP(PAD0, X16(MAD8 NOP));
+    if constexpr (ID == 34) LOOP(PAD0, X16(MADDEP8 DIP));
     if (r == 0x12345678u) out[0] = r;
     const unsigned long long t1 = now_cycles();
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
@@ -247,9 +269,16 @@ static const Row rows[] = {
     { 25, 128, 1, "mad_and_runs_of_8", "8 MADs, 8 masks, ... (64 + 64 per trip)" },
     { 26, 128, 1, "shr64_and_runs_of_1", "v_lshrrev_b64, mask, v_lshrrev_b64, mask ... (64 + 64 per trip)" },
     { 27, 128, 1, "mad_add_runs_of_1", "MAD, v_add_u32 (VOP2, two VGPRs), MAD, v_add_u32 ... (64 + 64 per trip)" },
+    { 30, 128, 1, "mad_dip_every_8", "v_mad_u64_u32, s_setprio 0 ; s_setprio 1 behind every 8 (128 MADs per trip)" },
+    { 31, 128, 1, "mad_dip_every_16", "v_mad_u64_u32, s_setprio 0 ; s_setprio 1 behind every 16" },
+    { 32, 128, 1, "mad_setprio1_every_8", "v_mad_u64_u32, s_setprio 1 behind every 8 (no change of level)" },
+    { 33, 128, 1, "mad_nop_every_8", "v_mad_u64_u32, s_nop 0 behind every 8" },
+    { 34, 128, 1, "mad_one_chain_dip_every_8", "v_mad_u64_u32, ONE dependent chain, the dip behind every 8" },
+    { 28, 128, 1, "mad_waves_and_vop2_waves", "half the waves pure MAD, half pure v_and_b32, equal priority" },
+    { 29, 128, 1, "mad_waves_and_vop2_waves_prio", "half the waves pure MAD (priority 1), half pure v_and_b32 (priority 0)" },
 };
 // the field streams again at lower occupancy: what the dependent-MAD penalty costs with 4 / 2 / 1 waves per SIMD
-static const int occupancy_rows[] = { 6, 9, 14, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27 };
+static const int occupancy_rows[] = { 6, 9, 14, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34 };
 
 static unsigned long long* g_cyc;          // [MAX_WAVES] device, g_cyc_host its mirror
 static unsigned long long* g_cyc_host;
@@ -267,7 +296,7 @@ static void dispatch(int id, int blocks, unsigned* d, int trips, hipStream_t s)
 {
     switch (id) {
 #define C(k) case k: launch<k>(blocks, d, trips, s); break;
-        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(18) C(19) C(20) C(21) C(22) C(23) C(24) C(25) C(26) C(27)
+        C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(18) C(19) C(20) C(21) C(22) C(23) C(24) C(25) C(26) C(27) C(28) C(29) C(30) C(31) C(32) C(33) C(34)
 #undef C
     }
 }
