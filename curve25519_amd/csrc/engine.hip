@@ -984,6 +984,76 @@ __global__ void __launch_bounds__(INV_BLOCK) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+// A/B only (C25519_AMD_SIGN_TAIL=<lanes>, profiles/r04_ab_sign_tail.txt): the signing pass's last two launches in one --
+// the shared inversion inside the workgroup (wave 0: one exponentiation per BLOCK / 64 elements, as k_x25519_fused does),
+// then every lane packs its enc(R) and goes straight on to h and S.  The other waves of the workgroup cannot hash while
+// wave 0 inverts (h wants enc(R)); only ANOTHER workgroup of the CU can, if it happens to be out of step.  It loses to the
+// two launches at every width: see the profile.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 4) k_ed25519_sign_tail(ProjScratch scr, void* sig, const void* priv, Msgs msgs, size_t n,
+                                                               u32* a_in, u32* r_in)
+{
+    constexpr int K = BLOCK / 64;
+    __shared__ u32 zbuf[10 * BLOCK];
+    __shared__ u32 pbuf[(K > 1 ? K - 1 : 1) * 10 * 64];
+    const int tid = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * BLOCK + tid;
+    const bool active = i < n;
+    {
+        fe z;
+        if (active) soa_load_fe(z, scr.z, n, i); else fe_set_u32(z, 1);
+        lds_put_fe(zbuf, BLOCK, tid, z);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        fe acc, z, zero;
+        fe_set_u32(zero, 0);
+        u32 zero_mask = 0;
+#pragma unroll 1
+        for (int t = 0; t < K; t++) {
+            lds_get_fe(z, zbuf, BLOCK, tid + 64 * t);
+            zero_mask |= (fe_zero_to_one(z) & 1u) << t;
+            if (t == 0) acc = z; else fe_mul(acc, acc, z);
+            if (t < K - 1) lds_put_fe(pbuf + t * 640, 64, tid, acc);
+        }
+        fe inv;
+        fe_invert(inv, acc);
+#pragma unroll 1
+        for (int t = K - 1; t >= 0; t--) {
+            fe zi;
+            const u32 was_zero = ((zero_mask >> t) & 1u) ? 0xffffffffu : 0u;
+            if (t > 0) {
+                fe p, one;
+                lds_get_fe(p, pbuf + (t - 1) * 640, 64, tid);
+                fe_mul(zi, inv, p);
+                lds_get_fe(z, zbuf, BLOCK, tid + 64 * t);
+                fe_set_u32(one, 1);
+                fe_select(z, was_zero, one, z);
+                fe_mul(inv, inv, z);
+                fe_select(zi, was_zero, zero, zi);
+            } else {
+                fe_select(zi, was_zero, zero, inv);
+            }
+            lds_put_fe(zbuf, BLOCK, tid + 64 * t, zi);
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    fe zi;
+    lds_get_fe(zi, zbuf, BLOCK, tid);
+    u32 encR[8], pkw[8], a[8], r[8], sw[8];
+    const u32 zero8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    affine_pack(encR, scr.a, scr.b, n, i, zi);
+    store32(sig, 2 * i, encR);
+    load32(pkw, priv, 2 * i + 1);
+    soa_load8(a, a_in, n, i);
+    soa_load8(r, r_in, n, i);
+    soa_store8(a_in, n, i, zero8);
+    soa_store8(r_in, n, i, zero8);
+    ed_sign_s(sw, encR, pkw, msgs.ptr(i), msgs.len(i), a, r);
+    store32(sig, 2 * i + 1, sw);
+}
+
 // ------------------------------------------------------------------------------------------------
 // unit-test hooks (the counterpart of the reference's ECP_SELF_TEST unit checks,
 // test/curve25519_selftest.c:624-741): one lane per input record, operations defined in lanes.cuh
@@ -1435,8 +1505,15 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
         k_ed25519_sign_mult<false><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl,
                                                                                 nullptr);
     C25519_TRY(hipGetLastError());
-    C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, sig, n, 2, 0, nullptr, 0, 0 }, stream));   // sig[e][0..31] = enc(R)
-    k_ed25519_sign_finish<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(sig, priv, msgs, n, a_buf, r_buf);
+    const char* tail_env = getenv("C25519_AMD_SIGN_TAIL");                        // A/B only (read per call: tools/ab_bench.py lib.so@KEY=VAL)
+    const int tail_lanes = tail_env ? atoi(tail_env) : 0;
+    if (tail_lanes == 256) k_ed25519_sign_tail<256><<<grid_for(n, 256), 256, 0, stream>>>(scr, sig, priv, msgs, n, a_buf, r_buf);
+    else if (tail_lanes == 512) k_ed25519_sign_tail<512><<<grid_for(n, 512), 512, 0, stream>>>(scr, sig, priv, msgs, n, a_buf, r_buf);
+    else if (tail_lanes == 1024) k_ed25519_sign_tail<1024><<<grid_for(n, 1024), 1024, 0, stream>>>(scr, sig, priv, msgs, n, a_buf, r_buf);
+    else {
+        C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, sig, n, 2, 0, nullptr, 0, 0 }, stream));   // sig[e][0..31] = enc(R)
+        k_ed25519_sign_finish<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(sig, priv, msgs, n, a_buf, r_buf);
+    }
     C25519_TRY(hipGetLastError());
     return lease.release();
 }

@@ -204,10 +204,13 @@ C25519_DEV void fe_sqr_chained(fe& r, const fe& a, Extra extra)
     fe_finish_chain(r, l, carry);
 }
 
+#ifndef C25519_ALL_PRODUCT_RUNS
+#define C25519_ALL_PRODUCT_RUNS 0        // A/B knob: the in-product runs in EVERY kernel's products, not the ladder's only
+#endif
 // r = a * b.   beta_a <= 5, beta_b <= 3.3; r may alias a or b.   (ecp_MulReduce)
 C25519_DEV void fe_mul(fe& r, const fe& a, const fe& b)
 {
-    fe_mul_chained<false>(r, a, b);
+    fe_mul_chained<C25519_ALL_PRODUCT_RUNS != 0>(r, a, b);
 }
 // ... with the low-priority runs inside (the ladder's products)
 C25519_DEV void fe_mul_runs(fe& r, const fe& a, const fe& b)
@@ -222,21 +225,21 @@ C25519_DEV void fe_sqr_runs(fe& r, const fe& a)
 // r = a^2.   beta_a <= 3.3; r may alias a.   (ecp_SqrReduce)
 C25519_DEV void fe_sqr(fe& r, const fe& a)
 {
-    fe_sqr_chained<false, true>(r, a, [](int) -> u64 { return 0; });
+    fe_sqr_chained<false, true, C25519_ALL_PRODUCT_RUNS != 0>(r, a, [](int) -> u64 { return 0; });
 }
 
 // r = a^2 - m with the subtraction folded into the carry chain (result reduced).
 // beta_a <= 3.3, beta_m <= 2 (bias 4p).
 C25519_DEV void fe_sqr_sub(fe& r, const fe& a, const fe& m)
 {
-    fe_sqr_chained<false>(r, a, [&](int k) -> u64 { return (u64)(2u * fe_2p(k) - m.v[k]); });
+    fe_sqr_chained<false, false, C25519_ALL_PRODUCT_RUNS != 0>(r, a, [&](int k) -> u64 { return (u64)(2u * fe_2p(k) - m.v[k]); });
 }
 
 // r = 2*a^2 + p - m, folded into the carry chain (result reduced).
 // beta_a <= 2.3 (columns are doubled), p any beta < 8, m reduced (bias 2p).
 C25519_DEV void fe_sqr2_add_sub(fe& r, const fe& a, const fe& p, const fe& m)
 {
-    fe_sqr_chained<true>(r, a, [&](int k) -> u64 { return (u64)(p.v[k] + fe_2p(k) - m.v[k]); });
+    fe_sqr_chained<true, false, C25519_ALL_PRODUCT_RUNS != 0>(r, a, [&](int k) -> u64 { return (u64)(p.v[k] + fe_2p(k) - m.v[k]); });
 }
 
 C25519_DEV void fe_sqr_n(fe& r, const fe& a, int n)
