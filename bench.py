@@ -75,6 +75,9 @@ WORKLOAD_NAME = {
 }
 
 
+CLOCK_RAMP_S = 0.06      # untimed launches in front of every block's warm-up steps (run_timed)
+
+
 def latest_profile(pattern):
     hits = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     return hits[-1] if hits else None
@@ -417,6 +420,17 @@ def main():
                 if og:
                     og.finish()
 
+        # clock ramp, untimed, ahead of the W warm-up steps: after an idle gap (the host-side set-up between two blocks of
+        # this script is one) the chip needs 20-40 ms of load to reach its sustained clock; the first launches run 10-19 %
+        # slower (profiles/r04_warmup_probe.txt).  A 1.6 ms signing pass times five warm-up steps would be timed on the ramp.
+        t_ramp = time.perf_counter()
+        step()
+        finish()
+        torch.cuda.synchronize()
+        one = max(time.perf_counter() - t_ramp, 1e-4)
+        for _ in range(min(200, int(CLOCK_RAMP_S / one))):
+            step()
+        finish()
         for _ in range(args.warmup):
             step()
         finish()
@@ -540,6 +554,8 @@ def main():
             "ms_per_step": primary["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "dtype_note": "26/25-bit limbs in u32 registers, 32x32+64->64-bit "
             "integer MACs (v_mad_u64_u32), bit-exact results", "data": "synthetic",
+            "clock_ramp_ms": round(CLOCK_RAMP_S * 1e3), "clock_ramp_note": "untimed launches of the same pass in front of every "
+            "block's W warm-up steps: after an idle gap the chip runs 10-19 % slower for its first 20-40 ms",
             "config": {"workload": WORKLOAD_NAME[wl], "batch_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"shard{world}" + (("+gloo_gather_SHARED_GPU_SELFTEST" if share_gpu else "+rccl_gather")
                                                           if use_dist else "")},

@@ -885,6 +885,21 @@ def test_small_calls_run_one_operation_per_wave_and_agree_with_the_batch_kernels
         assert np.array_equal(api.ed25519_SignMessage(priv, msg), oracle.ed25519_sign(priv, msg))
 
 
+def test_one_launch_sign_tail_variants_agree_with_the_oracle(api, oracle, monkeypatch):
+    """C25519_AMD_SIGN_TAIL (read per call) switches the signing pass's last two launches for k_ed25519_sign_tail<lanes>, the
+    one-launch tail kept for the A/B of profiles/r04_ab_sign_tail.txt: same bytes as the shipped pass at every width, ragged
+    batch sizes and a zero-length message included."""
+    for n, mlen in ((3000, 29), (4097, 0), (70001, 113)):
+        esk, msg = synth.random_bytes((n, 32), 0x7601 + n), synth.random_bytes((n, mlen), 0x7701 + n)
+        pub, priv = api.ed25519_CreateKeyPair(esk)
+        exp = oracle.ed25519_sign(priv, msg)
+        for lanes in ("256", "512", "1024"):
+            monkeypatch.setenv("C25519_AMD_SIGN_TAIL", lanes)
+            assert np.array_equal(api.ed25519_SignMessage(priv, msg), exp), (n, lanes)
+        monkeypatch.delenv("C25519_AMD_SIGN_TAIL")
+        assert np.array_equal(api.ed25519_SignMessage(priv, msg), exp), n
+
+
 def test_degenerate_but_valid_signatures_on_both_paths(api):
     """tests/golden/degenerate_verify.npz through ed25519_VerifySignature on the device: the default pass (lattice path +
     slow list) and, in a second process, C25519_AMD_VERIFY_REFERENCE_ORDER=1 (every element through the reference-order

@@ -13,6 +13,7 @@ import ctypes as C
 import os
 import statistics
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
@@ -86,7 +87,12 @@ for r in range(args.rounds + 1):
         for name, L in libs:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             set_env(name)
-            run(L, op)                                  # warm-up launch keeps the clocks up (DVFS)
+            run(L, op)                                  # warm-up: the chip needs 20-40 ms of load after an idle gap to reach
+            torch.cuda.synchronize()                    # its sustained clock (profiles/r04_warmup_probe.txt): a signing pass
+            w0 = time.perf_counter()                    # timed behind ONE warm-up launch reads 19 % slow
+            while time.perf_counter() - w0 < 0.05:
+                run(L, op)
+                torch.cuda.synchronize()
             a.record()
             for _ in range(BURST):
                 run(L, op)
