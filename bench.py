@@ -51,7 +51,7 @@ EXECUTED_MACS_PER_OP = {"x25519": 191400, "sign": 25100, "verify": 186400}
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md
 
 PASS_KERNELS = {
-    "x25519": ("k_x25519_ladder", "k_batch_invert<FinishX25519>"),     # batches above 2^18 (k_x25519_fused below)
+    "x25519": ("k_x25519_ladder", "k_batch_invert<FinishX25519>"),     # batches above 2^16 (k_x25519_fused below)
     "sign": ("k_ed25519_sign_mult", "k_batch_invert<FinishPack>", "k_ed25519_sign_finish"),
     "verify": ("k_ed25519_verify_fast_scalars", "k_ed25519_verify_fast_points", "k_ed25519_verify_fast_walk",
                "k_ed25519_verify_slow"),                # (the slow list is empty for on-curve keys: a ~10 us launch)
@@ -129,7 +129,7 @@ def issue_model(n, live):
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import cycle_probe
-            ms, rec = cycle_probe.measure(_b.PROBE_LIB, n, fused=n <= (1 << 18), reps=3)
+            ms, rec = cycle_probe.measure(_b.PROBE_LIB, n, fused=n <= (1 << 16), reps=3)
             out = cycle_probe.summary(ms, rec)[0]
             out["source"] = "live: s_memtime stamps of libcurve25519_amd_probe.so, this run"
             return out
@@ -150,7 +150,7 @@ def roofline_for(wl, n, kernel_ms, probe=None):
     kernel_s = kernel_ms * 1e-3
     achieved_gbs = BYTES_PER_OP[wl] * n / kernel_s / 1e9
     peak_mac, peak_src = measured_mad_peak()
-    kernels = PASS_KERNELS[wl] if wl != "x25519" or n > (1 << 18) else ("k_x25519_fused",)
+    kernels = PASS_KERNELS[wl] if wl != "x25519" or n > (1 << 16) else ("k_x25519_fused",)
     traffic, traffic_src = measured_traffic(kernels)
     achieved_mac = MACS_PER_OP[wl] * n / kernel_s
     valu = {"bound": "valu v_mad_u64_u32 issue", "achieved": round(achieved_mac / 1e12, 4),
@@ -423,14 +423,18 @@ def main():
         # clock ramp, untimed, ahead of the W warm-up steps: after an idle gap (the host-side set-up between two blocks of
         # this script is one) the chip needs 20-40 ms of load to reach its sustained clock; the first launches run 10-19 %
         # slower (profiles/r04_warmup_probe.txt).  A 1.6 ms signing pass times five warm-up steps would be timed on the ramp.
+        # (kernels only, no gathers: every rank decides its own launch count from its own clock)
+        def ramp_step():
+            for j, p in enumerate(passes):
+                with torch.cuda.stream(streams[j]) if streams else contextlib.nullcontext():
+                    p["launch"](outs[j])
         t_ramp = time.perf_counter()
-        step()
-        finish()
+        ramp_step()
         torch.cuda.synchronize()
         one = max(time.perf_counter() - t_ramp, 1e-4)
         for _ in range(min(200, int(CLOCK_RAMP_S / one))):
-            step()
-        finish()
+            ramp_step()
+        torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
         finish()

@@ -1309,7 +1309,7 @@ bool verify_coop_for(size_t n) { return coop_for(n, 2048); }       // the walk a
 bool x25519_split_for(size_t n)
 {
     if (const char* e = getenv("C25519_AMD_XF_SPLIT")) return atoi(e) != 0;
-    return std::max(n, c25519_host::batch_shape_hint()) > ((size_t)1 << 18);
+    return std::max(n, c25519_host::batch_shape_hint()) > ((size_t)1 << 16);   // measured at the sustained clock: two launches win from 2^17 up (3 / 2 / 1.2 % at 2^17 / 2^18 / 2^20), one launch by 1 % below
 }
 
 template <int BLOCK>

@@ -123,6 +123,9 @@ C25519_DEV void fe_finish_chain(fe& r, u32 (&l)[10], u64 carry)
 
 // RUNS: the operand doublings as a low-priority run and a priority dip behind every column (C25519_VOP2_RUN_*): worth
 // 1.7 % on the X25519 ladder at four waves per SIMD, costs 1.7 % in the verification walk at two (profiles/r04_ab_prio.txt)
+#ifndef C25519_DIP_EVERY
+#define C25519_DIP_EVERY 1                 // A/B knob: a dip behind every n-th column of a product with RUNS
+#endif
 template <bool RUNS = false>
 C25519_DEV void fe_mul_chained(fe& r, const fe& a, const fe& b)
 {
@@ -146,7 +149,7 @@ C25519_DEV void fe_mul_chained(fe& r, const fe& a, const fe& b)
             y[i] = wrap ? b19[j] : b.v[j];
         }
         acc = k == 0 ? mad_chain10_from_zero(x, y) : mad_chain10(acc, x, y);
-        if (RUNS) { C25519_MASK_RUN_BEGIN(); C25519_MASK_RUN_END(); }
+        if (RUNS && (k % C25519_DIP_EVERY) == C25519_DIP_EVERY - 1) { C25519_MASK_RUN_BEGIN(); C25519_MASK_RUN_END(); }
         l[k] = (u32)acc & fe_mask(k);
         acc >>= fe_w(k);
     }
@@ -197,7 +200,7 @@ C25519_DEV void fe_sqr_chained(fe& r, const fe& a, Extra extra)
             acc = from_zero ? mad_chain6_from_zero(x, y) : mad_chain6(acc, x, y);
         }
         if (SCALE2) acc = 2 * acc + carry + extra(k);
-        if (RUNS) { C25519_MASK_RUN_BEGIN(); C25519_MASK_RUN_END(); }
+        if (RUNS && (k % C25519_DIP_EVERY) == C25519_DIP_EVERY - 1) { C25519_MASK_RUN_BEGIN(); C25519_MASK_RUN_END(); }
         l[k] = (u32)acc & fe_mask(k);
         carry = acc >> fe_w(k);
     }

@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs (a rank of a self-launched bench.py waiting for a collective its peer never issues, say) must
+    fail, not sit on the box until the caller's limit: 300 s per test where pytest-timeout is there (the longest takes 20)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(300))
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle_lib import Oracle

@@ -268,10 +268,12 @@ def test_full_size_properties(api):
 
 
 @pytest.mark.parametrize("n", [65535, 65536, 65537, 131072, 131073, 262144, 262145])
-def test_workgroup_shapes_at_their_boundaries(api, oracle, n):
-    """A *_dev call picks its workgroup shape from n (X25519: 64 / 128 / 256 / 512 lanes up to 2^16 / 2^17 / 2^18 / beyond, an
-    inversion per 1 / 2 / 4 / 8 elements; the fixed-base kernels 256 / 512 / 1024 lanes): every shape, at the sizes where
-    it changes and with a ragged last workgroup, gives the reference's bytes."""
+def test_workgroup_shapes_at_their_boundaries(api, oracle, n, monkeypatch):
+    """A *_dev call picks its kernel shape from n (X25519: the one-launch kernel in 64-lane workgroups up to 2^16 elements,
+    ladder + shared inversion as two launches beyond; C25519_AMD_XF_SPLIT=0 / 1 forces either, the one-launch kernel then in
+    64 / 128 / 256 / 512 lanes up to 2^16 / 2^17 / 2^18 / beyond with an inversion per 1 / 2 / 4 / 8 elements; the
+    fixed-base kernels 256 / 512 / 1024 lanes): every shape, at the sizes where it changes and with a ragged last
+    workgroup, gives the reference's bytes."""
     import torch
     dev = torch.device("cuda", 0)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
@@ -285,6 +287,13 @@ def test_workgroup_shapes_at_their_boundaries(api, oracle, n):
     api.curve25519_dh_CreateSharedKey_dev(shared, pk, skc)
     e_shared, e_clamped = oracle.x25519_shared(pk_np, sk_np, threads=THREADS)
     assert np.array_equal(shared.cpu().numpy(), e_shared) and np.array_equal(skc.cpu().numpy(), e_clamped)
+    for forced in ("0", "1"):                                         # the shape the default did not pick at this n, too
+        monkeypatch.setenv("C25519_AMD_XF_SPLIT", forced)
+        shared.zero_()
+        skc = sk.clone()
+        api.curve25519_dh_CreateSharedKey_dev(shared, pk, skc)
+        assert np.array_equal(shared.cpu().numpy(), e_shared) and np.array_equal(skc.cpu().numpy(), e_clamped), forced
+    monkeypatch.delenv("C25519_AMD_XF_SPLIT")
     pub = torch.empty((n, 32), dtype=torch.uint8, device=dev)
     priv = torch.empty((n, 64), dtype=torch.uint8, device=dev)
     api.ed25519_CreateKeyPair_dev(pub, priv, sk)
@@ -543,7 +552,7 @@ def test_reference_harness_runs_on_this_library():
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_on_amd")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/ref_harness_on_amd not built (needs /root/reference at build time)")
-    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "Signature Verified Successfully" in p.stdout
     assert "FAILED" not in p.stdout
@@ -556,7 +565,7 @@ def test_reference_cxx_wrappers_run_on_this_library():
     exe = os.path.join(ROOT, "oracle", "_ref", "cxx_wrappers_on_amd")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/cxx_wrappers_on_amd not built (needs /root/reference at build time)")
-    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "0 failure(s)" in p.stdout and "FAIL" not in p.stdout
 
@@ -701,7 +710,7 @@ def test_bench_mixed_and_self_launch_run():
     gathers) runs with a world of one rank."""
     for extra in (["--workload", "mixed"], ["--dist-selftest", "--no-side"]):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu"] + extra,
-                           capture_output=True, text=True, timeout=900)
+                           capture_output=True, text=True, timeout=240)
         assert p.returncode == 0, p.stderr[-3000:]
         assert len(p.stdout.strip().splitlines()) == 1, p.stdout          # exactly one line on stdout
         line = json.loads(p.stdout)
@@ -719,7 +728,7 @@ def test_reference_openssl_harness_runs_on_this_library():
     exe = os.path.join(ROOT, "oracle", "_ref", "openssl_test_on_amd")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/openssl_test_on_amd not built (needs /root/reference and libcrypto at build time)")
-    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
     assert "Mismatched" not in p.stdout and p.stdout.count("ratio") == 4
 
@@ -836,7 +845,7 @@ def test_bench_self_launches_two_ranks(ranks, batch):
     if torch.cuda.device_count() < ranks:
         env["C25519_BENCH_SHARE_GPU"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
-                        "--batch", str(batch), "--no-cpu"], capture_output=True, text=True, timeout=900, env=env)
+                        "--batch", str(batch), "--no-cpu"], capture_output=True, text=True, timeout=240, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     assert len(p.stdout.strip().splitlines()) == 1, p.stdout
     line = json.loads(p.stdout)
@@ -926,7 +935,7 @@ def test_degenerate_but_valid_signatures_on_both_paths(api):
         "assert _lib.load().c25519_amd_verify_last_slow_elements() == -1\n"
         "assert np.array_equal(ok, d['verdict']), int((ok != d['verdict']).sum())\n") % ROOT
     p = subprocess.run([sys.executable, "-c", code, os.path.join(GOLD, "degenerate_verify.npz")], capture_output=True, text=True,
-                       timeout=600, env={**os.environ, "C25519_AMD_VERIFY_REFERENCE_ORDER": "1"})
+                       timeout=300, env={**os.environ, "C25519_AMD_VERIFY_REFERENCE_ORDER": "1"})
     assert p.returncode == 0, p.stderr[-2000:]
 
 
@@ -983,7 +992,7 @@ def test_lattice_fast_path_and_reference_order_agree(api, oracle):
     with tempfile.TemporaryDirectory() as tmp:
         np.savez(os.path.join(tmp, "in.npz"), sig=bsig, pk=mixed, msg=bmsg)
         p = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npy")],
-                           capture_output=True, text=True, timeout=600, env={**os.environ, "C25519_AMD_VERIFY_REFERENCE_ORDER": "1"})
+                           capture_output=True, text=True, timeout=300, env={**os.environ, "C25519_AMD_VERIFY_REFERENCE_ORDER": "1"})
         assert p.returncode == 0, p.stderr[-2000:]
         assert np.array_equal(np.load(os.path.join(tmp, "out.npy")), ok)
 
@@ -1018,7 +1027,7 @@ def test_host_pipeline_shapes_give_the_same_bytes(api, oracle, knobs):
     with tempfile.TemporaryDirectory() as tmp:
         np.savez(os.path.join(tmp, "in.npz"), pk=pk, sk=sk, esk=esk, msg=msg, bsig=bsig, bmsg=bmsg)
         p = subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")],
-                           capture_output=True, text=True, timeout=600, env={**os.environ, **knobs})
+                           capture_output=True, text=True, timeout=300, env={**os.environ, **knobs})
         assert p.returncode == 0, p.stderr[-2000:]
         out = np.load(os.path.join(tmp, "out.npz"))
         for name, want in (("shared", shared), ("pub", pub), ("priv", priv), ("sig", sig), ("ok", ok)):

@@ -11,7 +11,7 @@ WHAT=${*:-all}
 has() { [[ " $WHAT " == *" $1 "* || " $WHAT " == *" all "* ]]; }
 
 if has tests; then
-  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.full 2>&1
+  timeout 420 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.full 2>&1
   echo "pytest rc=$?" > $OUT/pytest_gpu.rc                      # pytest's own exit code, not a pipe's
   tail -30 $OUT/pytest_gpu.full > $OUT/pytest_gpu.log; cat $OUT/pytest_gpu.rc >> $OUT/pytest_gpu.log; rm -f $OUT/pytest_gpu.full
   grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -3; cat $OUT/pytest_gpu.rc
