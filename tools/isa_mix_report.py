@@ -63,10 +63,11 @@ print("# Instruction mix of the hot loops, from hipcc -S of curve25519_amd/csrc/
 print("# Issue classes, nominal: v_mad_u64_u32 4 cycles per wave-instruction per SIMD, the other VOP3 / 64-bit / multiply instructions")
 print("# (\"half-rate\") 4, VOP2 adds / ands / subs / moves (\"full-rate\") 2.  Measured in shader cycles at the kernels' four waves per SIMD")
 print("# (tools/ubench/mad_peak with s_memtime, profiles/r04_mad_peak.txt): 4.26 for both 4-cycle classes; a VOP2 instruction 2.13 in a")
-print("# run of its own kind on all waves and ~4 alone between another wave's MADs (2.7 on average inside the ladder, r04_cycle_probe.txt).")
+print("# run of its own kind on all waves and ~4 alone between another wave's MADs; with the runs at low priority (s_setprio) the ladder step")
+print("# pays 1.37 per VOP2 instruction on average (profiles/r04_cycle_probe.txt).")
 print("# mad_cycle_share = 4*mad / (4*mad + 4*half + 2*full): the most a VALU-bound kernel can reach of the v_mad_u64_u32 roof")
 print("# with this instruction stream.\n")
-show("X25519 ladder step (5 M + 4 S + a24 + 8 add/sub + select): one trip = one scalar bit", "k_x25519_ladderILb0E", lambda m: 1200 < m['n'] < 1400)
+show("X25519 ladder step (5 M + 4 S + a24 + 8 add/sub + select): one trip = one scalar bit", "k_x25519_ladderILb0E", lambda m: 1200 < m['n'] < 1480)   # 1246 VALU + 216 s_setprio + loop control
 show("verification walk: digit rounds (the biggest loop is one round: 4 doublings or 4 x (doubling + LDS-row addition), then two table-row "
      "additions from prefetched packed rows; inside it the 3-doubling loop and the 4-step sigma loop)", "k_ed25519_verify_fast_walk", lambda m: m['n'] > 800)
 show("verification points kernel: the squaring loops of the square root (99-101 instructions per squaring) and the table-build loop",
