@@ -774,7 +774,11 @@ __global__ void __launch_bounds__(WALK_BLOCK, C25519_VW_WAVES) k_ed25519_verify_
     }
     top = __builtin_amdgcn_readfirstlane(top);           // wave-uniform by construction: let the walk's loops be scalar ones
     if (!walks) return;
+#ifdef C25519_WALK_TABLE_ALIAS                           // TIMING ONLY (wrong verdicts): every element reads one of 1024 tables, L2-resident
+    const u32* tq = fs.tables + (i & 1023) * FAST_TABLE_WORDS;
+#else
     const u32* tq = fs.tables + i * FAST_TABLE_WORDS;
+#endif
     const WalkScalars sc{ fs.sigma, fs.tau, fs.rho, n, i };
     const u32 neutral = ge_walk_is_neutral(sc, tq, tq + WTABLE_WORDS, lds_tbl, top < 8 ? 8 : top);
     verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
