@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import isa_mix  # noqa: E402
 
 STEPS = 251 + 4 * 0.55            # 251 ladder steps + the opening doubling and the three closing ones (a doubling = 0.55 step)
-# the ladder step's instruction stream (profiles/r03_isa_mix.txt): v_mad_u64_u32, other 4-cycle-class VALU, VOP2
+# the ladder step's instruction stream (profiles/r04_isa_mix.txt): v_mad_u64_u32, other 4-cycle-class VALU, VOP2
 STEP_MAD, STEP_HALF, STEP_FULL = 739, 188, 319
 # class costs in SIMD cycles per wave-instruction: nominal, and as measured in place by tools/ubench/mad_peak at four
 # resident waves (profiles/r04_mad_peak.txt): MAD and the other 4-cycle-class instructions 4.26 -- 4.0 of execution and
