@@ -12,8 +12,16 @@ followed for N > 1 by the single RCCL gather of the result rows to rank 0 that n
 overlapped with the next batch; every gather of the timed steps completes inside the timed region).  Weak scaling:
 every rank owns its own 2^20 operations.
 
+Timing protocol of every block (run_timed): W warm-up steps; barrier; clock-ramp launches of the same pass (the ranks
+left the barrier together, whatever each did before it); synchronize; t0; EXACTLY K steps; every gather of those steps
+complete; synchronize; t1; barrier.  A rank's time is its own t1 - t0 (device events between the same two points ride
+along as a cross-check), the block's time the MAX over ranks.  After the timed steps every rank hashes its last output
+buffer (SHA-256) against the committed digest of the reference's portable-C outputs for its rank's inputs
+(tests/golden/digests.json, written by tests/golden/gen_golden.py from oracle/_ref): `bit_exact`; a mismatch makes the
+run exit non-zero behind the JSON line.
+
 BASELINE.json's metric is a pair -- "X25519 shared-key ops/sec + Ed25519 verifies/sec" -- so the default run times
-BOTH, each with its own W warm-up + K timed steps bracketed by barrier + synchronize (mean of steps, max over ranks):
+BOTH, each with its own W warm-up + K timed steps (mean of steps, max over ranks):
   value / ms_per_step / roofline  -- X25519 curve25519_dh_CreateSharedKey (configs[1]); `value` is this number;
   verify                          -- ed25519_VerifySignature on configs[3]'s set (valid + 1/64 corrupted);
   sign                            -- ed25519_SignMessage (configs[2]);
@@ -48,6 +56,22 @@ MACS_PER_OP = {"x25519": 184104, "sign": 52992, "verify": 245664}
 # 22 900 each (a 258 S + 24 M square root, a window table of 4 doublings, 3 additions, 8 row conversions) + ~2 000 in the
 # scalar kernel (profiles/r03_isa_mix.txt)
 EXECUTED_MACS_PER_OP = {"x25519": 191400, "sign": 25100, "verify": 186400}
+# ... replaced, when the round's count is committed, by profiles/rNN_executed_macs.json: v_mad_u64_u32 instructions counted
+# by running the DEVICE SOURCE one lane at a time against the C model of the gfx950 primitives (tools/executed_macs.py;
+# tests/test_bench_contract.py pins the file against a fresh count)
+
+
+def executed_macs():
+    path = latest_profile("r[0-9][0-9]_executed_macs.json")
+    if path:
+        try:
+            with open(path) as f:
+                d = json.load(f)["per_op"]
+            return {k: int(d[k]) for k in EXECUTED_MACS_PER_OP}, os.path.basename(path)
+        except Exception:
+            pass
+    return dict(EXECUTED_MACS_PER_OP), None
+
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md
 
 PASS_KERNELS = {
@@ -75,7 +99,24 @@ WORKLOAD_NAME = {
 }
 
 
-CLOCK_RAMP_S = 0.06      # untimed launches in front of every block's warm-up steps (run_timed)
+CLOCK_RAMP_S = 0.06      # untimed launches behind the opening barrier, directly in front of every block's timed steps (run_timed)
+DIGESTS = os.environ.get("C25519_BENCH_DIGESTS") or os.path.join(ROOT, "tests", "golden", "digests.json")   # (the env: tests only)
+DIGEST_KEY = {"x25519": "x25519_shared", "sign": "ed25519_sig", "verify": "ed25519_verdicts"}
+
+
+def expected_digests(rank, world, n):
+    """The committed SHA-256 digests of the REFERENCE's outputs (portable-C build, oracle/_ref; tests/golden/gen_golden.py)
+    for rank `rank`'s n elements -- rank r of a world > 1 draws its inputs from seed + 0x100 * r (synth.rank_seed_shift); the
+    seeded streams are positional, so a power-of-two batch below 2^20 is a prefix of the 2^20 one.  None: no digest
+    committed for this rank / size (the line then says bit_exact: null, it does not guess)."""
+    try:
+        with open(DIGESTS) as f:
+            d = json.load(f)
+        rec = d["ranks"]["by_rank"][rank if world > 1 else 0]
+        return rec["prefix"].get(str(n))
+    except Exception:
+        return None
+
 
 
 def latest_profile(pattern):
@@ -153,34 +194,54 @@ def roofline_for(wl, n, kernel_ms, probe=None):
     kernels = PASS_KERNELS[wl] if wl != "x25519" or n > (1 << 16) else ("k_x25519_fused",)
     traffic, traffic_src = measured_traffic(kernels)
     achieved_mac = MACS_PER_OP[wl] * n / kernel_s
+    executed, executed_src = executed_macs()
     valu = {"bound": "valu v_mad_u64_u32 issue", "achieved": round(achieved_mac / 1e12, 4),
             "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s",
             "frac": round(achieved_mac / peak_mac, 4) if peak_mac else None,
             "algorithmic_macs_per_op": MACS_PER_OP[wl],
-            "executed_macs_per_op": EXECUTED_MACS_PER_OP[wl],
-            "frac_executed": round(EXECUTED_MACS_PER_OP[wl] * n / kernel_s / peak_mac, 4) if peak_mac else None,
+            "executed_macs_per_op": executed[wl],
+            "executed_macs_source": f"profiles/{executed_src} (device source run against the C model of the primitives, "
+                                    "tools/executed_macs.py)" if executed_src else "bench.py constants (ISA counts x trip counts)",
+            "frac_executed": round(executed[wl] * n / kernel_s / peak_mac, 4) if peak_mac else None,
             "peak_source": f"profiles/{peak_src}" if peak_src else None,
             "peak_policy": "the fastest box's 8-waves-per-SIMD v_mad_u64_u32 stream of all committed rounds (wall-clock rate)"}
     if probe:
-        # the fraction that says how close the kernel is to what its instruction stream allows: class-cost cycles of
-        # one ladder step / SIMD cycles measured per step (un-profiled, in-kernel).  Headline = the floor of this stream at
-        # four waves: 4.26 cycles per 4-cycle-class instruction, every VOP2 instruction paired with another wave's and
-        # executed inside the former's issue bubbles as far as those reach (tools/cycle_probe.py: model_cycles("floor")).
-        valu.update({"issue_model_frac": probe.get("issue_model_frac_floor", probe.get("issue_model_frac_measured_vop2_paired")),
-                     "issue_model_cycles_per_step": probe.get("issue_model_cycles_floor"),
-                     "issue_model_frac_nominal_4_4_2": probe.get("issue_model_frac_nominal"),
-                     "simd_cycles_per_ladder_step": probe.get("simd_cycles_per_ladder_step"),
-                     "ladder_step_instructions": probe.get("ladder_step_instructions"),
-                     "vop2_cycles_implied": probe.get("vop2_cycles_implied"),
-                     "shader_clock_GHz": probe.get("shader_clock_GHz"),
-                     "issue_model_source": probe.get("source")})
+        attach_probe(valu, probe)
+    return finish_roofline(wl, n, kernel_ms, achieved_gbs, traffic, traffic_src, kernels, valu)
+
+
+def attach_probe(valu, probe):
+    """issue_model()'s result into a roofline's `valu` object: the fraction that says how close the kernel is to what its
+    instruction stream allows -- class-cost cycles of one ladder step / SIMD cycles measured per step (un-profiled,
+    in-kernel).  Headline = the floor of this stream at four waves: 4.26 cycles per 4-cycle-class instruction, every VOP2
+    instruction paired with another wave's and executed inside the former's issue bubbles as far as those reach
+    (tools/cycle_probe.py: model_cycles("floor"))."""
+    valu.update({"issue_model_frac": probe.get("issue_model_frac_floor", probe.get("issue_model_frac_measured_vop2_paired")),
+                 "issue_model_cycles_per_step": probe.get("issue_model_cycles_floor"),
+                 "issue_model_frac_nominal_4_4_2": probe.get("issue_model_frac_nominal"),
+                 "simd_cycles_per_ladder_step": probe.get("simd_cycles_per_ladder_step"),
+                 "ladder_step_instructions": probe.get("ladder_step_instructions"),
+                 "vop2_cycles_implied": probe.get("vop2_cycles_implied"),
+                 "shader_clock_GHz": probe.get("shader_clock_GHz"),
+                 "issue_model_source": probe.get("source")})
+
+
+def finish_roofline(wl, n, kernel_ms, achieved_gbs, traffic, traffic_src, kernels, valu):
     return {
         "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic,
         "traffic_source": f"profiles/{traffic_src}: (2*FETCH_SIZE + WRITE_SIZE) KiB per pass" if traffic_src else None,
         "kernel": " + ".join(kernels), "kernel_ms": round(kernel_ms, 4),
         "algorithmic_bytes_per_launch": BYTES_PER_OP[wl] * n,
-        "note": "VALU-integer bound path: the HBM fraction is tiny by construction, `valu` is the roof that binds",
+        "traffic_over_algorithmic": round(traffic / (BYTES_PER_OP[wl] * n), 2) if traffic else None,
+        # the contract's top-level fields are the HBM roof (bound = "hbm"); the roof that BINDS this path is the integer
+        # multiplier: `binding` names it and `binding_frac` is that roof's fraction (= valu.frac)
+        "binding": "valu", "binding_frac": valu["frac"],
+        "note": "VALU-integer bound path: the HBM fraction is tiny by construction, `valu` (v_mad_u64_u32 issue) is the roof "
+                "that binds: read binding_frac / valu.frac, not frac." + (
+                    "  X25519 above 2^16 runs as two launches (ladder, shared inversion): the projective results cross HBM "
+                    "once each way, which is the measured traffic over the algorithmic 96 B/op -- 0.04 ms of a 7.9 ms pass."
+                    if wl == "x25519" and n > (1 << 16) else ""),
         "valu": valu,
     }
 
@@ -345,7 +406,8 @@ def main():
 
     n = args.batch
     eng = HipEngine(dev)
-    seed_shift = 0x100 * rank if world > 1 else 0          # every rank owns its own 2^20 elements (weak scaling)
+    seed_shift = synth.rank_seed_shift(rank, world)        # every rank owns its own 2^20 elements (weak scaling)
+    delay_rank0_s = float(os.environ.get("C25519_BENCH_DELAY_RANK0_S", "0") or 0)   # test knob (run_timed)
     up = lambda a: torch.from_numpy(a).to(dev)             # noqa: E731
 
     def barrier():
@@ -358,7 +420,7 @@ def main():
     def make_x25519(m, lo=0):
         sk = up(synth.random_bytes((n, 32), synth.SEED_X25519_SK + seed_shift)[lo:lo + m])
         pk = up(synth.random_bytes((n, 32), synth.SEED_X25519_PK + seed_shift)[lo:lo + m])
-        return {"wl": "x25519", "n": m, "width": 32, "dtype": torch.uint8,
+        return {"wl": "x25519", "n": m, "width": 32, "dtype": torch.uint8, "sk": sk,
                 "launch": lambda dst: eng.api.curve25519_dh_CreateSharedKey_dev(dst, pk, sk)}
 
     ed_cache = {}
@@ -386,9 +448,14 @@ def main():
         return {"wl": "verify", "n": m, "width": 1, "dtype": torch.int32, "bad": e["bad"][lo:lo + m],
                 "launch": lambda dst: eng.api.ed25519_VerifySignature_dev(dst, vsig, pub, vmsg)}
 
-    def run_timed(passes):
-        """W warm-up + K timed steps of the given passes (each step launches every pass once, then starts its
-        gathers).  Returns (elapsed_s max over ranks, [mean kernel ms per pass], last result buffers)."""
+    def digest_of(t):
+        import hashlib
+        a = t.detach().cpu().numpy()
+        return hashlib.sha256(a.astype("<i4").tobytes() if a.dtype.itemsize == 4 else a.tobytes()).hexdigest()
+
+    def run_timed(passes, ramp=True, mixed=False):
+        """W warm-up + K timed steps of the given passes (each step launches every pass once, then starts its gathers).
+        Returns a dict: elapsed (s, max over ranks), kernel_ms per pass, outs, attribution (per rank), bit_exact per pass."""
         outs = [torch.empty((p["n"], p["width"]), dtype=p["dtype"], device=dev) for p in passes]
         ogs = [OverlappedGather(p["n"], p["width"], dev, root=0, dtype=p["dtype"]) if use_dist else None for p in passes]
 
@@ -396,6 +463,7 @@ def main():
         # independent sub-batches -- the library gives each stream its own work scratch, so one operation's last, partly
         # empty wave of workgroups fills up with the next operation's instead of draining alone
         streams = [torch.cuda.Stream(dev) for _ in passes] if len(passes) > 1 and not args.one_stream else None
+        cur = torch.cuda.current_stream(dev)
 
         def step(evs=None, origin=None):
             if origin is not None:
@@ -419,35 +487,52 @@ def main():
             for og in ogs:
                 if og:
                     og.finish()
+            if streams:                          # the current stream is behind every pass's stream
+                for st in streams:
+                    cur.wait_stream(st)
 
-        # clock ramp, untimed, ahead of the W warm-up steps: after an idle gap (the host-side set-up between two blocks of
-        # this script is one) the chip needs 20-40 ms of load to reach its sustained clock; the first launches run 10-19 %
-        # slower (profiles/r04_warmup_probe.txt).  A 1.6 ms signing pass times five warm-up steps would be timed on the ramp.
-        # (kernels only, no gathers: every rank decides its own launch count from its own clock)
-        def ramp_step():
+        def ramp_step():                         # kernels only, no gathers
             for j, p in enumerate(passes):
                 with torch.cuda.stream(streams[j]) if streams else contextlib.nullcontext():
                     p["launch"](outs[j])
-        t_ramp = time.perf_counter()
-        ramp_step()
-        torch.cuda.synchronize()
-        one = max(time.perf_counter() - t_ramp, 1e-4)
-        for _ in range(min(200, int(CLOCK_RAMP_S / one))):
-            ramp_step()
-        torch.cuda.synchronize()
+
         for _ in range(args.warmup):
             step()
         finish()
+        torch.cuda.synchronize()
+        # Clock ramp: after an idle gap (the host-side set-up between two blocks, a barrier that waits for a late rank) the
+        # chip needs 20-40 ms of load to reach its sustained clock; the first launches run 10-19 % slower
+        # (profiles/r04_warmup_probe.txt).  So every rank issues ~CLOCK_RAMP_S of untimed launches of the same pass BEHIND
+        # the opening barrier, directly in front of its timed steps: whatever a rank did before the barrier -- rank 0's extra
+        # bookkeeping, a slow first-touch -- its timed steps start on a chip that has just been busy for 60 ms.
+        t_one = time.perf_counter()
+        ramp_step()
+        torch.cuda.synchronize()
+        one = max(time.perf_counter() - t_one, 1e-4)
+        n_ramp = max(1, min(200, int(CLOCK_RAMP_S / one))) if ramp else 0
         events = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in passes]
                   for _ in range(args.steps)]
         origins = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        dev_t0, dev_t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if delay_rank0_s and rank == 0:          # test knob: a late rank 0 must not change anybody's timed region
+            time.sleep(delay_rank0_s)
         barrier()
+        wall0 = time.perf_counter()
+        for _ in range(n_ramp):
+            ramp_step()
+        torch.cuda.synchronize()                 # queue empty, clocks up; the first timed launch follows within microseconds
         t0 = time.perf_counter()
+        dev_t0.record()
         for k in range(args.steps):
             step(events[k], origins[k])
-        finish()                             # every gather of the timed steps has completed inside the timed region
+        finish()                                 # every gather of the timed steps has completed inside the timed region
+        dev_t1.record()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         barrier()
-        elapsed = time.perf_counter() - t0
+        wall = time.perf_counter() - wall0       # opening barrier to closing barrier: ramp + timed steps + rank skew
+        local = t1 - t0
+        elapsed = local
         kms = [sum(events[k][j][0].elapsed_time(events[k][j][1]) for k in range(args.steps)) / max(1, args.steps)
                for j in range(len(passes))]
         # device-side span of the timed steps over all their streams: the first pass's start to the last pass's end (HIP
@@ -455,10 +540,32 @@ def main():
         # between steps; with three streams it is what the overlapping kernels took together
         first = min(origins[0].elapsed_time(events[0][j][0]) for j in range(len(passes)))
         last = max(origins[0].elapsed_time(events[args.steps - 1][j][1]) for j in range(len(passes)))
-        run_timed.span_ms = (last - first) / max(1, args.steps)
+        span_ms = (last - first) / max(1, args.steps)
+
+        # ---- bit-exactness of what was just timed: the last step's output buffers against the reference's digests ----
+        want = expected_digests(rank, world, n)
+        exact = []
+        for j, p in enumerate(passes):
+            key = DIGEST_KEY[p["wl"]]
+            exp = (want.get("mixed_thirds", {}) if mixed else want).get(key) if want else None
+            ok = None if exp is None else bool(digest_of(outs[j]) == exp)
+            if ok and p["wl"] == "x25519" and not mixed:             # ... and the clamped secret keys written back in place
+                ok = bool(digest_of(p["sk"]) == want["x25519_sk_clamped"])
+            exact.append(ok)
+        gathered_exact = None
+        if use_dist and rank == 0 and not share_gpu:                 # the rows RCCL delivered to the root, rank by rank
+            gathered_exact = []
+            for j, p in enumerate(passes):
+                b = (ogs[j].step - 1) & 1
+                per = []
+                for r in range(world):
+                    w = expected_digests(r, world, n)
+                    exp = (w.get("mixed_thirds", {}) if mixed else w).get(DIGEST_KEY[p["wl"]]) if w else None
+                    per.append(None if exp is None else bool(digest_of(ogs[j].recv[b][r]) == exp))
+                gathered_exact.append(per)
+
         attribution = None
         if use_dist:
-            local_ms = elapsed / max(1, args.steps) * 1e3
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -474,22 +581,36 @@ def main():
             finish()
             barrier()
             gather_ms = (time.perf_counter() - g0) / max(1, args.steps) * 1e3
-            mine = {"rank": rank, "kernel_ms": [round(k, 4) for k in kms], "step_ms": round(local_ms, 4),
-                    "gather_ms_alone": round(gather_ms, 4)}
+            mine = {"rank": rank, "kernel_ms": [round(k, 4) for k in kms], "step_ms": round(local / max(1, args.steps) * 1e3, 4),
+                    "step_ms_device_events": round(dev_t0.elapsed_time(dev_t1) / max(1, args.steps), 4),
+                    "t0_offset_ms": t0, "ramp_launches": n_ramp, "gather_ms_alone": round(gather_ms, 4), "bit_exact": exact}
             everyone = [None] * world
             dist.all_gather_object(everyone, mine)
+            base = min(a["t0_offset_ms"] for a in everyone)          # CLOCK_MONOTONIC is shared by the processes of a node
+            for a in everyone:
+                a["t0_offset_ms"] = round((a["t0_offset_ms"] - base) * 1e3, 3)
             attribution = everyone
-        return elapsed, kms, outs, attribution
+        return {"elapsed": elapsed, "kms": kms, "outs": outs, "attribution": attribution, "span_ms": span_ms,
+                "bit_exact": exact, "gathered_bit_exact": gathered_exact,
+                "timing": {"step_ms_wall_this_rank": round(local / max(1, args.steps) * 1e3, 4),
+                           "step_ms_device_events_this_rank": round(dev_t0.elapsed_time(dev_t1) / max(1, args.steps), 4),
+                           "ramp_launches": n_ramp, "barrier_to_barrier_ms": round(wall * 1e3, 3)}}
 
-    def summarize(p, elapsed, kernel_ms, out, attribution=None, j=0):
-        probe = issue_model(p["n"], live=rank == 0 and not args.no_side) if p["wl"] == "x25519" else None
+    def summarize(p, run, j=0):
+        elapsed, kernel_ms, out, attribution = run["elapsed"], run["kms"][j], run["outs"][j], run["attribution"]
         r = {"value": round(world * p["n"] * args.steps / elapsed, 1), "unit": "ops/s",
              "ms_per_step": round(elapsed / args.steps * 1e3, 4), "steps": args.steps, "warmup": args.warmup,
              "n_gpus": world, "batch_per_gpu": p["n"], "workload": WORKLOAD_NAME[p["wl"]],
-             "roofline": roofline_for(p["wl"], p["n"], kernel_ms, probe)}
+             "roofline": roofline_for(p["wl"], p["n"], kernel_ms), "timing": run["timing"]}
+        # bit-exactness against the reference's digests: this rank's buffer, or every rank's (N > 1)
+        r["bit_exact"] = [a["bit_exact"][j] for a in attribution] if attribution else [run["bit_exact"][j]]
+        if run["gathered_bit_exact"]:
+            r["gathered_rows_bit_exact"] = run["gathered_bit_exact"][j]
         if attribution:
             r["per_rank"] = [{"rank": a["rank"], "kernel_ms": a["kernel_ms"][j], "step_ms": a["step_ms"],
-                              "gather_ms_alone": a["gather_ms_alone"]} for a in attribution]
+                              "step_ms_device_events": a["step_ms_device_events"], "t0_offset_ms": a["t0_offset_ms"],
+                              "ramp_launches": a["ramp_launches"], "gather_ms_alone": a["gather_ms_alone"],
+                              "bit_exact": a["bit_exact"][j]} for a in attribution]
         if p["wl"] == "verify":
             rejected = (out.view(-1) == 0).cpu().numpy()
             r["rejected"] = int(rejected.sum())
@@ -498,77 +619,116 @@ def main():
 
     wl = args.workload
     side = {}
+    runs = []                                              # (name, pass, run) of every timed block, for the bit_exact summary
     if wl == "mixed":
         (x0, x1), (s0, s1), (v0, v1) = mixed_thirds(n)
         passes = [make_x25519(x1 - x0, x0), make_sign(s1 - s0, s0), make_verify(v1 - v0, v0)]
-        elapsed, kms, outs, attr = run_timed(passes)
-        parts = [summarize(p, elapsed, k, o, attr, j) for j, (p, k, o) in enumerate(zip(passes, kms, outs))]
+        run = run_timed(passes, mixed=True)
+        elapsed, kms = run["elapsed"], run["kms"]
+        parts = [summarize(p, run, j) for j, p in enumerate(passes)]
+        runs += [(p["wl"], r) for p, r in zip(passes, parts)]
         # on three streams the passes' event spans overlap: the device-side span of the step (earliest start event to latest
         # end event over the three streams) is what the kernels took together -- not the wall time, which also holds the
         # gather submissions and the host's launch overhead
-        kernel_ms = sum(kms) if args.one_stream else run_timed.span_ms
+        kernel_ms = sum(kms) if args.one_stream else run["span_ms"]
         bytes_per_launch = sum(BYTES_PER_OP[p["wl"]] * p["n"] for p in passes)
         macs = sum(MACS_PER_OP[p["wl"]] * p["n"] for p in passes)
         peak_mac, peak_src = measured_mad_peak()
         gbs = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        vfrac = round(macs / (kernel_ms * 1e-3) / peak_mac, 4) if peak_mac else None
         roof = {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 6), "traffic": None,
-                "kernel": "k_x25519_fused + sign pass + verify pass (see parts)", "kernel_ms": round(kernel_ms, 4),
-                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "kernel": "X25519 pass + sign pass + verify pass (see parts)", "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_launch": bytes_per_launch, "binding": "valu", "binding_frac": vfrac,
                 "valu": {"bound": "valu v_mad_u64_u32 issue", "achieved": round(macs / (kernel_ms * 1e-3) / 1e12, 4),
-                         "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s",
-                         "frac": round(macs / (kernel_ms * 1e-3) / peak_mac, 4) if peak_mac else None},
+                         "peak": round(peak_mac / 1e12, 4) if peak_mac else None, "unit": "T 32x32 MAC/s", "frac": vfrac},
                 "streams": 1 if args.one_stream else len(passes),
                 "kernel_ms_is": "sum of the passes' event times" if args.one_stream else "device-side span over the streams (events)",
                 "parts": {p["wl"]: {"n": p["n"], ("kernel_ms" if args.one_stream else "span_ms_overlapping"): round(k, 4)}
                           for p, k in zip(passes, kms)}}
         primary = {"value": round(world * n * args.steps / elapsed, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-                   "roofline": roof}
+                   "roofline": roof, "timing": run["timing"]}
         side["verify_rejects_exactly_the_corrupted"] = parts[2]["rejects_exactly_the_corrupted"]
     else:
         make = {"x25519": make_x25519, "sign": make_sign, "verify": make_verify}[wl]
         p = make(n)
-        elapsed, kms, outs, attr = run_timed([p])
-        primary = summarize(p, elapsed, kms[0], outs[0], attr)
+        primary = summarize(p, run_timed([p]))
+        runs.append((wl, primary))
         if wl == "x25519" and not args.no_side:
             # the second half of BASELINE.json's metric, and config 3, with the same protocol
             for name, mk in (("verify", make_verify), ("sign", make_sign)):
-                q = mk(n)
-                e2, k2, o2, a2 = run_timed([q])
-                side[name] = summarize(q, e2, k2[0], o2[0], a2)
+                side[name] = summarize(mk(n), run_timed([mk(n)]))
+                runs.append((name, side[name]))
+
+    # ---- behind ALL timed blocks: the in-kernel probe.  Every rank measures the shader clock its X25519 ladder runs at
+    # (s_memtime / s_memrealtime inside the kernel, no host clock involved), so that a slow rank of an N-GPU run is
+    # attributable; rank 0's stamps also give the issue-model fraction of the ladder step.
+    probe, clocks = None, None
+    if wl in ("x25519", "mixed") and not args.no_side:
+        probe = issue_model(n, live=True)
+        mine = {"rank": rank, "shader_clock_GHz": (probe or {}).get("shader_clock_GHz"),
+                "live": bool(probe and str(probe.get("source", "")).startswith("live"))}
+        clocks = [mine]
+        if use_dist:
+            clocks = [None] * world
+            dist.all_gather_object(clocks, mine)
+    elif wl == "x25519":
+        probe = issue_model(n, live=False)
+    if wl == "x25519" and probe:
+        attach_probe(primary["roofline"]["valu"], probe)
+        primary["roofline"]["binding_frac"] = primary["roofline"]["valu"]["frac"]
 
     result = None
     if rank == 0:
         roof = primary["roofline"]
         for name in ("verify", "sign"):
             if name in side and isinstance(side[name], dict):
-                s = side[name]
-                roof[name] = {"value": s["value"], "unit": "ops/s", "ms_per_step": s["ms_per_step"],
-                              "kernel_ms": s["roofline"]["kernel_ms"], "hbm_frac": s["roofline"]["frac"],
-                              "achieved_GBps": s["roofline"]["achieved"], "traffic": s["roofline"]["traffic"],
-                              "algorithmic_bytes_per_launch": s["roofline"]["algorithmic_bytes_per_launch"],
+                q = side[name]
+                roof[name] = {"value": q["value"], "unit": "ops/s", "ms_per_step": q["ms_per_step"],
+                              "kernel_ms": q["roofline"]["kernel_ms"], "hbm_frac": q["roofline"]["frac"],
+                              "achieved_GBps": q["roofline"]["achieved"], "traffic": q["roofline"]["traffic"],
+                              "traffic_over_algorithmic": q["roofline"]["traffic_over_algorithmic"],
+                              "algorithmic_bytes_per_launch": q["roofline"]["algorithmic_bytes_per_launch"],
                               # two fractions of the MAD roof: the reference's operation count / time (a speed-up where the
                               # device does less work than the reference) and what the kernels really issue / time
-                              "valu_frac_algorithmic": s["roofline"]["valu"]["frac"],
-                              "valu_frac_executed": s["roofline"]["valu"]["frac_executed"],
-                              "kernel": s["roofline"]["kernel"]}
+                              "binding": "valu", "binding_frac": q["roofline"]["valu"]["frac_executed"],
+                              "valu_frac_algorithmic": q["roofline"]["valu"]["frac"],
+                              "valu_frac_executed": q["roofline"]["valu"]["frac_executed"],
+                              "executed_macs_per_op": q["roofline"]["valu"]["executed_macs_per_op"],
+                              "kernel": q["roofline"]["kernel"]}
+        # bit-exactness of everything this run timed, against the reference's portable-C outputs (committed digests)
+        flat = [b for _, r in runs for b in r["bit_exact"]] + [b for _, r in runs for b in r.get("gathered_rows_bit_exact", [])]
+        bit_exact = {name: (r["bit_exact"] if world > 1 else r["bit_exact"][0]) for name, r in runs}
+        bit_exact["all"] = None if any(b is None for b in flat) else bool(all(flat))
+        bit_exact["mismatch"] = any(b is False for b in flat)
+        if any("gathered_rows_bit_exact" in r for _, r in runs):
+            bit_exact["gathered_rows_at_root"] = {name: r["gathered_rows_bit_exact"] for name, r in runs if "gathered_rows_bit_exact" in r}
+        bit_exact["against"] = ("tests/golden/digests.json: SHA-256 of the reference's portable-C outputs (oracle/_ref, written by "
+                                "tests/golden/gen_golden.py) for each rank's seeded inputs; the last timed step's output buffers "
+                                "(X25519: shared keys and the clamped secret keys)" + ("" if bit_exact["all"] is not None else
+                                "; null = no digest committed for this rank / batch size"))
         result = {
             "metric": METRIC_NAME[wl],
             "value": primary["value"], "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": primary["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "dtype_note": "26/25-bit limbs in u32 registers, 32x32+64->64-bit "
             "integer MACs (v_mad_u64_u32), bit-exact results", "data": "synthetic",
-            "clock_ramp_ms": round(CLOCK_RAMP_S * 1e3), "clock_ramp_note": "untimed launches of the same pass in front of every "
-            "block's W warm-up steps: after an idle gap the chip runs 10-19 % slower for its first 20-40 ms",
+            "bit_exact": bit_exact,
+            "clock_ramp_ms": round(CLOCK_RAMP_S * 1e3), "timing_protocol": "per block: W warm-up steps; barrier; ~60 ms of untimed "
+            "launches of the same pass (after an idle gap the chip runs 10-19 % slower for its first 20-40 ms); synchronize; t0; K "
+            "steps + their gathers; synchronize; t1; barrier.  value = units of all ranks / max over ranks of (t1 - t0); device-event "
+            "time between the same points in `timing` / per_rank",
             "config": {"workload": WORKLOAD_NAME[wl], "batch_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"shard{world}" + (("+gloo_gather_SHARED_GPU_SELFTEST" if share_gpu else "+rccl_gather")
                                                           if use_dist else "")},
-            "roofline": roof,
+            "roofline": roof, "timing": primary.get("timing"),
         }
         if primary.get("per_rank"):
             result["per_rank"] = primary["per_rank"]
         if wl == "mixed" and parts[0].get("per_rank"):
             result["per_rank"] = {q["wl"]: r.get("per_rank") for q, r in zip(passes, parts)}
+        if clocks:
+            result["per_rank_shader_clock_GHz"] = [c["shader_clock_GHz"] for c in sorted(clocks, key=lambda c: c["rank"])]
         result.update(side)
 
     # ---- extra measurements outside the protocol above (rank 0, single GPU, default workload only) ----
@@ -589,6 +749,9 @@ def main():
         ms = timeit(lambda: eng.api.ed25519_CreateKeyPair_dev(pub2, priv2, e["esk"]))
         extra["ed25519_keypair_per_s"] = round(n / (ms * 1e-3), 1)
         extra["ed25519_keypair_kernel_ms"] = round(ms, 4)
+        want = expected_digests(0, 1, n)
+        extra["ed25519_keypair_bit_exact"] = (None if not want else
+                                              bool(digest_of(pub2) == want["ed25519_pub"] and digest_of(priv2) == want["ed25519_priv"]))
         # two-phase verification, ONE key for the whole batch (Verify_Init once, 2^20 Verify_Check)
         from curve25519_amd import _lib
         import ctypes as C
@@ -606,6 +769,25 @@ def main():
         ms = timeit(chk)
         extra["ed25519_verify_check_one_key_per_s"] = round(n / (ms * 1e-3), 1)
         extra["ed25519_verify_check_one_key_all_valid"] = bool(int(ok.sum().item()) == n)
+        # BASELINE.json configs[3] AS WORDED ("double-scalar, 4-fold"): every element through the reference's own operation
+        # order -- Verify_Init's 16-row 4-fold table per key, then the 4-fold + 8-fold walk and one shared inversion
+        # (ed25519_verify.c:179-313) -- instead of the shipped lattice-shortened walk; same verdicts, public data
+        vq = make_verify(n)
+        with _lib.tunable("VERIFY_REFERENCE_ORDER", 1):
+            vr = run_timed([vq])
+        rej = (vr["outs"][0].view(-1) == 0).cpu().numpy()
+        extra["verify_reference_order_per_s"] = round(n * args.steps / vr["elapsed"], 1)
+        extra["verify_reference_order_kernel_ms"] = round(vr["kms"][0], 4)
+        extra["verify_reference_order_bit_exact"] = vr["bit_exact"][0]
+        extra["verify_reference_order_rejects_exactly_the_corrupted"] = bool((rej == vq["bad"]).all())
+        # the same sign / verify blocks WITHOUT the clock ramp (the round-3 protocol): what part of a round-over-round change
+        # is the protocol's and what part the kernels'
+        off = {}
+        for name, mk in (("verify", make_verify), ("sign", make_sign)):
+            time.sleep(0.2)                                   # the idle gap the ramp exists for
+            r0 = run_timed([mk(n)], ramp=False)
+            off[name + "_per_s"] = round(n * args.steps / r0["elapsed"], 1)
+        extra["clock_ramp_off"] = off
         result["extra"] = extra
 
     if use_dist:
@@ -613,6 +795,10 @@ def main():
     if rank == 0:
         result["cpu_baseline"] = None if args.no_cpu else cpu_baseline(quick=world > 1)
         os.write(result_fd, (json.dumps(result) + "\n").encode())
+        if result["bit_exact"]["mismatch"]:
+            print("bench.py: OUTPUTS DIFFER from the reference's committed digests: " + json.dumps(result["bit_exact"]),
+                  file=sys.stderr)
+            sys.exit(3)
 
 
 if __name__ == "__main__":

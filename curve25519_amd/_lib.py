@@ -43,6 +43,10 @@ SIGNATURES = {
     "c25519_amd_multi_destroy": [_vp],
     "c25519_amd_multi_device_count": [_vp],
     "c25519_amd_multi_set_gather": [_vp, C.c_int],
+    "c25519_amd_multi_helper_threads": [_vp],
+    "c25519_amd_tunable_set": [C.c_char_p, C.c_long],
+    "c25519_amd_tunable_get": [C.c_char_p],
+    "c25519_amd_usable_cpus": [],
     "curve25519_dh_CreateSharedKey_multi": [_vp, _vp, _vp, _vp, _sz],
     "ed25519_SignMessage_multi": [_vp, _vp, _vp, _vp, _sz, _sz],
     "ed25519_VerifySignature_multi": [_vp, _vp, _vp, _vp, _vp, _sz, _sz],
@@ -72,6 +76,7 @@ SIGNATURES = {
 _RESTYPE = {
     "ed25519_VerifySignature_scratch_bytes": _sz,
     "c25519_amd_verify_last_slow_elements": C.c_long,
+    "c25519_amd_tunable_get": C.c_long,
     "c25519_amd_version": C.c_char_p,
     "c25519_amd_last_error": C.c_char_p,
     "ed25519_Blinding_Init": _vp,
@@ -116,6 +121,27 @@ def load(build_if_missing: bool = True):
         fn.restype = _RESTYPE.get(name, C.c_int)
     _lib = lib
     return lib
+
+
+def set_tunable(name: str, value: int):
+    """A tuning / A-B knob of the library (include/curve25519_amd.h: c25519_amd_tunable_set); value < 0 = built-in choice."""
+    check(load().c25519_amd_tunable_set(name.encode(), int(value)), f"c25519_amd_tunable_set({name})")
+
+
+class tunable:
+    """with tunable("COOP_MAX", 0): ...  -- the knob for the duration of the block, its previous value afterwards"""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = load().c25519_amd_tunable_get(self.name.encode())
+        set_tunable(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_tunable(self.name, self.prev)
+        return False
 
 
 def check(rc: int, what: str):

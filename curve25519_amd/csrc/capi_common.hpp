@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <sched.h>
 
 namespace c25519_host {
 
@@ -51,6 +53,76 @@ inline int bad_arg(const char* msg)
                     "curve25519_amd: this library has no CPU fallback; a gfx950 device is required.\n",
             fn, rc, last_error().c_str());
     abort();
+}
+
+// ---- tuning / A-B knobs (include/curve25519_amd.h: c25519_amd_tunable_set / _get) ------------------------------------
+// One table of process-wide atomics.  Every knob is initialised ONCE from the environment variable C25519_AMD_<NAME> --
+// when the first of them is read -- so no call path runs getenv() afterwards (which is not safe against a setenv() in
+// another thread), and tests / bench.py / the A-B tools change a knob at run time through the C ABI instead of through the
+// environment.  T_UNSET = the library's built-in choice.
+enum Tunable {
+    T_COOP_MAX,                 // largest batch that runs one operation per WAVE (0: never; unset: per operation, engine.hip)
+    T_XF_SPLIT,                 // X25519 as ladder + shared inversion in two launches (1) or one fused launch (0)
+    T_INV_K,                    // elements per inverting lane of k_batch_invert, 1..16
+    T_VERIFY_REFERENCE_ORDER,   // 1: every verification through the reference-order kernels (BASELINE.json configs[3] as worded)
+    T_MULTI_FORCE_GATHER,       // 1: a one-device *_multi handle takes the gather path too
+    T_MULTI_VIRTUAL,            // c25519_amd_multi_create: a one-device list becomes this many virtual devices on it
+    T_BASE_COMB,                // fixed-base walks: 0 = the 8-table signed comb in LDS, 1 = the wide comb read from L2
+    T_HELPER_THREADS,           // cap on the staging helper threads of one process (unset: the CPUs this process may use)
+    T_COUNT
+};
+constexpr long T_UNSET = -1;
+inline const char* const* tunable_names()
+{
+    static const char* const names[T_COUNT] = { "COOP_MAX", "XF_SPLIT", "INV_K", "VERIFY_REFERENCE_ORDER", "MULTI_FORCE_GATHER",
+                                                "MULTI_VIRTUAL", "BASE_COMB", "HELPER_THREADS" };
+    return names;
+}
+inline std::atomic<long>* tunable_table()
+{
+    static std::atomic<long> v[T_COUNT];
+    static const bool once = [] {
+        for (int i = 0; i < T_COUNT; i++) {
+            const std::string name = std::string("C25519_AMD_") + tunable_names()[i];
+            const char* e = getenv(name.c_str());
+            v[i].store(e && *e ? atol(e) : T_UNSET, std::memory_order_relaxed);
+        }
+        return true;
+    }();
+    (void)once;
+    return v;
+}
+inline long tunable(Tunable t) { return tunable_table()[t].load(std::memory_order_relaxed); }
+inline long tunable_or(Tunable t, long dflt) { const long v = tunable(t); return v == T_UNSET ? dflt : v; }
+
+// CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota (a container on a 256-thread host
+// is typically allowed 8-16) -- NOT std::thread::hardware_concurrency(), which reports the host.
+inline int usable_cpus()
+{
+    static const int n = [] {
+        int cpus = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) cpus = CPU_COUNT(&set);
+        auto quota_of = [](const char* path, bool v2) -> double {
+            FILE* f = fopen(path, "r");
+            if (!f) return 0.0;
+            char a[64] = {}, b[64] = {};
+            double q = 0.0;
+            if (v2) {                                              // cgroup v2: "max 100000" or "<quota> <period>"
+                if (fscanf(f, "%63s %63s", a, b) == 2 && strcmp(a, "max") != 0 && atof(b) > 0) q = atof(a) / atof(b);
+            } else if (fscanf(f, "%63s", a) == 1 && atof(a) > 0) { // cgroup v1: cpu.cfs_quota_us (-1: none) / cpu.cfs_period_us
+                FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+                if (g) { if (fscanf(g, "%63s", b) == 1 && atof(b) > 0) q = atof(a) / atof(b); fclose(g); }
+            }
+            fclose(f);
+            return q;
+        };
+        double q = quota_of("/sys/fs/cgroup/cpu.max", true);
+        if (q <= 0.0) q = quota_of("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false);
+        if (q > 0.0 && (int)(q + 0.5) < cpus) cpus = (int)(q + 0.5);
+        return cpus < 1 ? 1 : cpus;
+    }();
+    return n;
 }
 
 // Set to false by an atexit handler registered after the first HIP call (so it runs before the HIP runtime's own

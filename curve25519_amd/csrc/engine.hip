@@ -5,8 +5,9 @@
 //
 // The reference pays one field inversion (ecp_Inverse, 254 S + 11 M) per call (curve25519_dh.c:148,
 // ed25519_sign.c:265); here it is shared between several elements with Montgomery's trick:
-//   * X25519 is ONE launch (k_x25519_fused): the workgroup's waves park their projective results in LDS and
-//     one wave inverts them all;
+//   * X25519: a batch that fills the chip is two launches (k_x25519_ladder, then k_batch_invert<FinishX25519>); up to 2^16
+//     elements it is ONE (k_x25519_fused: the workgroup's waves park their projective results in LDS and one wave inverts
+//     them all); a call of a few elements runs one operation per WAVE (k_x25519_coop);
 //   * Ed25519 operations are two or three launches on the caller's stream: a "mult" kernel leaves the
 //     projective point in scratch, k_batch_invert (K elements per lane) writes the canonical bytes, and sign
 //     adds a finish kernel that hashes enc(R) || pk || m and computes S.
@@ -384,6 +385,22 @@ __global__ void __launch_bounds__(BASE_ROWS) k_gen_base_table(u32* tbl_limbs /*[
     }
 }
 
+// the wide comb's WB_NT tables (ge25519.cuh): one packed 128-byte row per thread, generated on first use of BASE_COMB = 1
+__global__ void __launch_bounds__(128) k_gen_wide_table(u32* wide /*[WB_NT][WB_ROWS][WB_ROW_WORDS]*/)
+{
+    const u32 g = blockIdx.x * 128 + threadIdx.x;             // table * WB_ROWS + row
+    const int table = (int)(g / WB_ROWS);
+    u32 rows[3][8];
+    ge_signed_comb_row(rows, g % WB_ROWS, (WB_NT - 1 - table) * WB_STEP, WB_TEETH, WB_COLS);
+    uint4* out = reinterpret_cast<uint4*>(wide + (size_t)g * WB_ROW_WORDS);
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        out[2 * f] = make_uint4(rows[f][0], rows[f][1], rows[f][2], rows[f][3]);
+        out[2 * f + 1] = make_uint4(rows[f][4], rows[f][5], rows[f][6], rows[f][7]);
+    }
+    out[6] = out[7] = make_uint4(0, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Ed25519
 // ------------------------------------------------------------------------------------------------
@@ -415,27 +432,58 @@ C25519_DEV void store_proj(const ProjScratch& scr, size_t n, size_t i, const ge_
     soa_store_fe(scr.z, n, i, S.Z);
 }
 
-// S = k*B by the LDS walk; with a blinding context (wave-uniform, 48 words in global memory) as
-// (k + bl)*B + BP from a randomised starting point   (edp_BasePointMultiply, ed25519_sign.c:246-268)
-template <bool BLIND>
-C25519_DEV void base_mult_maybe_blinded(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl, const u32* blind_ctx)
-{
-    if (BLIND) {
-        ge_base_mult_blinded(S, k, blind_ctx, lds_tbl);
-    } else {
-        ge_base_mult(S, k, lds_tbl);
+// The fixed-base kernels come in two shapes (tunable BASE_COMB, A/B: profiles/r05_ab_base_comb.txt):
+//   WIDE = false  the 8 x 32 signed comb, eight tables staged in 120 KiB of LDS per 1024-lane workgroup: 31 additions + 3 doublings;
+//   WIDE = true   the 13 x 20 signed comb of ge25519.cuh read through L2: 19 additions + 4 doublings, 256-lane workgroups, the
+//                 only LDS the lanes' parked column numbers (10 KiB).
+constexpr int WB_BLOCK = 256;
+template <bool WIDE> struct BaseComb;
+template <> struct BaseComb<false> {
+    static constexpr int BLOCK = BM_BLOCK;
+    u32* lds;
+    C25519_DEV void stage(const u32* __restrict__ g_tbl) const { lds_stage_words(lds, g_tbl, BASE_NT * BASE_TBL_WORDS); }
+    template <bool BLIND>
+    C25519_DEV void mult(ge_ext& S, const u32 (&k)[8], const u32* __restrict__, const u32* blind_ctx) const
+    {
+        if (BLIND) ge_base_mult_blinded(S, k, blind_ctx, lds);
+        else ge_base_mult(S, k, lds);
     }
-}
+};
+template <> struct BaseComb<true> {
+    static constexpr int BLOCK = WB_BLOCK;
+    unsigned short* cols;                                     // [WB_COLS][blockDim.x]
+    C25519_DEV void stage(const u32* __restrict__) const {}
+    template <bool BLIND>
+    C25519_DEV void mult(ge_ext& S, const u32 (&k)[8], const u32* __restrict__ g_wide, const u32* blind_ctx) const
+    {
+        unsigned short* mine = cols + threadIdx.x;
+        const int stride = (int)blockDim.x;
+        if (BLIND) {
+            ge_base_mult_blinded_with(S, k, blind_ctx, [&](ge_ext& P, const u32 (&t)[8], const fe& zr) {
+                wb_columns(mine, stride, t);
+                ge_base_mult_wide<true>(P, g_wide, mine, stride, &zr);
+            });
+        } else {
+            wb_columns(mine, stride, k);
+            ge_base_mult_wide(S, g_wide, mine, stride);
+        }
+    }
+};
+#define C25519_BASE_COMB_SETUP(comb)                                                                          \
+    __shared__ __attribute__((aligned(16))) u32 comb##_lds[WIDE ? WB_COLS * WB_BLOCK / 2 : BASE_NT * BASE_TBL_WORDS]; \
+    BaseComb<WIDE> comb;                                                                                      \
+    if constexpr (WIDE) comb.cols = reinterpret_cast<unsigned short*>(comb##_lds); else comb.lds = comb##_lds; \
+    comb.stage(g_tbl)
 
 // ed25519_CreateKeyPair (ed25519_sign.c:344-367), first part: a = clamp(H(sk)), S = a*B projective;
 // privKey[0..31] = sk.  The public key bytes are written by k_batch_invert<FinishPack>.
-template <bool BLIND>
-__global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_keypair_mult(ProjScratch scr, void* priv, const void* sk,
-                                                                       size_t n, const u32* __restrict__ g_tbl,
-                                                                       const u32* __restrict__ blind_ctx)
+// (g_tbl: the LDS comb's tables in device memory, or the wide comb's)
+template <bool BLIND, bool WIDE>
+__global__ void __launch_bounds__(BaseComb<WIDE>::BLOCK, 4) k_ed25519_keypair_mult(ProjScratch scr, void* priv, const void* sk,
+                                                                                    size_t n, const u32* __restrict__ g_tbl,
+                                                                                    const u32* __restrict__ blind_ctx)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
-    lds_stage_words(lds_tbl, g_tbl, BASE_NT * BASE_TBL_WORDS);
+    C25519_BASE_COMB_SETUP(comb);
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 seed[8], a[8];
@@ -444,17 +492,17 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_keypair_mult(ProjScratc
     store32(priv, 2 * i, seed);
     ed_expand_seed(a, b_words, seed);
     ge_ext S;
-    base_mult_maybe_blinded<BLIND>(S, a, lds_tbl, blind_ctx);
+    comb.template mult<BLIND>(S, a, g_tbl, blind_ctx);
     store_proj(scr, n, i, S);
 }
 
 // curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189): S = clamp(sk)*B, u = (Z+Y)/(Z-Y);
 // numerator and denominator go to scratch in the X25519 slots.
-__global__ void __launch_bounds__(BM_BLOCK, 4) k_x25519_public_fast_mult(ProjScratch scr, void* sk, size_t n,
-                                                                          const u32* __restrict__ g_tbl)
+template <bool WIDE>
+__global__ void __launch_bounds__(BaseComb<WIDE>::BLOCK, 4) k_x25519_public_fast_mult(ProjScratch scr, void* sk, size_t n,
+                                                                                       const u32* __restrict__ g_tbl)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
-    lds_stage_words(lds_tbl, g_tbl, BASE_NT * BASE_TBL_WORDS);
+    C25519_BASE_COMB_SETUP(comb);
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 k[8];
@@ -462,7 +510,7 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_x25519_public_fast_mult(ProjScr
     clamp_words(k);
     store32(sk, i, k);
     ge_ext S;
-    ge_base_mult(S, k, lds_tbl);
+    comb.template mult<false>(S, k, g_tbl, nullptr);
     fe num, den, t;
     fe_add(t, S.Z, S.Y);  fe_carry32(num, t);
     fe_sub(t, S.Z, S.Y);  fe_carry32(den, t);
@@ -472,14 +520,13 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_x25519_public_fast_mult(ProjScr
 
 // ed25519_SignMessage (ed25519_sign.c:372-419), first part (:385-400):
 // a = clamp(H(sk)[0..31]), r = H(H(sk)[32..63] || m) mod L (canonical), R = r*B projective.
-template <bool BLIND>
-__global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_sign_mult(ProjScratch scr, u32* a_out, u32* r_out,
-                                                                    const void* priv, Msgs msgs, size_t n,
-                                                                    const u32* __restrict__ g_tbl,
-                                                                    const u32* __restrict__ blind_ctx)
+template <bool BLIND, bool WIDE>
+__global__ void __launch_bounds__(BaseComb<WIDE>::BLOCK, 4) k_ed25519_sign_mult(ProjScratch scr, u32* a_out, u32* r_out,
+                                                                                 const void* priv, Msgs msgs, size_t n,
+                                                                                 const u32* __restrict__ g_tbl,
+                                                                                 const u32* __restrict__ blind_ctx)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds_tbl[BASE_NT * BASE_TBL_WORDS];
-    lds_stage_words(lds_tbl, g_tbl, BASE_NT * BASE_TBL_WORDS);
+    C25519_BASE_COMB_SETUP(comb);
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 seed[8], a[8], r[8];
@@ -488,7 +535,7 @@ __global__ void __launch_bounds__(BM_BLOCK, 4) k_ed25519_sign_mult(ProjScratch s
     soa_store8(a_out, n, i, a);
     soa_store8(r_out, n, i, r);
     ge_ext S;
-    base_mult_maybe_blinded<BLIND>(S, r, lds_tbl, blind_ctx);
+    comb.template mult<BLIND>(S, r, g_tbl, blind_ctx);
     store_proj(scr, n, i, S);
 }
 
@@ -988,76 +1035,6 @@ __global__ void __launch_bounds__(INV_BLOCK) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-// A/B only (C25519_AMD_SIGN_TAIL=<lanes>, profiles/r04_ab_sign_tail.txt): the signing pass's last two launches in one --
-// the shared inversion inside the workgroup (wave 0: one exponentiation per BLOCK / 64 elements, as k_x25519_fused does),
-// then every lane packs its enc(R) and goes straight on to h and S.  The other waves of the workgroup cannot hash while
-// wave 0 inverts (h wants enc(R)); only ANOTHER workgroup of the CU can, if it happens to be out of step.  It loses to the
-// two launches at every width: see the profile.
-template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 4) k_ed25519_sign_tail(ProjScratch scr, void* sig, const void* priv, Msgs msgs, size_t n,
-                                                               u32* a_in, u32* r_in)
-{
-    constexpr int K = BLOCK / 64;
-    __shared__ u32 zbuf[10 * BLOCK];
-    __shared__ u32 pbuf[(K > 1 ? K - 1 : 1) * 10 * 64];
-    const int tid = threadIdx.x;
-    const size_t i = (size_t)blockIdx.x * BLOCK + tid;
-    const bool active = i < n;
-    {
-        fe z;
-        if (active) soa_load_fe(z, scr.z, n, i); else fe_set_u32(z, 1);
-        lds_put_fe(zbuf, BLOCK, tid, z);
-    }
-    __syncthreads();
-    if (tid < 64) {
-        fe acc, z, zero;
-        fe_set_u32(zero, 0);
-        u32 zero_mask = 0;
-#pragma unroll 1
-        for (int t = 0; t < K; t++) {
-            lds_get_fe(z, zbuf, BLOCK, tid + 64 * t);
-            zero_mask |= (fe_zero_to_one(z) & 1u) << t;
-            if (t == 0) acc = z; else fe_mul(acc, acc, z);
-            if (t < K - 1) lds_put_fe(pbuf + t * 640, 64, tid, acc);
-        }
-        fe inv;
-        fe_invert(inv, acc);
-#pragma unroll 1
-        for (int t = K - 1; t >= 0; t--) {
-            fe zi;
-            const u32 was_zero = ((zero_mask >> t) & 1u) ? 0xffffffffu : 0u;
-            if (t > 0) {
-                fe p, one;
-                lds_get_fe(p, pbuf + (t - 1) * 640, 64, tid);
-                fe_mul(zi, inv, p);
-                lds_get_fe(z, zbuf, BLOCK, tid + 64 * t);
-                fe_set_u32(one, 1);
-                fe_select(z, was_zero, one, z);
-                fe_mul(inv, inv, z);
-                fe_select(zi, was_zero, zero, zi);
-            } else {
-                fe_select(zi, was_zero, zero, inv);
-            }
-            lds_put_fe(zbuf, BLOCK, tid + 64 * t, zi);
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-    fe zi;
-    lds_get_fe(zi, zbuf, BLOCK, tid);
-    u32 encR[8], pkw[8], a[8], r[8], sw[8];
-    const u32 zero8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    affine_pack(encR, scr.a, scr.b, n, i, zi);
-    store32(sig, 2 * i, encR);
-    load32(pkw, priv, 2 * i + 1);
-    soa_load8(a, a_in, n, i);
-    soa_load8(r, r_in, n, i);
-    soa_store8(a_in, n, i, zero8);
-    soa_store8(r_in, n, i, zero8);
-    ed_sign_s(sw, encR, pkw, msgs.ptr(i), msgs.len(i), a, r);
-    store32(sig, 2 * i + 1, sw);
-}
-
 // ------------------------------------------------------------------------------------------------
 // unit-test hooks (the counterpart of the reference's ECP_SELF_TEST unit checks,
 // test/curve25519_selftest.c:624-741): one lane per input record, operations defined in lanes.cuh
@@ -1111,8 +1088,9 @@ using c25519_host::tls;
 
 constexpr int MAX_DEVICES = 64;
 struct DeviceTables {
-    std::once_flag once;
-    int rc = 0;
+    std::once_flag once, wide_once;
+    int rc = 0, wide_rc = 0;
+    u32* wide = nullptr;      // [WB_NT][WB_ROWS][WB_ROW_WORDS]: the wide comb's packed tables (2 MiB), made on first use
     u32* limbs = nullptr;     // [BASE_NT][30][128] signed comb tables 2^28 Ts .. Ts, [30][256]: the reference's table T, [30][SC_ROWS]: the lattice walk's comb
     u32* bytes = nullptr;     // [256][24]
 };
@@ -1143,6 +1121,28 @@ int base_tables(const u32** limbs, const u32** bytes)
 }
 
 inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+// the wide fixed-base comb of the current device (tunable BASE_COMB = 1), generated at its first use
+int wide_tables(const u32** wide)
+{
+    int dev = 0;
+    C25519_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return bad_arg("device ordinal out of range");
+    DeviceTables& t = g_tables[dev];
+    std::call_once(t.wide_once, [&] {
+        t.wide_rc = [&]() -> int {
+            C25519_TRY(hipMalloc(&t.wide, WB_TBL_WORDS * sizeof(u32)));
+            k_gen_wide_table<<<WB_NT * WB_ROWS / 128, 128, 0, nullptr>>>(t.wide);
+            C25519_TRY(hipGetLastError());
+            C25519_TRY(hipStreamSynchronize(nullptr));
+            return 0;
+        }();
+    });
+    if (t.wide_rc) return t.wide_rc;
+    *wide = t.wide;
+    return 0;
+}
+inline bool base_comb_wide() { return c25519_host::tunable_or(c25519_host::T_BASE_COMB, 0) == 1; }
 
 // *_dev arguments: n in range, pointers 16-byte aligned and -- unless C25519_AMD_NO_PTR_CHECK is set -- device (or
 // managed) memory of the CURRENT device: a pointer of another GPU or a host pointer is an error here, not a fault
@@ -1184,10 +1184,8 @@ ProjScratch carve_proj(u32* base, size_t n)
 // (measured at n = 2^20: K = 2 / 4 / 8 / 16 -> 9.52 / 9.39 / 9.33 / 9.29 ms per two-launch X25519 pass)
 inline int inversion_k(size_t n)
 {
-    if (const char* e = getenv("C25519_AMD_INV_K")) {      // tuning knob, 1..16
-        int v = atoi(e);
-        if (v >= 1 && v <= INV_MAX_K) return v;
-    }
+    const long v = c25519_host::tunable(c25519_host::T_INV_K);    // tuning knob, 1..16
+    if (v >= 1 && v <= INV_MAX_K) return (int)v;
     size_t k = n / ((size_t)1024 * 64);
     if (k < 1) k = 1;
     if (k > INV_MAX_K) k = INV_MAX_K;
@@ -1294,11 +1292,12 @@ int x25519_block_for(size_t n)
 
 // a call of a few elements -- the reference's single-call prototypes are a batch of one -- runs ONE operation per wave
 // (k_x25519_coop): ~5 x less latency than one operation per lane, at ~12 x the instructions per operation, so only while
-// the waves still find idle SIMDs.  C25519_AMD_COOP_MAX = the largest such batch (A/B knob, read per call; 0 = never).
+// the waves still find idle SIMDs.  Tunable COOP_MAX = the largest such batch (A/B and test knob; 0 = never; at most 2^20:
+// one workgroup per element).
 bool coop_for(size_t n, size_t dflt)
 {
-    size_t max = dflt;
-    if (const char* e = getenv("C25519_AMD_COOP_MAX")) max = (size_t)atol(e);
+    const long v = c25519_host::tunable(c25519_host::T_COOP_MAX);
+    const size_t max = v == c25519_host::T_UNSET ? dflt : (size_t)std::min<long>(std::max<long>(v, 0), 1L << 20);
     return n <= max && c25519_host::batch_shape_hint() <= max;
 }
 // crossovers measured on MI355X (tools/small_batch_sweep.py, profiles/r04_small_batch_sweep.txt): the ladder one per wave
@@ -1309,10 +1308,11 @@ bool fixed_base_coop_for(size_t n) { return coop_for(n, 2048); }
 bool verify_coop_for(size_t n) { return coop_for(n, 2048); }       // the walk alone: 0.25-0.38 against 0.60 ms
 
 // a batch that fills the chip runs the ladder and the shared inversion as two launches (k_x25519_ladder's comment);
-// C25519_AMD_XF_SPLIT=0/1 forces either shape (A/B knob, read per call)
+// tunable XF_SPLIT = 0 / 1 forces either shape (A/B knob)
 bool x25519_split_for(size_t n)
 {
-    if (const char* e = getenv("C25519_AMD_XF_SPLIT")) return atoi(e) != 0;
+    const long v = c25519_host::tunable(c25519_host::T_XF_SPLIT);
+    if (v != c25519_host::T_UNSET) return v != 0;
     return std::max(n, c25519_host::batch_shape_hint()) > ((size_t)1 << 16);   // measured at the sustained clock: two launches win from 2^17 up (3 / 2 / 1.2 % at 2^17 / 2^18 / 2^20), one launch by 1 % below
 }
 
@@ -1353,6 +1353,29 @@ int c25519_amd_host_unregister(void* p)
     C25519_TRY(hipHostUnregister(p));
     return 0;
 }
+
+// tuning / A-B knobs (capi_common.hpp: Tunable).  name = the part behind C25519_AMD_ of the environment variable that
+// initialises the knob; value < 0 restores the library's built-in choice.
+int c25519_amd_tunable_set(const char* name, long value)
+{
+    if (!name) return bad_arg("null pointer");
+    for (int i = 0; i < c25519_host::T_COUNT; i++)
+        if (!strcmp(name, c25519_host::tunable_names()[i])) {
+            c25519_host::tunable_table()[i].store(value < 0 ? c25519_host::T_UNSET : value, std::memory_order_relaxed);
+            return 0;
+        }
+    return bad_arg("c25519_amd_tunable_set: no such knob");
+}
+
+long c25519_amd_tunable_get(const char* name)
+{
+    if (name)
+        for (int i = 0; i < c25519_host::T_COUNT; i++)
+            if (!strcmp(name, c25519_host::tunable_names()[i])) return c25519_host::tunable((c25519_host::Tunable)i);
+    return -2;
+}
+
+int c25519_amd_usable_cpus(void) { return c25519_host::usable_cpus(); }
 
 int c25519_amd_set_device(int device)
 {
@@ -1441,7 +1464,13 @@ int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void
     c25519_host::WorkLease lease;
     C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
-    k_x25519_public_fast_mult<<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, sk, n, tbl);
+    if (base_comb_wide()) {
+        const u32* wide = nullptr;
+        C25519_RC(wide_tables(&wide));
+        k_x25519_public_fast_mult<true><<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(scr, sk, n, wide);
+    } else {
+        k_x25519_public_fast_mult<false><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, sk, n, tbl);
+    }
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishX25519{ scr.a, pk, n }, stream));
     return lease.release();
@@ -1463,10 +1492,15 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
     c25519_host::WorkLease lease;
     C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
-    if (blinding)
-        k_ed25519_keypair_mult<true><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, priv, sk, n, tbl, (const u32*)blinding);
+    if (base_comb_wide()) {
+        const u32* wide = nullptr;
+        C25519_RC(wide_tables(&wide));
+        if (blinding) k_ed25519_keypair_mult<true, true><<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(scr, priv, sk, n, wide, (const u32*)blinding);
+        else k_ed25519_keypair_mult<false, true><<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(scr, priv, sk, n, wide, nullptr);
+    } else if (blinding)
+        k_ed25519_keypair_mult<true, false><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, priv, sk, n, tbl, (const u32*)blinding);
     else
-        k_ed25519_keypair_mult<false><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, priv, sk, n, tbl, nullptr);
+        k_ed25519_keypair_mult<false, false><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, priv, sk, n, tbl, nullptr);
     C25519_TRY(hipGetLastError());
     // pub[e] and priv[e][32..63] <- enc(A)
     C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, pub, n, 1, 0, priv, 2, 1 }, stream));
@@ -1502,22 +1536,22 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
     const ProjScratch scr = carve_proj((u32*)w, n);
     u32* a_buf = (u32*)w + proj_words(n);
     u32* r_buf = a_buf + sc_words;
-    if (blinding)
-        k_ed25519_sign_mult<true><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl,
-                                                                               (const u32*)blinding);
+    if (base_comb_wide()) {
+        const u32* wide = nullptr;
+        C25519_RC(wide_tables(&wide));
+        if (blinding) k_ed25519_sign_mult<true, true><<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, wide, (const u32*)blinding);
+        else k_ed25519_sign_mult<false, true><<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, wide, nullptr);
+    } else if (blinding)
+        k_ed25519_sign_mult<true, false><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl,
+                                                                                      (const u32*)blinding);
     else
-        k_ed25519_sign_mult<false><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl,
-                                                                                nullptr);
+        k_ed25519_sign_mult<false, false><<<grid_for(n, bm_block_for(n)), bm_block_for(n), 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, tbl,
+                                                                                       nullptr);
     C25519_TRY(hipGetLastError());
-    const char* tail_env = getenv("C25519_AMD_SIGN_TAIL");                        // A/B only (read per call: tools/ab_bench.py lib.so@KEY=VAL)
-    const int tail_lanes = tail_env ? atoi(tail_env) : 0;
-    if (tail_lanes == 256) k_ed25519_sign_tail<256><<<grid_for(n, 256), 256, 0, stream>>>(scr, sig, priv, msgs, n, a_buf, r_buf);
-    else if (tail_lanes == 512) k_ed25519_sign_tail<512><<<grid_for(n, 512), 512, 0, stream>>>(scr, sig, priv, msgs, n, a_buf, r_buf);
-    else if (tail_lanes == 1024) k_ed25519_sign_tail<1024><<<grid_for(n, 1024), 1024, 0, stream>>>(scr, sig, priv, msgs, n, a_buf, r_buf);
-    else {
-        C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, sig, n, 2, 0, nullptr, 0, 0 }, stream));   // sig[e][0..31] = enc(R)
-        k_ed25519_sign_finish<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(sig, priv, msgs, n, a_buf, r_buf);
-    }
+    // (the last two launches in one -- the shared inversion inside the workgroup, then h and S -- lost to this at every width:
+    // profiles/r04_ab_sign_tail.txt)
+    C25519_RC(launch_invert(scr, n, FinishPack{ scr.a, scr.b, sig, n, 2, 0, nullptr, 0, 0 }, stream));   // sig[e][0..31] = enc(R)
+    k_ed25519_sign_finish<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(sig, priv, msgs, n, a_buf, r_buf);
     C25519_TRY(hipGetLastError());
     return lease.release();
 }
@@ -1559,8 +1593,9 @@ size_t ed25519_VerifySignature_scratch_bytes(size_t n) { return verify_scratch_b
 
 static int verify_dev(void* verdict, const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t stream)
 {
-    // C25519_AMD_VERIFY_REFERENCE_ORDER=1: every element through the reference-order kernels (A/B and test knob)
-    static const bool fast = getenv("C25519_AMD_VERIFY_REFERENCE_ORDER") == nullptr;
+    // tunable VERIFY_REFERENCE_ORDER = 1: every element through the reference-order kernels -- Verify_Init's 4-fold table per
+    // key, then the 4-fold + 8-fold walk of ed25519_verify.c:243-280: BASELINE.json configs[3] as worded (A/B and test knob)
+    const bool fast = c25519_host::tunable_or(c25519_host::T_VERIFY_REFERENCE_ORDER, 0) == 0;
     if (int rc = check_dev_args(n, { verdict, sig, pk })) return rc;
     if (n == 0) return 0;
     return verify_run(sig, pk, msgs, n, stream, (int*)verdict, fast,

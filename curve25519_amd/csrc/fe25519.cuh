@@ -114,7 +114,8 @@ C25519_DEV void fe_finish_chain(fe& r, u32 (&l)[10], u64 carry)
 #ifdef C25519_FENCE_FIELD                 // A/B knob (profiles/r03_ab_fence.txt): a fence behind every product
     C25519_SCHED_FENCE();
 #endif
-    const u64 t = carry * 19 + l[0];
+    const u64 t = carry * 19 + l[0];                      // one v_mad_u64_u32
+    C25519_COUNT_MAD(1);
     l[0] = (u32)t & M26;
     l[1] += (u32)(t >> 26);
 #pragma unroll
@@ -258,6 +259,7 @@ C25519_DEV void fe_mul121665_add(fe& r, const fe& a, const fe& b)
     // carry is < 2^21 and a.v[i] + carry still fits 32 bits -- no 64-bit carry arithmetic (it was a 64-bit shift and a
     // 64-bit add per limb)
     u32 l[10], carry = 0;
+    C25519_COUNT_MAD(10);
 #pragma unroll
     for (int i = 0; i < 10; i++) {
         const u64 h = (u64)b.v[i] * 121665u + (u64)(a.v[i] + carry);
@@ -275,6 +277,7 @@ C25519_DEV void fe_mul121665_add(fe& r, const fe& a, const fe& b)
 C25519_DEV void fe_mul_small(fe& r, const fe& a, u32 c)
 {
     u32 l[10], carry = 0;                                 // a*c < 2^45: carries < 2^20, chained like above
+    C25519_COUNT_MAD(10);
 #pragma unroll
     for (int i = 0; i < 10; i++) {
         const u64 h = (u64)a.v[i] * c + carry;

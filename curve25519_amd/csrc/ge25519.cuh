@@ -329,6 +329,105 @@ C25519_DEV void ge_base_mult(ge_ext& S, const u32 (&k)[8], const u32* lds_tbl, c
     }
 }
 
+// ---- the WIDE fixed-base comb, read through L2 (tunable BASE_COMB = 1) ----------------------------------------------
+// The LDS comb above is capped at 8 teeth by 120 KiB of LDS: 31 additions + 3 doublings per scalar.  A signed comb of
+// WB_TEETH = 13 teeth WB_COLS = 20 bits apart, cut into WB_NT = 4 tables T_t = 2^((WB_NT-1-t) * WB_STEP) * T of 4096 rows
+// each, needs 19 additions + 4 doublings -- a third fewer field products -- at 4 x 4096 rows x 128 bytes = 2 MiB of table:
+// not LDS, but resident in every XCD's 4 MB L2.  A lane fetches the row its (secret) column selects straight from
+// global memory, exactly as the reference indexes its table (ed25519_sign.c:239-243): one 128-byte line per row (packed
+// canonical Y+X | Y-X | 2dT | pad), no staging, no LDS table -- so the workgroup shape is free (256 lanes, four waves per
+// SIMD: while one wave waits ~500 cycles for its row, the other three issue MADs).  The columns are gathered ONCE, with
+// compile-time bit positions, into 20 x 16 bits per lane parked in LDS (the walk's loops stay rolled: a run-time column
+// number would index the scalar's registers dynamically).
+// Same recoding as above with 260 digits: w = (k' >> 1) | 2^259; column p = bits p, p + 20, ..., p + 240 of w, the top one
+// its sign; sum_p 2^p T[col_p] = sum_{m < STEP} 2^(STEP-1-m) sum_{t < NT} T_t[col_(COLS-1-(t*STEP+m))].
+constexpr int WB_TEETH = 13;
+constexpr int WB_COLS = 20;
+constexpr int WB_NT = 4;
+constexpr int WB_STEP = WB_COLS / WB_NT;
+constexpr int WB_ROWS = 1 << (WB_TEETH - 1);
+constexpr int WB_ROW_WORDS = 32;                             // one 128-byte line: 3 x 8 words + 8 of padding
+constexpr size_t WB_TBL_WORDS = (size_t)WB_NT * WB_ROWS * WB_ROW_WORDS;    // 2 MiB
+static_assert(WB_NT * WB_STEP == WB_COLS && WB_TEETH * WB_COLS >= 256, "the wide comb covers 256 + bits");
+
+// the 20 columns of k in the order the walk consumes them (s = m * WB_NT + t), 16 bits each, to cols[s * stride]
+template <typename ColT>
+C25519_DEV void wb_columns(ColT* cols, int stride, const u32 (&k)[8])
+{
+    const u32 even = (k[0] & 1u) - 1u;                       // all-ones when k is even
+    u32 t[9], w[9];
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (u64)k[i] + (K_L[i] & even);
+        t[i] = (u32)c;
+        c >>= 32;
+    }
+    t[8] = (u32)c;                                           // k + L < 2^256 + 2^253: one more bit at most
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = (t[i] >> 1) | (t[i + 1] << 31);
+    w[8] = t[8] >> 1;
+    constexpr int TOP = WB_TEETH * WB_COLS - 1;              // digit TOP is +1
+    w[TOP >> 5] |= 1u << (TOP & 31);
+#pragma unroll
+    for (int m = 0; m < WB_STEP; m++)
+#pragma unroll
+        for (int tt = 0; tt < WB_NT; tt++) {
+            const int p = WB_COLS - 1 - (tt * WB_STEP + m);
+            u32 idx = 0;
+#pragma unroll
+            for (int j = 0; j < WB_TEETH; j++) {
+                const int bit = WB_COLS * j + p;
+                idx |= ((w[bit >> 5] >> (bit & 31)) & 1u) << j;
+            }
+            cols[(m * WB_NT + tt) * stride] = (ColT)idx;
+        }
+}
+
+// the row a 13-bit column c selects in table `tbl` (4096 packed rows): tooth 12 is the sign
+C25519_DEV void wb_load_pa_signed(ge_pa& q, const u32* __restrict__ tbl, u32 c)
+{
+    const u32 neg = ((c >> (WB_TEETH - 1)) & 1u) - 1u;        // all-ones: negative column
+    const u32 row = (c ^ neg) & (u32)(WB_ROWS - 1);
+    const uint4* r = reinterpret_cast<const uint4*>(tbl + (size_t)row * WB_ROW_WORDS);
+    const uint4* p_ypx = r + (neg ? 2 : 0);                  // a negative column swaps Y+X and Y-X ...
+    const uint4* p_ymx = r + (neg ? 0 : 2);
+    const uint4 a0 = p_ypx[0], a1 = p_ypx[1], b0 = p_ymx[0], b1 = p_ymx[1], c0 = r[4], c1 = r[5];
+    const u32 wa[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+    const u32 wb[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+    const u32 wc[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+    fe t, n;
+    fe_from_words(q.ypx, wa);
+    fe_from_words(q.ymx, wb);
+    fe_from_words(t, wc);
+    fe_neg(n, t);                                            // ... and negates 2dxy
+    fe_select(q.t2d, neg, n, t);
+}
+
+// S = k * B over the wide comb.  g_wide: the WB_NT packed tables in device memory; cols: this lane's parked columns
+// (wb_columns), `stride` elements apart.  FINAL_T as in ge_base_mult.
+template <bool FINAL_T = false, typename ColT>
+C25519_DEV void ge_base_mult_wide(ge_ext& S, const u32* __restrict__ g_wide, const ColT* cols, int stride, const fe* zr = nullptr)
+{
+    ge_pa q;
+    wb_load_pa_signed(q, g_wide, cols[0]);
+    ge_from_pa(S, q, zr);
+#pragma unroll 1
+    for (int m = 0; m < WB_STEP; m++) {
+        if (m) ge_double(S);
+#pragma unroll 1
+        for (int t = m ? 0 : 1; t < WB_NT - 1; t++) {
+            wb_load_pa_signed(q, g_wide + (size_t)t * WB_ROWS * WB_ROW_WORDS, cols[(m * WB_NT + t) * stride]);
+            C25519_SCHED_FENCE();
+            ge_add_pa<true>(S, q);
+        }
+        wb_load_pa_signed(q, g_wide + (size_t)(WB_NT - 1) * WB_ROWS * WB_ROW_WORDS, cols[(m * WB_NT + WB_NT - 1) * stride]);
+        C25519_SCHED_FENCE();
+        if (FINAL_T) ge_add_pa_rt(S, q, m == WB_STEP - 1);
+        else ge_add_pa<false>(S, q);
+    }
+}
+
 // affine canonical words of S: x = X/Z, y = Y/Z   (tail of edp_BasePointMultiply, ed25519_sign.c:265-267)
 C25519_DEV void ge_to_affine_words(u32 (&xw)[8], u32 (&yw)[8], const ge_ext& S)
 {

@@ -92,12 +92,15 @@ private:
 // ---- host-pointer pipeline used by the *_batch entry points -------------------------------------------------------
 // A call is cut into pieces; piece c uses buffer set c % SETS (pinned host + device staging), and these roles work on
 // different pieces at the same time:
-//     stage-in  : helper threads (4, or 2 on a small host; C25519_AMD_STAGERS) copy the caller's pageable arrays into a set's pinned buffers
+//     stage-in  : helper threads (pipeline_helpers(): 4, 2 or 1 by the CPUs this process may use and the pipelines that run
+//                 beside this one; C25519_AMD_STAGERS) copy the caller's pageable arrays into a set's pinned buffers
 //     submit    : the calling thread enqueues the piece: upload on the upload stream, the *_dev kernels on one of two
 //                 kernel streams, download on the download stream, chained by events (pinned memory: hipMemcpyAsync is
 //                 a real DMA).  With copies and kernels on the same stream, piece c+4's upload queued behind piece c's
 //                 kernels and the device idled between rounds of four.
 //     stage-out : helper threads (2, or 1; C25519_AMD_DRAINERS) wait for the set's event and copies the results out
+//                 (a pipeline that is granted ONE helper has it do both: stage the first SETS pieces, then drain piece
+//                 c - SETS and stage piece c in turn)
 // so both CPU copies and both PCIe directions ride under the kernels of the neighbouring pieces.  Pieces are n/8 for
 // big batches: two of them (2^18 lanes) fill every kernel's occupancy, and a piece cannot finish faster than one
 // ladder's latency (~0.7-1.2 ms), so fewer, larger pieces in flight beat many small ones.  Eight buffer sets let a 2^20
@@ -118,6 +121,27 @@ inline int env_count(const char* name, int dflt, int max)
     const char* e = getenv(name);
     const int v = e ? atoi(e) : 0;
     return v >= 1 && v <= max ? v : dflt;
+}
+
+// How many helper threads a pipelined call may park, from the CPUs this process may use (usable_cpus(): affinity and cgroup
+// quota, not the host's thread count; C25519_AMD_HELPER_THREADS overrides) and the number of pipelines running beside each
+// other (the multi-GPU layer runs one per device and says so through concurrent_pipelines()): 4 + 2 with cores to spare
+// (sign moves 160 B per 1.8 ns of kernel time: one copier per direction cannot keep up), 2 + 1, 1 + 1, or ONE helper that
+// stages and drains in turn -- so that eight devices' pipelines on a 16-CPU container park 8 helpers, not 48.
+inline int& concurrent_pipelines() { thread_local int n = 1; return n; }
+inline int& reserved_helper_threads() { thread_local int n = 0; return n; }
+struct HelperPlan { int stagers, drainers; bool combined; int total() const { return combined ? 1 : stagers + drainers; } };
+inline HelperPlan pipeline_helpers(int concurrent, int reserved = 0)
+{
+    const long budget = tunable_or(T_HELPER_THREADS, usable_cpus());
+    const long share = (budget - reserved) / (concurrent < 1 ? 1 : concurrent);
+    HelperPlan p = share >= (concurrent > 1 ? 6 : 16) ? HelperPlan{ 4, 2, false }
+                 : share >= 3 ? HelperPlan{ 2, 1, false } : share >= 2 ? HelperPlan{ 1, 1, false } : HelperPlan{ 0, 0, true };
+    if (!p.combined) {
+        p.stagers = env_count("C25519_AMD_STAGERS", p.stagers, MAX_STAGERS);
+        p.drainers = env_count("C25519_AMD_DRAINERS", p.drainers, MAX_DRAINERS);
+    }
+    return p;
 }
 
 // is [p, p + bytes) page-locked host memory the device can DMA from (hipHostMalloc / hipHostRegister /
@@ -284,15 +308,37 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
     size_t submitted = 0;
     int failed = 0;                                       // first error of any role; everybody stops
     std::string failed_text;                              // ... and its text: last_error() is thread-local, helpers have their own
-    // helper threads: 4 + 2 on a machine with cores to spare (sign moves 160 B per 1.8 ns of kernel time: one copier
-    // per direction cannot keep up), 2 + 1 on a small one; parked in the calling thread's pool between calls
-    static const bool roomy = std::thread::hardware_concurrency() >= 16;
-    static const int STAGERS = env_count("C25519_AMD_STAGERS", roomy ? 4 : 2, MAX_STAGERS);
-    static const int DRAINERS = env_count("C25519_AMD_DRAINERS", roomy ? 2 : 1, MAX_DRAINERS);
-    HelperPool& pool = helper_pool(STAGERS + DRAINERS);
+    // helper threads: pipeline_helpers() above; parked in the calling thread's pool between calls
+    const HelperPlan plan = pipeline_helpers(concurrent_pipelines(), reserved_helper_threads());
+    const int STAGERS = plan.combined ? 1 : plan.stagers, DRAINERS = plan.combined ? 0 : plan.drainers;
+    HelperPool& pool = helper_pool(plan.total());
     if (!pool.ok()) return sequential();                  // the process cannot have more threads: do without them
+    auto drain_piece = [&](size_t c) -> bool {            // false: somebody failed, stop
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return failed || submitted > c; });
+            if (failed) return false;
+        }
+        const int rc = drain(c);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc && !failed) { failed = rc; failed_text = last_error(); }
+            drained[c] = 1;
+        }
+        cv.notify_all();
+        return rc == 0;
+    };
     auto helper = [&](int idx) {
-        if (idx < STAGERS) {
+        if (plan.combined) {                              // one helper: piece c's buffer set is free once piece c - sets has left
+            for (size_t c = 0; c < nchunks + (size_t)sets; c++) {
+                if (c >= (size_t)sets && !drain_piece(c - sets)) return;
+                if (c < nchunks) {
+                    stage_in(c, 0, 1);
+                    { std::lock_guard<std::mutex> lk(mu); staged[c]++; }
+                    cv.notify_all();
+                }
+            }
+        } else if (idx < STAGERS) {
             const int sidx = idx;
             for (size_t c = 0; c < nchunks; c++) {        // every stager copies its share of every piece: pieces
                                                           // become ready in order, each in 1/STAGERS of the time
@@ -307,23 +353,11 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
             }
         } else {
             const int didx = idx - STAGERS;
-            for (size_t c = didx; c < nchunks; c += DRAINERS) {
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return failed || submitted > c; });
-                    if (failed) return;
-                }
-                const int rc = drain(c);
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    if (rc && !failed) { failed = rc; failed_text = last_error(); }
-                    drained[c] = 1;
-                }
-                cv.notify_all();
-            }
+            for (size_t c = didx; c < nchunks; c += DRAINERS)
+                if (!drain_piece(c)) return;
         }
     };
-    pool.run(STAGERS + DRAINERS, helper);
+    pool.run(plan.total(), helper);
     for (size_t c = 0; c < nchunks; c++) {
         {
             std::unique_lock<std::mutex> lk(mu);

@@ -140,7 +140,9 @@ constexpr int BLIND_WORDS = 48;
 // one at a time for the final addition (held across the walk they cost 40 registers the 1024-thread kernels do not have).
 // k + bl is reduced mod L before the recoding: sc_signed_comb adds L to an even scalar in 256 bits, so it needs its input
 // below 2^256 - L; contexts from ed25519_Blinding_Init have bl <= L, but a context is caller-supplied bytes.
-C25519_DEV void ge_base_mult_blinded(ge_ext& S, const u32 (&k)[8], const u32* ctx, const u32* lds_tbl)
+// base_mult(S, t, zr): S = t * B from the starting point spread by zr, T of the result included (either comb).
+template <typename BaseMult>
+C25519_DEV void ge_base_mult_blinded_with(ge_ext& S, const u32 (&k)[8], const u32* ctx, BaseMult base_mult)
 {
     u32 t[8], w[8];
     {
@@ -155,7 +157,7 @@ C25519_DEV void ge_base_mult_blinded(ge_ext& S, const u32 (&k)[8], const u32* ct
 #pragma unroll
         for (int i = 0; i < 8; i++) w[i] = ctx[8 + i];
         fe_from_words(zr, w);
-        ge_base_mult<true>(S, t, lds_tbl, &zr);  // T of the result feeds the addition below
+        base_mult(S, t, zr);                  // T of the result feeds the addition below
     }
     // S += BP (:257); the affine conversion that follows never reads T.  ge_add_pe with the fields streamed in.
     fe q, a, b, e, f, g, h;
@@ -177,6 +179,11 @@ C25519_DEV void ge_base_mult_blinded(ge_ext& S, const u32 (&k)[8], const u32* ct
     fe_mul(S.X, e, f);
     fe_mul(S.Z, g, f);
     fe_mul(S.Y, g, h);
+}
+
+C25519_DEV void ge_base_mult_blinded(ge_ext& S, const u32 (&k)[8], const u32* ctx, const u32* lds_tbl)
+{
+    ge_base_mult_blinded_with(S, k, ctx, [&](ge_ext& P, const u32 (&t)[8], const fe& zr) { ge_base_mult<true>(P, t, lds_tbl, &zr); });
 }
 
 // ---- 8-fold base table rows ----------------------------------------------------------------------------------

@@ -17,6 +17,11 @@
 //      piece's gather and download are not hidden (round 3 ran the three phases strictly one after the other).
 //   c25519_amd_multi_set_gather(handle, 0) leaves the gather out: every device hands its own rows to the caller over
 //   its own PCIe link (no root-link bound for host destinations); the gather mode is what north_star names and the default.
+//   Virtual devices: a device list that names one device several times (or C25519_AMD_MULTI_VIRTUAL=V with a one-device
+//   list) runs V workers, shards, pipelines and gather streams on that ONE device -- everything of the D > 1 path except
+//   RCCL, which refuses a duplicate device: the gather of a piece is then D device-to-device copies on the gather streams.
+//   It is how the D > 1 code (cut rows, pad rows, rank-major blocks, drain / copier hand-over, thread budget) runs on a
+//   one-GPU box; it is not a way to go faster.
 // RCCL is loaded with dlopen on first use, so single-GPU users of the library do not pay for (or need) it; without its
 // header the few declarations used here are spelled out below, so the library builds on a machine that lacks RCCL.
 #include "capi_common.hpp"
@@ -94,7 +99,7 @@ struct Worker {
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::function<int()>> jobs;
+    std::deque<std::function<int(bool)>> jobs;     // int job(bool skipped): skipped = a job before it in this sequence failed
     size_t submitted = 0, finished = 0;
     bool stop = false;
     int rc = 0;
@@ -106,7 +111,7 @@ struct Worker {
         th = std::thread([this] {
             (void)hipSetDevice(device);
             for (;;) {
-                std::function<int()> j;
+                std::function<int(bool)> j;
                 bool skip;
                 {
                     std::unique_lock<std::mutex> lk(mu);
@@ -116,7 +121,7 @@ struct Worker {
                     jobs.pop_front();
                     skip = rc != 0;
                 }
-                const int r = skip ? 0 : j();
+                const int r = j(skip);
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     if (r && !rc) { rc = r; err = last_error(); }     // the error text is thread-local: carry it to the caller
@@ -127,7 +132,13 @@ struct Worker {
             c25519_amd_thread_release();                         // staging zeroed and freed on the worker's own device
         });
     }
+    // an ordinary job is skipped behind a failed one ...
     void submit(std::function<int()> j)
+    {
+        submit_always([j = std::move(j)](bool skipped) -> int { return skipped ? 0 : j(); });
+    }
+    // ... a job that hands something back (a pinned slot) runs either way and is told whether to do its work
+    void submit_always(std::function<int(bool)> j)
     {
         { std::lock_guard<std::mutex> lk(mu); jobs.push_back(std::move(j)); submitted++; }
         cv.notify_all();
@@ -171,6 +182,9 @@ struct c25519_amd_multi {
     std::condition_variable slot_cv;
     std::vector<hipEvent_t> gathered_ev;      // on devices[0]: piece c has arrived in `gathered`
     bool gather = true;                       // c25519_amd_multi_set_gather
+    bool virtual_devices = false;             // the list names a device more than once: no RCCL, device-to-device copies
+    std::vector<hipEvent_t> copy_ev;          // virtual devices: "worker d's rows of this piece are in `gathered`"
+    int copy_threads = 1;
     std::vector<void*> buf[MAX_ARR];          // per device: the shard's rows of gathered output array a (grow-only)
     std::vector<size_t> cap[MAX_ARR];
     void* gathered[MAX_ARR] = {};             // on devices[0]: D x (largest shard) rows of output array a
@@ -220,7 +234,7 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
     const int D = (int)m->dev.size();
     // C25519_AMD_MULTI_FORCE_GATHER=1: a one-device handle takes the gather path too (how the tests run the N > 1 code --
     // resident results, piece-wise grouped ncclGather, hand-over -- on a one-GPU box)
-    const bool gathers = m->gather && (D > 1 || getenv("C25519_AMD_MULTI_FORCE_GATHER") != nullptr);
+    const bool gathers = m->gather && (D > 1 || c25519_host::tunable_or(c25519_host::T_MULTI_FORCE_GATHER, 0) != 0);
     int prev = 0;
     C25519_TRY(hipGetDevice(&prev));
     std::vector<size_t> lo(D + 1);
@@ -238,6 +252,29 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
     std::vector<std::vector<hipEvent_t>> piece_ev(D, std::vector<hipEvent_t>(P, nullptr));
     bool any_failed = false;
 
+    // everything of the gather's set-up that can fail, BEFORE a worker gets a job: the jobs capture this frame's locals by
+    // reference, so from the first submit on no path may leave run_multi without waiting for the workers
+    bool pinned_out[MAX_ARR] = {};
+    auto gather_setup = [&]() -> int {
+        C25519_TRY(hipSetDevice(m->dev[0]));
+        while (m->gathered_ev.size() < P) {
+            hipEvent_t e = nullptr;
+            C25519_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            m->gathered_ev.push_back(e);
+        }
+        for (int a = 0; a < na; a++)
+            if (arr[a].out && arr[a].gather) {
+                C25519_RC(reserve(m->gathered[a], m->gcap[a], arr[a].elem * rows * D));
+                pinned_out[a] = c25519_host::host_pinned(arr[a].out, n * arr[a].elem);
+            }
+        return 0;
+    };
+    if (gathers) {
+        const int rc = gather_setup();
+        (void)hipSetDevice(prev);
+        if (rc) return rc;
+    }
+
     auto body = [&]() -> int {
         // 1. every device at once: its worker pipelines the shard (pinned staging, upload / kernel / download streams)
         //    and leaves the gathered outputs in buf[a][d]
@@ -252,6 +289,9 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
                         if (arr[a].out && arr[a].gather && gathers) {
                             C25519_RC(reserve(m->buf[a][d], m->cap[a][d], arr[a].elem * rows));
                             pa[a].dev = m->buf[a][d];
+                            // a short shard's pad rows travel through the gather and the pinned slots: zero, not what an
+                            // earlier call left there (nothing reads buf now: every call ends with the gather streams idle)
+                            if (cnt < rows) C25519_TRY(hipMemset((char*)m->buf[a][d] + cnt * arr[a].elem, 0, (rows - cnt) * arr[a].elem));
                         } else if (arr[a].out && arr[a].gather) {
                             // no gather (one device, or switched off): the rows leave through the worker's pipeline like any
                             // output (piece by piece, under the next piece's kernels, over this device's own link)
@@ -259,6 +299,8 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
                         }
                     }
                     if (!cnt) return 0;
+                    c25519_host::concurrent_pipelines() = D;              // D pipelines share this process' CPUs ...
+                    c25519_host::reserved_helper_threads() = m->copy_threads;   // ... with the root's copy-out threads
                     c25519_host::PieceHook hook;
                     hook.chunk = chunk;
                     if (gathers)
@@ -283,20 +325,6 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
             });
         }
         int rc = 0;
-        bool pinned_out[MAX_ARR] = {};
-        if (gathers) {
-            C25519_TRY(hipSetDevice(m->dev[0]));
-            while (m->gathered_ev.size() < P) {
-                hipEvent_t e = nullptr;
-                C25519_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                m->gathered_ev.push_back(e);
-            }
-            for (int a = 0; a < na && !rc; a++)
-                if (arr[a].out && arr[a].gather) {
-                    rc = reserve(m->gathered[a], m->gcap[a], arr[a].elem * rows * D);
-                    pinned_out[a] = c25519_host::host_pinned(arr[a].out, n * arr[a].elem);
-                }
-        }
         for (size_t c = 0; gathers && c < P && !rc; c++) {
             {   // every device has enqueued piece c: its event says when the rows are there
                 std::unique_lock<std::mutex> lk(mu);
@@ -308,19 +336,33 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
             //    Block d of piece c lands at gathered + elem * (D * r0 + d * cnt); a short shard sends pad rows.
             auto gather_piece = [&]() -> int {
                 for (int d = 0; d < D; d++)
-                    if (piece_ev[d][c]) C25519_TRY(hipStreamWaitEvent(m->stream[d], piece_ev[d][c], 0));
+                    if (piece_ev[d][c]) {
+                        C25519_TRY(hipSetDevice(m->dev[d]));
+                        C25519_TRY(hipStreamWaitEvent(m->stream[d], piece_ev[d][c], 0));
+                    }
                 for (int a = 0; a < na; a++) {
                     if (!arr[a].out || !arr[a].gather) continue;
+                    char* dst = (char*)m->gathered[a] + arr[a].elem * (size_t)D * r0;
+                    if (m->virtual_devices) {                          // one physical device: RCCL would refuse the duplicates
+                        for (int d = 0; d < D; d++)
+                            C25519_TRY(hipMemcpyAsync(dst + arr[a].elem * cnt * d, (char*)m->buf[a][d] + r0 * arr[a].elem,
+                                                      arr[a].elem * cnt, hipMemcpyDeviceToDevice, m->stream[d]));
+                        continue;
+                    }
                     NCCL_TRY(m, m->rccl.GroupStart());
                     for (int d = 0; d < D; d++) {
                         C25519_TRY(hipSetDevice(m->dev[d]));
-                        NCCL_TRY(m, m->rccl.Gather((char*)m->buf[a][d] + r0 * arr[a].elem,
-                                                    d == 0 ? (char*)m->gathered[a] + arr[a].elem * (size_t)D * r0 : nullptr,
+                        NCCL_TRY(m, m->rccl.Gather((char*)m->buf[a][d] + r0 * arr[a].elem, d == 0 ? dst : nullptr,
                                                     arr[a].elem * cnt, ncclUint8, 0, m->comm[d], m->stream[d]));
                     }
                     NCCL_TRY(m, m->rccl.GroupEnd());
                 }
                 C25519_TRY(hipSetDevice(m->dev[0]));
+                if (m->virtual_devices)                                // the root's stream is behind every worker's copies
+                    for (int d = 1; d < D; d++) {
+                        C25519_TRY(hipEventRecord(m->copy_ev[d], m->stream[d]));
+                        C25519_TRY(hipStreamWaitEvent(m->stream[0], m->copy_ev[d], 0));
+                    }
                 C25519_TRY(hipEventRecord(m->gathered_ev[c], m->stream[0]));
                 return 0;
             };
@@ -367,10 +409,12 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
                     const int r = fill();
                     if (r) { { std::lock_guard<std::mutex> lk(m->slot_mu); sl.busy = false; } m->slot_cv.notify_all(); return r; }
                     char* out = (char*)arr[a].out;
-                    m->copier->submit([&, k, out, elem, r0, cnt]() -> int {
+                    // (submit_always: behind a failed copy the remaining ones are skipped, but every one of them still hands
+                    // its slot back -- or the drain thread would wait for a free slot for ever, in this call and the next)
+                    m->copier->submit_always([&, k, out, elem, r0, cnt](bool skipped) -> int {
                         c25519_amd_multi::Slot& s2 = m->slot[k];
-                        const hipError_t e = hipEventSynchronize(s2.ev);
-                        if (e == hipSuccess) {
+                        const hipError_t e = hipEventSynchronize(s2.ev);   // also when skipped: the DMA into the slot must have ended
+                        if (e == hipSuccess && !skipped) {
                             // D blocks, each cut into parts: every copy thread takes its share of every block
                             const int parts = m->copy_pool->ok() ? m->copy_pool->size() : 1;
                             auto copy = [&](int part) {
@@ -387,7 +431,8 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
                         }
                         { std::lock_guard<std::mutex> lk(m->slot_mu); s2.busy = false; }
                         m->slot_cv.notify_all();
-                        return e == hipSuccess ? 0 : c25519_host::fail(e, "hipEventSynchronize(gathered piece)", __FILE__, __LINE__);
+                        if (e != hipSuccess) (void)hipGetLastError();
+                        return e == hipSuccess || skipped ? 0 : c25519_host::fail(e, "hipEventSynchronize(gathered piece)", __FILE__, __LINE__);
                     });
                 }
                 return 0;
@@ -426,31 +471,46 @@ int c25519_amd_multi_create(c25519_amd_multi** out, const int* devices, int n_de
     C25519_TRY(hipGetDeviceCount(&have));
     for (int d = 0; d < n_dev; d++)
         if (devices[d] < 0 || devices[d] >= have) return bad_arg("c25519_amd_multi_create: no such device");
+    // virtual devices: a list that names a device twice, or C25519_AMD_MULTI_VIRTUAL=V with a one-device list
+    std::vector<int> list(devices, devices + n_dev);
+    const long v = c25519_host::tunable_or(c25519_host::T_MULTI_VIRTUAL, 0);
+    if (n_dev == 1 && v > 1) list.assign((size_t)(v > 64 ? 64 : v), devices[0]);
+    n_dev = (int)list.size();
+    bool dup = false;
+    for (int d = 0; d < n_dev; d++)
+        for (int e = 0; e < d; e++) dup = dup || list[d] == list[e];
     c25519_amd_multi* m = new c25519_amd_multi();
     int prev = 0;
     (void)hipGetDevice(&prev);
     auto init = [&]() -> int {
-        C25519_RC(load_rccl(m->rccl));
-        m->dev.assign(devices, devices + n_dev);
+        m->virtual_devices = dup;
+        m->dev = list;
         m->stream.assign(n_dev, nullptr);
         m->comm.assign(n_dev, nullptr);
+        m->copy_ev.assign(n_dev, nullptr);
         for (int a = 0; a < MAX_ARR; a++) { m->buf[a].assign(n_dev, nullptr); m->cap[a].assign(n_dev, 0); }
         for (int d = 0; d < n_dev; d++) {
-            C25519_TRY(hipSetDevice(devices[d]));
+            C25519_TRY(hipSetDevice(list[d]));
             C25519_TRY(hipStreamCreateWithFlags(&m->stream[d], hipStreamNonBlocking));
+            if (dup) C25519_TRY(hipEventCreateWithFlags(&m->copy_ev[d], hipEventDisableTiming));
         }
-        NCCL_TRY(m, m->rccl.CommInitAll(m->comm.data(), n_dev, devices));
+        if (!dup) {                                       // (RCCL refuses a communicator with a duplicate device)
+            C25519_RC(load_rccl(m->rccl));
+            NCCL_TRY(m, m->rccl.CommInitAll(m->comm.data(), n_dev, list.data()));
+        }
         for (int d = 0; d < n_dev; d++) {
             m->worker.emplace_back(new Worker());
-            m->worker.back()->start(devices[d]);
+            m->worker.back()->start(list[d]);
         }
-        C25519_TRY(hipSetDevice(devices[0]));
+        C25519_TRY(hipSetDevice(list[0]));
         C25519_TRY(hipStreamCreateWithFlags(&m->drain_stream, hipStreamNonBlocking));
         m->drain.reset(new Worker());
-        m->drain->start(devices[0]);
+        m->drain->start(list[0]);
         m->copier.reset(new Worker());
-        m->copier->start(devices[0]);
-        m->copy_pool.reset(new c25519_host::HelperPool(std::thread::hardware_concurrency() >= 16 ? 4 : 2));
+        m->copier->start(list[0]);
+        // the root's copy-out threads come out of the same CPU budget as the devices' staging helpers (host_pipeline.hpp)
+        m->copy_threads = c25519_host::tunable_or(c25519_host::T_HELPER_THREADS, c25519_host::usable_cpus()) >= 16 + 2 * n_dev ? 4 : 2;
+        m->copy_pool.reset(new c25519_host::HelperPool(m->copy_threads));
         return 0;
     };
     int rc = 0;
@@ -473,6 +533,7 @@ void c25519_amd_multi_destroy(c25519_amd_multi* m)
     if (!m->dev.empty()) {
         (void)hipSetDevice(m->dev[0]);
         for (hipEvent_t e : m->gathered_ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : m->copy_ev) if (e) (void)hipEventDestroy(e);
         for (auto& sl : m->slot) {                                    // results passed through the pinned slots
             if (sl.pinned) { memset(sl.pinned, 0, sl.cap); (void)hipHostFree(sl.pinned); }
             if (sl.ev) (void)hipEventDestroy(sl.ev);
@@ -495,6 +556,15 @@ void c25519_amd_multi_destroy(c25519_amd_multi* m)
 }
 
 int c25519_amd_multi_device_count(const c25519_amd_multi* m) { return m ? (int)m->dev.size() : 0; }
+
+// threads of this handle that copy memory on the host while a call runs: every device pipeline's staging helpers plus the
+// root's copy-out threads (the D workers, the drain and the copier thread only enqueue and wait)
+int c25519_amd_multi_helper_threads(const c25519_amd_multi* m)
+{
+    if (!m) return 0;
+    const int D = (int)m->dev.size();
+    return D * c25519_host::pipeline_helpers(D, m->copy_threads).total() + m->copy_threads;
+}
 
 int c25519_amd_multi_set_gather(c25519_amd_multi* m, int on)
 {

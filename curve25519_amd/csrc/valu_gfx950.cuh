@@ -52,6 +52,11 @@ typedef uint64_t u64;
 #define C25519_VOP2_RUN_END() do { } while (0)
 #endif
 
+// Where the compiler emits v_mad_u64_u32 for a plain C expression (a 32x32+64 multiply-add outside the asm chains): a
+// no-op here; the CPU model of these primitives counts n instructions (tests/host_emul/valu_model.h, tools/executed_macs.py),
+// so that the model's count of a ladder step equals the ISA's (739: 5 x 100 + 4 x 55 in chains, + 9 + 10 of these).
+#define C25519_COUNT_MAD(n) ((void)0)
+
 // 2x as v_add_u32 x, x: v_add_u32 is full-rate, while v_lshlrev_b32 -- what the compiler picks for x*2 or x+x --
 // is in the half-rate class.
 C25519_DEV u32 dbl32(u32 x)

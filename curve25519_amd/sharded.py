@@ -166,10 +166,9 @@ def ed25519_verify_sharded(engine, sig_local, pk_local, msg_local, root: int = 0
 
 # ---- BASELINE.json configs[4]: a mixed X25519 + Ed25519 batch sharded over the ranks -----------------------
 def mixed_thirds(n: int) -> Tuple[Tuple[int, int], Tuple[int, int], Tuple[int, int]]:
-    """Element i of a mixed batch is X25519 / sign / verify by contiguous thirds (the split SURVEY.md 8(d)
-    allows; stated here so fixtures and ranks agree): [0, a) X25519, [a, b) sign, [b, n) verify."""
-    a, b = n // 3, 2 * (n // 3)
-    return (0, a), (a, b), (b, n)
+    """[0, a) X25519, [a, b) sign, [b, n) verify -- synth.mixed_thirds (one definition for fixtures and ranks)."""
+    from .synth import mixed_thirds as _thirds
+    return _thirds(n)
 
 
 def mixed_sharded(engine, x_pk, x_sk, s_priv, s_msg, v_sig, v_pk, v_msg, root: int = 0, group=None):

@@ -29,14 +29,30 @@ def random_bytes(shape, seed: int) -> np.ndarray:
     return z.astype("<u8").view(np.uint8)[:n].reshape(shape).copy()
 
 
-def x25519_inputs(n: int):
+RANK_SEED_STRIDE = 0x100     # bench.py: rank r of a world > 1 draws its own 2^20 elements from seed + 0x100 * r
+
+
+def rank_seed_shift(rank: int, world: int) -> int:
+    """The seed offset of rank `rank`'s inputs (weak scaling: every rank owns its own batch).  A world of one is rank 0
+    of any world: the committed digests of tests/golden/digests.json["ranks"][r] belong to shift 0x100 * r."""
+    return RANK_SEED_STRIDE * rank if world > 1 else 0
+
+
+def x25519_inputs(n: int, seed_shift: int = 0):
     """(sk, pk): n x 32 uniform bytes each.  pk bit 255 is deliberately NOT masked."""
-    return random_bytes((n, 32), SEED_X25519_SK), random_bytes((n, 32), SEED_X25519_PK)
+    return random_bytes((n, 32), SEED_X25519_SK + seed_shift), random_bytes((n, 32), SEED_X25519_PK + seed_shift)
 
 
-def ed25519_inputs(n: int, msg_size: int = 32):
+def ed25519_inputs(n: int, msg_size: int = 32, seed_shift: int = 0):
     """(sk32, msg): secret seeds and fixed-length messages."""
-    return random_bytes((n, 32), SEED_ED_SK), random_bytes((n, msg_size), SEED_ED_MSG)
+    return random_bytes((n, 32), SEED_ED_SK + seed_shift), random_bytes((n, msg_size), SEED_ED_MSG + seed_shift)
+
+
+def mixed_thirds(n: int):
+    """Element i of a mixed batch (BASELINE.json configs[4]) is X25519 / sign / verify by contiguous thirds (the split
+    SURVEY.md 8(d) allows; stated here so fixtures and ranks agree): [0, a) X25519, [a, b) sign, [b, n) verify."""
+    a, b = n // 3, 2 * (n // 3)
+    return (0, a), (a, b), (b, n)
 
 
 def corrupt_for_verify(sig: np.ndarray, msg: np.ndarray):

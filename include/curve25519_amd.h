@@ -34,6 +34,17 @@ const char *c25519_amd_version(void);
 const char *c25519_amd_last_error(void);               /* per-thread, "" when none */
 int  c25519_amd_device_count(void);                    /* usable HIP devices (0 when none) */
 int  c25519_amd_set_device(int device);                /* device used by this host thread */
+/* Tuning / A-B knobs.  Each knob is read ONCE from the environment variable C25519_AMD_<name> when the library is first
+ * used (no getenv() on any call path afterwards) and can be changed at run time here; value < 0 restores the built-in
+ * choice.  Names: COOP_MAX (largest batch that runs one operation per wave; 0 = never), XF_SPLIT (X25519 as two launches 1 /
+ * one fused launch 0), INV_K (elements per inverting lane, 1..16), VERIFY_REFERENCE_ORDER (1: every verification in the
+ * reference's 4-fold + 8-fold order), MULTI_FORCE_GATHER (1: a one-device *_multi handle gathers too), MULTI_VIRTUAL (V: a
+ * one-device list given to c25519_amd_multi_create becomes V virtual devices on it), BASE_COMB (fixed-base walks: 0 = LDS comb,
+ * 1 = wide comb read through L2), HELPER_THREADS (cap on the staging helper threads; default: the CPUs this process may use).
+ * _get returns -1 for "built-in choice", -2 for an unknown name. */
+int  c25519_amd_tunable_set(const char *name, long value);
+long c25519_amd_tunable_get(const char *name);
+int  c25519_amd_usable_cpus(void);                     /* CPUs this process may use (affinity mask cut to the cgroup quota) */
 /* *_dev calls a thread issues on different streams may overlap on the device: each stream gets its own work scratch (up
  * to four per device; a further stream reuses the least recently used one after waiting for it).  Splitting a mixed batch
  * over streams is worth ~13 % (one operation's last round of workgroups fills up with the next operation's).
@@ -162,6 +173,7 @@ typedef struct c25519_amd_multi c25519_amd_multi;
 int  c25519_amd_multi_create(c25519_amd_multi **m, const int *devices, int n_dev);
 void c25519_amd_multi_destroy(c25519_amd_multi *m);
 int  c25519_amd_multi_device_count(const c25519_amd_multi *m);
+int  c25519_amd_multi_helper_threads(const c25519_amd_multi *m);  /* host threads that copy memory while a call runs */
 int  c25519_amd_multi_set_gather(c25519_amd_multi *m, int on);   /* 1 (default): gather to devices[0]; 0: per-device downloads */
 int curve25519_dh_CreateSharedKey_multi(c25519_amd_multi *m, unsigned char *shared, const unsigned char *pk,
                                         unsigned char *sk, size_t n);

@@ -6,6 +6,7 @@ are data (inputs + the reference's outputs), never reference source.
     python tests/golden/gen_golden.py            # kat.json, random_1024.npz, digests.json
     python tests/golden/gen_golden.py --no-big   # skip the 2^20 digests (minutes of CPU)
     python tests/golden/gen_golden.py --degenerate-only   # only degenerate_verify.npz (seconds)
+    python tests/golden/gen_golden.py --ranks-only        # only digests.json["ranks"]: bench.py's ranks 0..7 at 2^20
 
 Known-answer inputs come from RFC 7748 5.2, RFC 8032 7.1 and from the reference's own tests
 (test/curve25519_test.c:412-445, test/openssl_test.c:20,97,138); the expected outputs are whatever the
@@ -170,17 +171,17 @@ def kat(ref):
 # ---- seeded batches: digests of the reference's outputs -----------------------------------------------
 
 def _chunk_x(args):
-    lo, hi, n = args
+    lo, hi, n, shift = args
     ref = Reference()
-    sk, pk = synth.x25519_inputs(n)
+    sk, pk = synth.x25519_inputs(n, seed_shift=shift)
     out, cl = ref.x25519_shared(pk[lo:hi], sk[lo:hi])
     return out, cl
 
 
 def _chunk_ed(args):
-    lo, hi, n = args
+    lo, hi, n, shift = args
     ref = Reference()
-    sk, msg = synth.ed25519_inputs(n)
+    sk, msg = synth.ed25519_inputs(n, seed_shift=shift)
     pub, priv = ref.ed25519_keypair(sk[lo:hi])
     sig = ref.ed25519_sign(priv, msg[lo:hi])
     return pub, priv, sig
@@ -192,8 +193,10 @@ def _chunk_v(args):
     return ref.ed25519_verify(sig, pub, msg)
 
 
-def seeded(n, pool, chunks=64):
-    bounds = [(n * i // chunks, n * (i + 1) // chunks, n) for i in range(chunks)]
+def seeded(n, pool, chunks=64, seed_shift=0):
+    """Digests (and the arrays) of the reference's outputs on the seeded batch of n; seed_shift = the rank offset of
+    bench.py's weak-scaling inputs (synth.rank_seed_shift)."""
+    bounds = [(n * i // chunks, n * (i + 1) // chunks, n, seed_shift) for i in range(chunks)]
     xs = pool.map(_chunk_x, bounds)
     shared = np.concatenate([a for a, _ in xs])
     clamped = np.concatenate([b for _, b in xs])
@@ -201,15 +204,48 @@ def seeded(n, pool, chunks=64):
     pub = np.concatenate([a for a, _, _ in eds])
     priv = np.concatenate([b for _, b, _ in eds])
     sig = np.concatenate([c for _, _, c in eds])
-    _, msg = synth.ed25519_inputs(n)
+    _, msg = synth.ed25519_inputs(n, seed_shift=seed_shift)
     bsig, bmsg, bad = synth.corrupt_for_verify(sig, msg)
-    ok = np.concatenate(pool.map(_chunk_v, [(lo, hi, bsig[lo:hi], pub[lo:hi], bmsg[lo:hi]) for lo, hi, _ in bounds]))
+    ok = np.concatenate(pool.map(_chunk_v, [(lo, hi, bsig[lo:hi], pub[lo:hi], bmsg[lo:hi]) for lo, hi, _, _ in bounds]))
     assert np.array_equal(ok == 0, bad), "corrupted entries must be exactly the rejected ones"
     d = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
     return {"n": n, "x25519_shared": d(shared), "x25519_sk_clamped": d(clamped), "ed25519_pub": d(pub),
             "ed25519_priv": d(priv), "ed25519_sig": d(sig), "ed25519_verdicts": d(ok.astype("<i4")),
             "verify_rejected": int(bad.sum())}, dict(shared=shared, clamped=clamped, pub=pub, priv=priv, sig=sig,
                                                      bsig=bsig, bmsg=bmsg, ok=ok.astype(np.int32))
+
+
+PREFIXES = (1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20)
+
+
+def rank_digests(n, world, pool):
+    """digests.json["ranks"]: what bench.py's rank r (its own n elements from seed + 0x100 * r) must produce -- every
+    pass's output buffer, and the three slices of the mixed workload (BASELINE.json configs[4]: contiguous thirds) --
+    so that a bench line on any number of GPUs attests bit-exactness of what it timed.  The seeded streams are
+    positional (element i's bytes do not depend on n), so the outputs of a batch of m < n are the first m rows of the
+    batch of n: "prefix" holds the digests of the power-of-two batches bench.py's tests run at."""
+    d = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    by_rank = []
+    for r in range(world):
+        shift = synth.RANK_SEED_STRIDE * r
+        rec, full = seeded(n, pool, chunks=256, seed_shift=shift)
+        rec["rank"], rec["seed_shift"] = r, shift
+        rec["prefix"] = {}
+        for m in PREFIXES:
+            if m > n:
+                continue
+            (x0, x1), (s0, s1), (v0, v1) = synth.mixed_thirds(m)
+            ok = full["ok"][:m].astype("<i4")
+            rec["prefix"][str(m)] = {
+                "x25519_shared": d(full["shared"][:m]), "x25519_sk_clamped": d(full["clamped"][:m]),
+                "ed25519_pub": d(full["pub"][:m]), "ed25519_priv": d(full["priv"][:m]), "ed25519_sig": d(full["sig"][:m]),
+                "ed25519_verdicts": d(ok), "verify_rejected": int((ok == 0).sum()),
+                "mixed_thirds": {"x25519_shared": d(full["shared"][x0:x1]), "ed25519_sig": d(full["sig"][s0:s1]),
+                                 "ed25519_verdicts": d(ok[v0:v1]), "verify_rejected": int((ok[v0:v1] == 0).sum())}}
+        assert all(rec["prefix"][str(n)][k] == rec[k] for k in ("x25519_shared", "ed25519_sig", "ed25519_verdicts"))
+        by_rank.append(rec)
+        print(f"rank {r}: {rec['x25519_shared'][:16]}.. rejected {rec['verify_rejected']}", flush=True)
+    return {"n": n, "seed_stride": synth.RANK_SEED_STRIDE, "prefixes": [m for m in PREFIXES if m <= n], "by_rank": by_rank}
 
 
 def degenerate(ref):
@@ -230,6 +266,17 @@ def degenerate(ref):
 def main():
     assert Reference.available(), "build oracle/_ref first: make -C oracle ref"
     ref = Reference()
+    if "--ranks-only" in sys.argv:           # only digests.json["ranks"] (8 x 2^20 through the reference: ~10 min on 8 cores)
+        path = os.path.join(HERE, "digests.json")
+        with open(path) as f:
+            dig = json.load(f)
+        with mp.Pool(os.cpu_count()) as pool:
+            dig["ranks"] = rank_digests(1 << 20, 8, pool)
+        assert all(dig["ranks"]["by_rank"][0][k] == v for k, v in dig[str(1 << 20)].items()), "rank 0 = the world-1 batch"
+        with open(path, "w") as f:
+            json.dump(dig, f, indent=1)
+        print("wrote digests.json[ranks]")
+        return
     degenerate(ref)
     if "--degenerate-only" in sys.argv:
         return
@@ -249,7 +296,9 @@ def main():
         dig["1024"] = d1024
         dig["4096"], _ = seeded(4096, pool)
         if "--no-big" not in sys.argv:
-            dig[str(1 << 20)], _ = seeded(1 << 20, pool, chunks=256)
+            dig["ranks"] = rank_digests(1 << 20, 8, pool)
+            dig[str(1 << 20)] = {k: v for k, v in dig["ranks"]["by_rank"][0].items()
+                                 if k not in ("rank", "seed_shift", "prefix")}
         with open(os.path.join(HERE, "digests.json"), "w") as f:
             json.dump(dig, f, indent=1)
         print("wrote digests.json")

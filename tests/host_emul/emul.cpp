@@ -13,7 +13,7 @@
 
 using namespace c25519;
 
-namespace c25519 { unsigned long long emul_mad_overflows = 0; LatCounters emul_lat_counters = { 0, 0, 0 }; }
+namespace c25519 { unsigned long long emul_mad_overflows = 0, emul_mad_count = 0; LatCounters emul_lat_counters = { 0, 0, 0 }; }
 thread_local EmulWave* emul_wave = nullptr;
 
 namespace {
@@ -74,11 +74,93 @@ void affine_pack_host(u32 (&enc)[8], const ge_ext& S)
     ge_pack(enc, xw, yw);
 }
 
+// ---- the wide fixed-base comb (ge25519.cuh: WB_*): the same packed tables k_gen_wide_table writes, built here with one
+// addition per row (Gray-code order: consecutive rows differ in one tooth, S +- 2 * 2^(20 j + extra) B) and ONE shared
+// inversion per table instead of 250 doublings and an inversion per row; spot-checked against ge_signed_comb_row, the
+// function the device generates its rows with, by emul_wide_row_check (tests/test_host_emul.py).
+std::vector<u32> g_wide;
+std::once_flag g_wide_once;
+int g_base_comb = 0;                    // emul_set_base_comb: 1 = the fixed-base operations below walk the wide comb
+
+void build_wide()
+{
+    g_wide.assign(WB_TBL_WORDS, 0);
+    for (int table = 0; table < WB_NT; table++) {
+        const int extra = (WB_NT - 1 - table) * WB_STEP;
+        // P[j] = 2^(20 j + extra) B, j = 0 .. 12
+        ge_ext P[WB_TEETH];
+        {
+            u32 rows[3][8];
+            ge_base_table_row(rows, 1, 0);                           // B as (y+x, y-x, 2dxy)
+            ge_pa b;
+            fe_from_words(b.ypx, rows[0]); fe_from_words(b.ymx, rows[1]); fe_from_words(b.t2d, rows[2]);
+            ge_from_pa(P[0], b);
+            for (int j = 0; j < extra; j++) ge_double(P[0]);
+            for (int j = 1; j < WB_TEETH; j++) {
+                P[j] = P[j - 1];
+                for (int d = 0; d < WB_COLS; d++) ge_double(P[j]);
+            }
+        }
+        ge_pe plus2[WB_TEETH - 1], minus2[WB_TEETH - 1], minus1[WB_TEETH - 1];
+        for (int j = 0; j < WB_TEETH - 1; j++) {
+            ge_ext D = P[j];
+            ge_double(D);
+            ge_to_pe(plus2[j], D);
+            minus2[j] = plus2[j];
+            std::swap(minus2[j].ypx, minus2[j].ymx);
+            { fe t; fe_neg(t, plus2[j].t2d); fe_carry32(minus2[j].t2d, t); }
+            ge_to_pe(minus1[j], P[j]);
+            std::swap(minus1[j].ypx, minus1[j].ymx);
+            { fe t; fe_neg(t, minus1[j].t2d); fe_carry32(minus1[j].t2d, t); }
+        }
+        std::vector<ge_ext> pts(WB_ROWS);
+        ge_ext S = P[WB_TEETH - 1];                                   // row 0: the top tooth plus, every other tooth minus
+        for (int j = 0; j < WB_TEETH - 1; j++) { ge_ext R; ge_add_pe(R, S, minus1[j]); S = R; }
+        u32 gray = 0;
+        pts[0] = S;
+        for (u32 i = 1; i < (u32)WB_ROWS; i++) {
+            const u32 g = i ^ (i >> 1), flip = g ^ gray;
+            const int j = __builtin_ctz(flip);
+            ge_ext R;
+            ge_add_pe(R, S, (g & flip) ? plus2[j] : minus2[j]);
+            S = R; gray = g;
+            pts[g] = S;
+        }
+        // one inversion for the table (Montgomery's trick over Z)
+        std::vector<fe> pre(WB_ROWS);
+        fe acc = pts[0].Z;
+        for (int i = 1; i < WB_ROWS; i++) { pre[i] = acc; fe_mul(acc, acc, pts[i].Z); }
+        fe inv;
+        fe_invert(inv, acc);
+        for (int i = WB_ROWS - 1; i >= 0; i--) {
+            fe zi;
+            if (i) { fe_mul(zi, inv, pre[i]); fe_mul(inv, inv, pts[i].Z); } else zi = inv;
+            fe x, y, t, row[3];
+            fe_mul(x, pts[i].X, zi);
+            fe_mul(y, pts[i].Y, zi);
+            fe_add(row[0], y, x);
+            fe_sub(row[1], y, x);
+            fe_mul(t, x, y);
+            fe_mul(row[2], t, fe_const(K_2D));
+            u32* out = g_wide.data() + ((size_t)table * WB_ROWS + i) * WB_ROW_WORDS;
+            for (int f = 0; f < 3; f++) { u32 w[8]; fe_to_words(w, row[f]); memcpy(out + 8 * f, w, 32); }
+        }
+    }
+}
+
+const u32* wide_tables()
+{
+    std::call_once(g_wide_once, build_wide);
+    return g_wide.data();
+}
+
 }  // namespace
 
 extern "C" {
 
 unsigned long long emul_mad_overflow_count(void) { return emul_mad_overflows; }
+// v_mad_u64_u32 instructions issued since the last call (valu_model.h: mad64)
+unsigned long long emul_mad_count_take(void) { return __atomic_exchange_n(&emul_mad_count, 0ULL, __ATOMIC_RELAXED); }
 
 void emul_fe_op(unsigned char* out, const unsigned char* a, const unsigned char* b, size_t n, int op)
 {
@@ -134,16 +216,34 @@ void emul_x25519(unsigned char* out, const unsigned char* pk, unsigned char* sk,
     }
 }
 
+static void base_mult_any(ge_ext& S, const u32 (&k)[8], const unsigned char* blinding);
+
+// 0: the fixed-base operations walk the 8 x 32 comb (the LDS tables), 1: the wide 13 x 20 comb (tunable BASE_COMB)
+void emul_set_base_comb(int wide) { g_base_comb = wide; }
+
+// rows `idx[i]` of wide table `table` as the device generates them (ge_signed_comb_row) against the table built here:
+// number of differing rows
+int emul_wide_row_check(int table, const unsigned* idx, size_t n)
+{
+    int bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        u32 rows[3][8];
+        ge_signed_comb_row(rows, idx[i] % WB_ROWS, (WB_NT - 1 - table) * WB_STEP, WB_TEETH, WB_COLS);
+        const u32* have = wide_tables() + ((size_t)table * WB_ROWS + idx[i] % WB_ROWS) * WB_ROW_WORDS;
+        if (memcmp(rows, have, 96) != 0) bad++;
+    }
+    return bad;
+}
+
 void emul_x25519_public_fast(unsigned char* pk, unsigned char* sk, size_t n)
 {
-    const u32* tbl = tables();
     for (size_t i = 0; i < n; i++) {
         u32 k[8], w[8];
         rd32(k, sk, i);
         clamp_words(k);
         wr32(sk, i, k);
         ge_ext S;
-        ge_base_mult(S, k, tbl);
+        base_mult_any(S, k, nullptr);
         fe num, den, t;
         fe_add(t, S.Z, S.Y);  fe_carry32(num, t);
         fe_sub(t, S.Z, S.Y);  fe_carry32(den, t);
@@ -161,8 +261,26 @@ void emul_blinding_init(unsigned char* ctx /* 192 */, const unsigned char* seed,
     memcpy(ctx, w, sizeof w);
 }
 
+static void base_mult_wide(ge_ext& S, const u32 (&k)[8], const fe* zr, bool final_t)
+{
+    unsigned short cols[WB_COLS];
+    wb_columns(cols, 1, k);
+    if (final_t) ge_base_mult_wide<true>(S, wide_tables(), cols, 1, zr);
+    else ge_base_mult_wide<false>(S, wide_tables(), cols, 1, zr);
+}
+
 static void base_mult_any(ge_ext& S, const u32 (&k)[8], const unsigned char* blinding)
 {
+    if (g_base_comb == 1) {
+        if (blinding) {
+            u32 w[BLIND_WORDS];
+            memcpy(w, blinding, sizeof w);
+            ge_base_mult_blinded_with(S, k, w, [&](ge_ext& P, const u32 (&t)[8], const fe& zr) { base_mult_wide(P, t, &zr, true); });
+        } else {
+            base_mult_wide(S, k, nullptr, false);
+        }
+        return;
+    }
     if (blinding) {
         u32 w[BLIND_WORDS];
         memcpy(w, blinding, sizeof w);
@@ -252,8 +370,18 @@ void emul_ed25519_verify_slow(int* verdict, unsigned char* point, const unsigned
 
 // the lattice fast path (verify_fast.cuh), one element at a time: verdicts (meaningful where need_slow[i] == 0) and the
 // need_slow flags
+void emul_ed25519_verify_fast_at(int* verdict, int* need_slow, const unsigned char* sig, const unsigned char* pk,
+                                 const unsigned char* msg, size_t len, size_t n, int wave_top);
 void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char* sig, const unsigned char* pk,
                               const unsigned char* msg, size_t len, size_t n)
+{
+    emul_ed25519_verify_fast_at(verdict, need_slow, sig, pk, msg, len, n, 0);
+}
+
+// ... wave_top: the walk starts at max(the element's own first digit, wave_top) -- on the device a wave walks from its
+// LONGEST element's first digit (k_ed25519_verify_fast_walk), the others' digits above their own being zero
+void emul_ed25519_verify_fast_at(int* verdict, int* need_slow, const unsigned char* sig, const unsigned char* pk,
+                                 const unsigned char* msg, size_t len, size_t n, int wave_top)
 {
     const u32* tbl = tables() + (size_t)SC_TBL_OFFSET;
     std::vector<u32> q(2 * WTABLE_WORDS);
@@ -274,7 +402,8 @@ void emul_ed25519_verify_fast(int* verdict, int* need_slow, const unsigned char*
         if (need_slow[i]) continue;                                   // the walk's lanes skip listed elements
         wtable_build(tq, QX, QY);
         wtable_build(tr, RX, RY);
-        const int top = walk_top_digit(tau, rho);                    // a "wave" of one lane: every start digit gets exercised
+        int top = walk_top_digit(tau, rho);                          // a "wave" of one lane: every start digit gets exercised
+        if (top < wave_top) top = wave_top;
         const WalkScalars sc{ cols, tau, rho, 1, 0 };
         const u32 neutral = ge_walk_is_neutral(sc, tq, tr, tbl, top < 8 ? 8 : top);
         verdict[i] = (r_ok && neutral) ? 1 : 0;

@@ -76,8 +76,14 @@ inline u32 alignbit32(u32 hi, u32 lo, int s) { return (u32)((((u64)hi << 32) | l
 // because the field layer's bound contract says it can never happen (tools/fe_bounds.py proves it; this checks it
 // on the values that actually flow through the tests).
 extern unsigned long long emul_mad_overflows;
+// ... and COUNTS the instruction: every v_mad_u64_u32 the device source issues goes through here, so a run of one
+// operation on the model is a count of the MADs the kernels execute for it (tools/executed_macs.py -> bench.py's
+// roofline.valu.executed_macs_per_op)
+extern unsigned long long emul_mad_count;
+#define C25519_COUNT_MAD(n) __atomic_fetch_add(&::c25519::emul_mad_count, (unsigned long long)(n), __ATOMIC_RELAXED)
 inline u64 mad64(u64 acc, u32 x, u32 y)
 {
+    __atomic_fetch_add(&emul_mad_count, 1ULL, __ATOMIC_RELAXED);
     const u64 p = (u64)x * y;
     const u64 r = acc + p;
     if (r < acc) emul_mad_overflows++;

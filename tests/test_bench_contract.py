@@ -50,3 +50,52 @@ def test_roofline_object_from_the_committed_measurements():
     with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as f:
         assert json.load(f)
     assert r["traffic"] is None or 2e8 < r["traffic"] < 4e8
+    # the roof that binds is named at the top level, beside the contract's HBM fields
+    assert r["binding"] == "valu" and r["binding_frac"] == v["frac"] and "two launches" in r["note"]
+    assert r["traffic"] is None or abs(r["traffic_over_algorithmic"] - r["traffic"] / (96 * n)) < 0.01
+
+
+def test_executed_macs_are_counted_from_the_device_source():
+    """roofline.valu.executed_macs_per_op comes from profiles/rNN_executed_macs.json, which tools/executed_macs.py writes by
+    running the device source on the C model of the gfx950 primitives and counting v_mad_u64_u32: a fresh count equals
+    the committed file for all three passes, the ladder's count agrees with the ISA's 739 MADs per step
+    (profiles/r04_isa_mix.txt, tools/cycle_probe.py), and bench.py uses the file."""
+    bench = load(os.path.join(ROOT, "bench.py"), "c25519_bench_macs")
+    em = load(os.path.join(ROOT, "tools", "executed_macs.py"), "c25519_executed_macs")
+    cp = load(os.path.join(ROOT, "tools", "cycle_probe.py"), "c25519_cycle_probe_macs")
+    fresh = em.count(sample=16)
+    used, src = bench.executed_macs()
+    assert src and src.endswith("_executed_macs.json")
+    with open(os.path.join(ROOT, "profiles", src)) as f:
+        committed = json.load(f)
+    for k in ("x25519", "sign", "verify"):
+        assert used[k] == committed["per_op"][k]
+        assert abs(fresh["per_op"][k] - committed["per_op"][k]) <= 0.005 * committed["per_op"][k], (k, fresh["per_op"], committed["per_op"])
+    d = fresh["detail"]
+    assert (d["fe_mul"], d["fe_sq"]) == (101.0, 56.0)                 # 100 / 55 in the asm chains + the x19 fold
+    assert abs(d["x25519_ladder"] / cp.STEPS - cp.STEP_MAD) < 0.005 * cp.STEP_MAD
+    # executed <= the reference's algorithmic count for the re-designed passes, a few per cent above it for the ladder
+    assert 1.0 < used["x25519"] / bench.MACS_PER_OP["x25519"] < 1.05
+    assert used["sign"] < 0.5 * bench.MACS_PER_OP["sign"] and used["verify"] < 0.8 * bench.MACS_PER_OP["verify"]
+
+
+def test_expected_digests_cover_every_rank_of_the_scaling_run():
+    """bench.py attests bit-exactness per rank from tests/golden/digests.json["ranks"] (the reference's outputs for each
+    rank's seeded inputs): ranks 0..7 at 2^20 and the power-of-two prefixes its tests run at; rank 0 of any world and the
+    lone rank of a world of one share the unshifted seed, i.e. the digests the parity tests already pin."""
+    bench = load(os.path.join(ROOT, "bench.py"), "c25519_bench_digests")
+    with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+        dig = json.load(f)
+    n = 1 << 20
+    seen = set()
+    for r in range(8):
+        e = bench.expected_digests(r, 8, n)
+        assert e and len(e["x25519_shared"]) == 64 and set(e["mixed_thirds"]) >= {"x25519_shared", "ed25519_sig", "ed25519_verdicts"}
+        seen.add(e["x25519_shared"])
+        for m in (1 << 14, 1 << 16):
+            assert bench.expected_digests(r, 8, m)
+    assert len(seen) == 8                                              # every rank has inputs of its own
+    assert bench.expected_digests(0, 1, n) == bench.expected_digests(0, 8, n)
+    for k, v in dig[str(n)].items():
+        assert bench.expected_digests(0, 1, n)[k] == v
+    assert bench.expected_digests(0, 1, 12345) is None and bench.expected_digests(9, 16, n) is None

@@ -205,3 +205,44 @@ def test_blinding_is_real_and_output_neutral(dev, emul):
             assert np.array_equal(bpub, pub) and np.array_equal(bpriv, priv)
             assert np.array_equal(dev.sign(priv, msg, blinding=ctx2), sig)
     assert len(seen) == 4
+
+
+def test_wide_fixed_base_comb(dev, emul):
+    """The wide fixed-base comb (ge25519.cuh WB_*: 13 signed teeth 20 bits apart, four tables of 4096 packed rows read through
+    L2 on the device, tunable BASE_COMB = 1): table rows as the device generates them (ge_signed_comb_row) against the table
+    the model builds with one addition per row; then every fixed-base operation over it -- key pairs, signatures, X25519
+    public keys, with and without a blinding context, the RFC 8032 vectors and the extreme scalars included -- gives the
+    bytes of the 8 x 32 LDS comb, i.e. the reference's (edp_BasePointMultiply, ed25519_sign.c:246-268)."""
+    emul.emul_wide_row_check.argtypes = [C.c_int, vp, sz]
+    emul.emul_wide_row_check.restype = C.c_int
+    idx = np.array([0, 1, 2, 4095, 4094, 2048, 2047, 1365, 2730, 777], np.uint32)
+    for table in range(4):
+        assert emul.emul_wide_row_check(table, ptr(idx), len(idx)) == 0, table
+    g, m = R1024, 160
+    emul.emul_set_base_comb(1)
+    try:
+        pub, priv = dev.keypair(g["ed_sk"][:m])
+        assert np.array_equal(pub, g["ed_pub"][:m]) and np.array_equal(priv, g["ed_priv"][:m])
+        assert np.array_equal(dev.sign(priv, g["ed_msg"][:m]), g["ed_sig"][:m])
+        for r in KAT["ed25519"]:
+            msg = np.frombuffer(bytes.fromhex(r["msg"]), np.uint8).reshape(1, -1)
+            pub, priv = dev.keypair(h2a(r["sk"]))
+            assert pub.tobytes().hex() == r["pk"] and dev.sign(priv, msg).tobytes().hex() == r["sig"], r["name"]
+        recs = KAT["x25519_public"]
+        sk = np.concatenate([h2a(r["sk"]) for r in recs] + [np.zeros((1, 32), np.uint8), np.full((1, 32), 0xff, np.uint8)])
+        pk, clamped = dev.public_fast(sk)
+        ref_pk, ref_clamped = dev.x25519(None, sk)                     # the ladder on u = 9
+        assert np.array_equal(pk, ref_pk) and np.array_equal(clamped, ref_clamped)
+        for i, r in enumerate(recs):
+            assert pk[i].tobytes().hex() == r["pk"], r["name"]
+        # blinded: (k + bl) * B + BP over the wide comb, T of the walk's result feeding the last addition
+        ctx = np.empty(192, np.uint8)
+        seed = np.frombuffer(b"wide comb", np.uint8).copy()
+        emul.emul_set_base_comb(0)
+        emul.emul_blinding_init(ptr(ctx), ptr(seed), len(seed))
+        emul.emul_set_base_comb(1)
+        bpub, bpriv = dev.keypair(g["ed_sk"][:48], blinding=ctx)
+        assert np.array_equal(bpub, g["ed_pub"][:48]) and np.array_equal(bpriv, g["ed_priv"][:48])
+        assert np.array_equal(dev.sign(g["ed_priv"][:48], g["ed_msg"][:48], blinding=ctx), g["ed_sig"][:48])
+    finally:
+        emul.emul_set_base_comb(0)

@@ -3,8 +3,9 @@
 
     python tools/ab_bench.py build_a.so build_b.so lib.so@KEY=VAL,KEY2=VAL2 ...   [--ops x25519,sign,verify,keypair] [--rounds 5]
 
-`lib.so@KEY=VAL` times a library under run-time knobs the engine reads per call (C25519_AMD_INV_K, ...): the
-environment is switched right before that variant's launches.
+`lib.so@KEY=VAL` times a library under run-time knobs (the library's tunables, include/curve25519_amd.h:
+c25519_amd_tunable_set -- INV_K, XF_SPLIT, BASE_COMB, ...; a C25519_AMD_ prefix is accepted and dropped): the knobs are
+set in that library's own table right before its launches.
 
 Each library is dlopen'ed privately; every round runs each (library, op) once at N = 2^20 with inputs
 resident in HBM and reports min / median kernel time from HIP events on torch's current stream."""
@@ -44,10 +45,19 @@ for spec in args.libs:
 KNOBS = sorted({k for e in envs.values() for k in e})
 
 
+LIB_OF = dict(libs)
+
+
 def set_env(name):
+    L = LIB_OF[name]
+    if not hasattr(L, "c25519_amd_tunable_set"):
+        assert not envs[name], f"{name}: this build has no tunable table"
+        return
+    L.c25519_amd_tunable_set.argtypes = [C.c_char_p, C.c_long]
     for k in KNOBS:
-        os.environ.pop(k, None)
-    os.environ.update(envs[name])
+        L.c25519_amd_tunable_set(k.replace("C25519_AMD_", "").encode(), -1)
+    for k, v in envs[name].items():
+        assert L.c25519_amd_tunable_set(k.replace("C25519_AMD_", "").encode(), int(v)) == 0, (name, k)
 
 
 sk_np, pk_np = synth.x25519_inputs(n)

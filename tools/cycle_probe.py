@@ -67,8 +67,8 @@ def measure(lib_path, n=1 << 20, fused=False, reps=6, verbose=False):
     buf = torch.zeros(((n + 63) // 64, WORDS), dtype=torch.int64, device=dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    saved = os.environ.get("C25519_AMD_XF_SPLIT")
-    os.environ["C25519_AMD_XF_SPLIT"] = "0" if fused else "1"
+    L.c25519_amd_tunable_set.argtypes = [C.c_char_p, C.c_long]
+    assert L.c25519_amd_tunable_set(b"XF_SPLIT", 0 if fused else 1) == 0          # the probe library's own knob table
     try:
         assert L.c25519_amd_probe_set(p(buf)) == 0
         best = None
@@ -86,10 +86,7 @@ def measure(lib_path, n=1 << 20, fused=False, reps=6, verbose=False):
                 print(f"  run {r}: {ms:.3f} ms")
         L.c25519_amd_probe_set(None)
     finally:
-        if saved is None:
-            os.environ.pop("C25519_AMD_XF_SPLIT", None)
-        else:
-            os.environ["C25519_AMD_XF_SPLIT"] = saved
+        L.c25519_amd_tunable_set(b"XF_SPLIT", -1)
     return best
 
 

@@ -107,17 +107,20 @@ for name, cfn, rfn, pfn, dfn, moved in (
 # gather / slab-download code as for eight), against the single-GPU *_batch call on the same pageable arrays
 import ctypes as C  # noqa: E402
 ndev = min(api.device_count(), 8)
-mh = C.c_void_p()
-assert L.c25519_amd_multi_create(C.byref(mh), (C.c_int * ndev)(*range(ndev)), ndev) == 0
 m32, m64, mok = np.zeros((n, 32), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32)
-# three shapes of the same call: as shipped (a one-device handle skips the gather), the N > 1 path forced on the devices
-# that exist (resident results, piece-wise grouped ncclGather, the root's drain and copy threads), and the gather switched off
-# (every device downloads its own rows: c25519_amd_multi_set_gather(h, 0))
-for label, force, gather in (("as shipped", False, 1), ("gather path forced", True, 1), ("gather off", True, 0)):
-    if force:
-        os.environ["C25519_AMD_MULTI_FORCE_GATHER"] = "1"
-    else:
-        os.environ.pop("C25519_AMD_MULTI_FORCE_GATHER", None)
+# four shapes of the same call: as shipped (a one-device handle skips the gather), the N > 1 path forced on the devices
+# that exist (resident results, piece-wise grouped ncclGather, the root's drain and copy threads), the gather switched off
+# (every device downloads its own rows: c25519_amd_multi_set_gather(h, 0)) -- and, on a one-GPU box, EIGHT VIRTUAL DEVICES
+# on the one GPU (a device list naming it eight times: the 8-GPU code with device-to-device copies for the gather), both modes
+shapes = [("as shipped", ndev, False, 1, "multi"), ("gather path forced", ndev, True, 1, "multi_forced_gather"),
+          ("gather off", ndev, True, 0, "multi_gather_off")]
+if ndev == 1:
+    shapes += [("8 virtual, gather", 8, False, 1, "multi_virtual8"), ("8 virtual, no gather", 8, False, 0, "multi_virtual8_gather_off")]
+for label, D, force, gather, key in shapes:
+    mh = C.c_void_p()
+    devs = list(range(ndev)) if D == ndev else [0] * D
+    assert L.c25519_amd_multi_create(C.byref(mh), (C.c_int * D)(*devs), D) == 0
+    _lib.set_tunable("MULTI_FORCE_GATHER", 1 if force else -1)
     assert L.c25519_amd_multi_set_gather(mh, gather) == 0
     for name, mfn, bfn in (("x25519", lambda: L.curve25519_dh_CreateSharedKey_multi(mh, P(m32), P(pk), P(sk), n),
                             lambda: L.curve25519_dh_CreateSharedKey_batch(P(h32), P(pk), P(sk), n)),
@@ -130,13 +133,14 @@ for label, force, gather in (("as shipped", False, 1), ("gather path forced", Tr
         assert np.array_equal(m32 if name == "x25519" else m64 if name == "sign" else mok,
                               h32 if name == "x25519" else h64 if name == "sign" else hok), (label, name)
         tm, tb = host_rate_pair(mfn, bfn)                 # alternating calls, medians
-        key = {"as shipped": "multi", "gather path forced": "multi_forced_gather", "gather off": "multi_gather_off"}[label]
         rows[name].update({"multi_devices": ndev, key + "_ms": round(tm * 1e3, 3), key + "_Mops": round(n / tm / 1e6, 2),
-                           key + "_batch_ms_interleaved": round(tb * 1e3, 3), key + "_over_batch": round(tb / tm, 3)})
-        print(f"{name:7s} *_multi over {ndev} device(s), {label:18s} {tm * 1e3:8.2f} ms = {n / tm / 1e6:7.1f} M ops/s | *_batch "
-              f"alternating with it {tb * 1e3:8.2f} ms | ratio to *_batch {tb / tm:.2f}")
-os.environ.pop("C25519_AMD_MULTI_FORCE_GATHER", None)
-L.c25519_amd_multi_destroy(mh)
+                           key + "_batch_ms_interleaved": round(tb * 1e3, 3), key + "_over_batch": round(tb / tm, 3),
+                           key + "_helper_threads": int(L.c25519_amd_multi_helper_threads(mh))})
+        print(f"{name:7s} *_multi over {D} device(s), {label:20s} {tm * 1e3:8.2f} ms = {n / tm / 1e6:7.1f} M ops/s | *_batch "
+              f"alternating with it {tb * 1e3:8.2f} ms | ratio to *_batch {tb / tm:.2f} | helper threads "
+              f"{L.c25519_amd_multi_helper_threads(mh)} of {L.c25519_amd_usable_cpus()} usable CPUs")
+    L.c25519_amd_multi_destroy(mh)
+_lib.set_tunable("MULTI_FORCE_GATHER", -1)
 assert np.array_equal(hok, np.ones(n, np.int32)) and np.array_equal(reg["hok"], hok)
 assert np.array_equal(reg["h32"], h32) and np.array_equal(reg["h64"], h64)
 for v in reg.values():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/small_batch_sweep.py -- latency of a call of n device-resident elements, one operation per wave (coop25519.cuh)
-against one operation per lane (the batch kernels' narrow shapes), around the crossover C25519_AMD_COOP_MAX sets."""
+against one operation per lane (the batch kernels' narrow shapes), around the crossover the tunable COOP_MAX sets."""
 import os
 import sys
 
@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from curve25519_amd import api, synth  # noqa: E402
+from curve25519_amd import _lib, api, synth  # noqa: E402
 
 dev = torch.device("cuda", 0)
 N = 1 << 14
@@ -42,9 +42,9 @@ def us(fn, n, reps=12):
 print(f"{'op':12s} {'n':>6s} {'one per wave [us]':>18s} {'one per lane [us]':>18s}")
 for name, fn in ops.items():
     for n in (1, 16, 64, 256, 1024, 2048, 4096, 8192, 16384):
-        os.environ["C25519_AMD_COOP_MAX"] = str(1 << 20)
+        _lib.set_tunable("COOP_MAX", 1 << 20)
         c = us(fn, n)
-        os.environ["C25519_AMD_COOP_MAX"] = "0"
+        _lib.set_tunable("COOP_MAX", 0)
         b = us(fn, n)
         print(f"{name:12s} {n:6d} {c:18.1f} {b:18.1f}", flush=True)
-os.environ.pop("C25519_AMD_COOP_MAX", None)
+_lib.set_tunable("COOP_MAX", -1)
