@@ -67,7 +67,7 @@ enum Tunable {
     T_VERIFY_REFERENCE_ORDER,   // 1: every verification through the reference-order kernels (BASELINE.json configs[3] as worded)
     T_MULTI_FORCE_GATHER,       // 1: a one-device *_multi handle takes the gather path too
     T_MULTI_VIRTUAL,            // c25519_amd_multi_create: a one-device list becomes this many virtual devices on it
-    T_BASE_COMB,                // fixed-base walks: 0 = the 8-table signed comb in LDS, 1 = the wide comb read from L2
+    T_BASE_COMB,                // fixed-base walks: 0 = the 8-table signed comb in LDS, 1 = the wide comb read from L2 (default)
     T_HELPER_THREADS,           // cap on the staging helper threads of one process (unset: the CPUs this process may use)
     T_COUNT
 };

@@ -178,11 +178,18 @@ inline HelperPool& helper_pool(int n)
 }
 
 // rows per piece of a pipelined call of n rows of `row` bytes: n/8 (C25519_AMD_BATCH_PIECES) in multiples of 256 for big
-// batches, everything at once for small ones, at most 256 MiB of staging per buffer set
+// batches but not below 2^16 rows -- two pieces' kernels are in flight at a time, and 2^15 lanes and fewer leave most of
+// the chip idle (a 2^17-row shard of an eight-GPU call is two pieces of 2^16, not eight of 2^14) --, everything at once
+// for small ones, at most 256 MiB of staging per buffer set
 inline size_t piece_rows(size_t n, size_t row)
 {
     static const size_t pieces = [] { const char* e = getenv("C25519_AMD_BATCH_PIECES"); int v = e ? atoi(e) : 0; return (size_t)(v >= 2 && v <= 64 ? v : 8); }();
-    size_t chunk = n >= ((size_t)1 << 17) ? round_up((n + pieces - 1) / pieces, 256) : n;
+    static const size_t floor_rows = [] { const char* e = getenv("C25519_AMD_PIECE_MIN_ROWS"); long v = e ? atol(e) : 0; return (size_t)(v >= 256 ? v : 1 << 16); }();
+    size_t chunk = n;
+    if (n >= ((size_t)1 << 17)) {
+        chunk = round_up((n + pieces - 1) / pieces, 256);
+        if (chunk < floor_rows) chunk = floor_rows;
+    }
     const size_t cap = round_up(((size_t)256 << 20) / (row ? row : 1) + 1, 256);
     return chunk > cap ? cap : chunk;
 }

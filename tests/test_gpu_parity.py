@@ -999,24 +999,23 @@ def test_bench_detects_a_wrong_output_and_exits_nonzero():
 
 def test_a_late_rank_does_not_change_the_timed_region():
     """bench.py's protocol: the clock-ramp launches come BEHIND the opening barrier, directly in front of the timed steps, and
-    a rank's time is its own t1 - t0 -- so a rank 0 that arrives half a second late at every block (C25519_BENCH_DELAY_RANK0_S,
-    the live probe of round 4 was such a delay) leaves the other ranks idle at the barrier, not on the clock ramp inside their
-    timed region.  Two ranks sharing the one GPU; sign is the pass most sensitive to the ramp (1.6 ms per step)."""
-    import torch
+    a rank's time is its own t1 - t0 -- so a rank that arrives half a second late at every block (C25519_BENCH_DELAY_RANK0_S;
+    round 4's live probe on rank 0 was such a delay, in front of the side blocks) starts its timed steps on a chip that has
+    just been busy for 60 ms, not on the clock ramp (10-19 % slow, profiles/r04_warmup_probe.txt).  The N > 1 code path with
+    a world of one rank (RCCL gathers), 2^20 per pass; sign is the pass most sensitive to the ramp (1.6 ms per step)."""
     res = {}
     for delay in ("0", "0.5"):
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
         env["C25519_BENCH_DELAY_RANK0_S"] = delay
-        if torch.cuda.device_count() < 2:
-            env["C25519_BENCH_SHARE_GPU"] = "1"
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
-                            "--batch", str(1 << 18), "--no-cpu"], capture_output=True, text=True, timeout=300, env=env)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dist-selftest", "--steps", "20", "--warmup", "2",
+                            "--no-cpu"], capture_output=True, text=True, timeout=300, env=env)
         assert p.returncode == 0, p.stderr[-3000:]
         res[delay] = json.loads(p.stdout)
-    for name in ("verify", "sign"):
-        a, b = res["0"][name]["ms_per_step"], res["0.5"][name]["ms_per_step"]
-        # two processes time-slicing one GPU are noisier than two GPUs: the bar here is 5 %, the ask on real ranks 1 %
-        assert abs(a - b) / a < 0.05, (name, a, b)
+        assert res[delay]["bit_exact"]["all"] is True
+    for name in ("x25519", "verify", "sign"):
+        a = res["0"]["ms_per_step"] if name == "x25519" else res["0"][name]["ms_per_step"]
+        b = res["0.5"]["ms_per_step"] if name == "x25519" else res["0.5"][name]["ms_per_step"]
+        assert abs(a - b) / a < 0.02, (name, a, b)
 
 
 def test_small_calls_run_one_operation_per_wave_and_agree_with_the_batch_kernels(api, oracle, monkeypatch):

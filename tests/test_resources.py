@@ -28,9 +28,12 @@ HOT = {
     "k_x25519_ladder<false>": 128, "k_x25519_ladder<true>": 128,                                          # full batches
     "k_ed25519_verify_fast_scalars": 128, "k_ed25519_verify_fast_points": 168, "k_ed25519_verify_fast_walk": 256,
     "k_ed25519_verify_slow": 256,
-    "k_ed25519_sign_mult<false>": 128, "k_ed25519_sign_mult<true>": 128,
-    "k_ed25519_keypair_mult<false>": 128, "k_ed25519_keypair_mult<true>": 128,
-    "k_x25519_public_fast_mult": 128, "k_ed25519_sign_finish": 128,
+    # the fixed-base kernels, <BLIND, WIDE>: the wide comb read through L2 (shipped) and the 8 x 32 comb staged in LDS
+    "k_ed25519_sign_mult<false, true>": 128, "k_ed25519_sign_mult<true, true>": 128,
+    "k_ed25519_sign_mult<false, false>": 128, "k_ed25519_sign_mult<true, false>": 128,
+    "k_ed25519_keypair_mult<false, true>": 128, "k_ed25519_keypair_mult<true, true>": 128,
+    "k_ed25519_keypair_mult<false, false>": 128, "k_ed25519_keypair_mult<true, false>": 128,
+    "k_x25519_public_fast_mult<true>": 128, "k_x25519_public_fast_mult<false>": 128, "k_ed25519_sign_finish": 128,
     "k_ed25519_verify_check_shared": 168, "k_ed25519_verify_check<c25519::QTableLimbs>": 168,
 }
 

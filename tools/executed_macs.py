@@ -27,7 +27,8 @@ INV_K = 16            # engine.hip: inversion_k(2^20)
 WAVE_TOP = 32         # engine.hip: FastScratch::order -- waves of elements whose scalars start at digit 32 or below
 
 
-def count(sample=64):
+def count(sample=64, base_comb=1):
+    """base_comb: 1 = the wide 13 x 20 fixed-base comb (shipped default, engine.hip: base_comb_wide), 0 = the 8 x 32 LDS comb"""
     import build as emul_build
     from curve25519_amd import synth
     lib = C.CDLL(emul_build.build())
@@ -36,6 +37,7 @@ def count(sample=64):
     p = lambda a: a.ctypes.data  # noqa: E731
     take = lambda: int(lib.emul_mad_count_take())  # noqa: E731
     n = sample
+    lib.emul_set_base_comb(base_comb)
 
     def fe_op(op):                                     # one field operation on random operands
         a, b, out = synth.random_bytes((n, 32), 11), synth.random_bytes((n, 32), 12), np.empty((n, 32), np.uint8)
@@ -71,19 +73,22 @@ def count(sample=64):
 
     ok, slow = np.empty(n, np.int32), np.empty(n, np.int32)
     lib.emul_ed25519_verify_fast_at.argtypes = [vp, vp, vp, vp, vp, sz, sz, C.c_int]
+    lib.emul_ed25519_verify_fast_at(p(ok), p(slow), p(sig), p(pub), p(msg), 32, 1, WAVE_TOP)     # (builds the walk's comb table)
     take()
     lib.emul_ed25519_verify_fast_at(p(ok), p(slow), p(sig), p(pub), p(msg), 32, n, WAVE_TOP)
     verify = take() / n
     assert ok.all() and not slow.any()
+    lib.emul_set_base_comb(0)
     return {"per_op": {"x25519": round(x25519), "sign": round(sign), "verify": round(verify)},
             "detail": {"fe_mul": mul, "fe_sq": sq, "fe_invert": inv, "x25519_ladder": round(ladder, 1),
                        "shared_inversion_per_element_K16": round(shared_inv, 1), "ed25519_keypair": round(keypair),
+                       "fixed_base_comb": "13 x 20, four tables through L2" if base_comb else "8 x 32, eight tables in LDS",
                        "verify_wave_top_digit": WAVE_TOP, "sample_elements": n},
             "method": "device source on the C model of the gfx950 primitives, v_mad_u64_u32 counted (tools/executed_macs.py)"}
 
 
 if __name__ == "__main__":
-    r = count()
+    r = count(base_comb=0 if "--lds-comb" in sys.argv else 1)
     print(json.dumps(r, indent=1))
     if "--write" in sys.argv:
         with open(sys.argv[sys.argv.index("--write") + 1], "w") as f:

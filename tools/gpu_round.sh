@@ -1,10 +1,10 @@
 #!/bin/bash
 # tools/gpu_round.sh -- one gpurun call's worth of work: the GPU test suite, bench lines, the instruction-rate
-# microbenchmark, the host-API rates and the rocprofv3 passes.  Everything lands under gpurun_out/$ROUND/ (default r04).
+# microbenchmark, the host-API rates and the rocprofv3 passes.  Everything lands under gpurun_out/$ROUND/ (default r05).
 #   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tests|bench|ubench|prof|all ...]'
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/${ROUND:-r04}
+OUT=$REPO/gpurun_out/${ROUND:-r05}
 mkdir -p $OUT
 cd $REPO
 WHAT=${*:-all}
@@ -34,6 +34,11 @@ if has probe; then                                     # in-kernel s_memtime pro
   timeout 300 python tools/cycle_probe.py $P --fused >> $OUT/cycle_probe.txt 2>&1; echo "probe fused rc=$?"
   timeout 300 python tools/single_call_latency.py > $OUT/single_call.txt 2>&1; timeout 300 python tools/single_call_breakdown.py >> $OUT/single_call.txt 2>&1
   timeout 600 python tools/small_batch_sweep.py > $OUT/small_batch_sweep.txt 2>&1; echo "sweep rc=$?"
+fi
+if has comb; then                                      # A/B of the fixed-base combs, interleaved in one process (tunable BASE_COMB)
+  L=curve25519_amd/libcurve25519_amd.so
+  timeout 600 python tools/ab_bench.py $L $L@BASE_COMB=1 --ops sign,keypair --rounds ${AB_ROUNDS:-6} > $OUT/ab_base_comb.txt 2>&1
+  echo "comb rc=$?"; cat $OUT/ab_base_comb.txt
 fi
 if has ab && ls build_ab/*.so >/dev/null 2>&1; then
   timeout 900 python tools/ab_bench.py curve25519_amd/libcurve25519_amd.so build_ab/*.so ${AB_EXTRA:-} --ops ${AB_OPS:-x25519,sign,verify,keypair} --rounds ${AB_ROUNDS:-4} > $OUT/ab_bench.txt 2>&1
