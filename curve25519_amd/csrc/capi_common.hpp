@@ -69,13 +69,14 @@ enum Tunable {
     T_MULTI_VIRTUAL,            // c25519_amd_multi_create: a one-device list becomes this many virtual devices on it
     T_BASE_COMB,                // fixed-base walks: 0 = the 8-table signed comb in LDS, 1 = the wide comb read from L2 (default)
     T_HELPER_THREADS,           // cap on the staging helper threads of one process (unset: the CPUs this process may use)
+    T_VERIFY_LAT_CAP_BITS,      // TEST knob: verification's lattice walk takes short vectors up to this many bits (100..158)
     T_COUNT
 };
 constexpr long T_UNSET = -1;
 inline const char* const* tunable_names()
 {
     static const char* const names[T_COUNT] = { "COOP_MAX", "XF_SPLIT", "INV_K", "VERIFY_REFERENCE_ORDER", "MULTI_FORCE_GATHER",
-                                                "MULTI_VIRTUAL", "BASE_COMB", "HELPER_THREADS" };
+                                                "MULTI_VIRTUAL", "BASE_COMB", "HELPER_THREADS", "VERIFY_LAT_CAP_BITS" };
     return names;
 }
 inline std::atomic<long>* tunable_table()
@@ -156,6 +157,9 @@ struct ThreadState {
     hipEvent_t computed[SETS] = {};        // end of a set's last kernels
     void* dbuf[SETS][SLOTS] = {};          // device staging
     size_t dcap[SETS][SLOTS] = {};
+    void* vctx = nullptr;                  // the 2080-byte context of this thread's last ed25519_Verify_Check_batch (nothing else writes it)
+    unsigned char vctx_host[2080] = {};    // ... and the bytes that were uploaded into it
+    bool vctx_valid = false;
     void* hbuf[SETS][SLOTS] = {};          // pinned host staging (hipHostMalloc)
     size_t hcap[SETS][SLOTS] = {};
     // work scratch of the *_dev entry points: grow-only slabs, CALLER_SLABS PER DEVICE (a thread may drive several GPUs, see
@@ -318,6 +322,8 @@ struct ThreadState {
                 *e = nullptr;
             }
         }
+        if (vctx) { (void)hipMemset(vctx, 0, 2080); (void)hipFree(vctx); vctx = nullptr; }
+        vctx_valid = false;
         for (int l = 0; l < LANES; l++) {
             free_slab(lane_work[l]);
             if (stream[l]) (void)hipStreamDestroy(stream[l]);

@@ -395,6 +395,43 @@ C25519_DEV u32 ge_base_mult(u32* lds, const Lane& L, const u32 (&k)[8], const u3
     return v;
 }
 
+// The same walk over the WIDE comb (ge25519.cuh: 13 teeth 20 bits apart, four packed 4096-row tables): 19 additions + 4
+// doublings = 46 product levels instead of 68.  A packed row is Y+X | Y-X | 2dT as 255-bit integers; a lane takes the limb
+// of the field its row multiplies by straight out of the row's words (packed_limb).
+C25519_DEV u32 packed_limb(const u32* __restrict__ p, const Lane& L);
+C25519_DEV u32 wide_row_limb(const u32* __restrict__ tbl, const Lane& L, u32 col, u32 f)
+{
+    const u32 neg = ((col >> (WB_TEETH - 1)) & 1u) - 1u;  // all-ones: negative column
+    const u32 row = (col ^ neg) & (u32)(WB_ROWS - 1);
+    const u32 ff = (f < 2 && neg) ? 1u - f : f;
+    const u32 wd = packed_limb(tbl + (size_t)row * WB_ROW_WORDS + 8 * ff, L);
+    return (f == 2 && neg) ? L.p2 - wd : wd;
+}
+
+C25519_DEV u32 ge_base_mult_wide(u32* lds, const Lane& L, const u32 (&k)[8], const u32* __restrict__ wide)
+{
+    u32 cols[WB_COLS];                                    // (compile-time indices below: registers)
+    wb_columns(cols, 1, k);
+    const u32 lane = L.row * 16 + L.c;
+    // every row fetch is issued before the walk starts (the addresses depend on the scalar alone)
+#pragma unroll
+    for (int s = 1; s < WB_COLS; s++)
+        lds[ROWQ_OFF + s * 64 + lane] = wide_row_limb(wide + (size_t)(s % WB_NT) * WB_ROWS * WB_ROW_WORDS, L, cols[s], by_row(L, 1, 0, 2, 2));
+    const u32 ypx = wide_row_limb(wide, L, cols[0], 0), ymx = wide_row_limb(wide, L, cols[0], 1), t2d = wide_row_limb(wide, L, cols[0], 2);
+    put_y(lds, L, SLOT_KDI, my_limb(lds, L, fe_const(K_DI)));
+    const u32 two = L.c == 0 ? 2u : 0u;
+    put_a(lds, L, L.row, L.upper ? (L.odd_row ? t2d : two) : (L.odd_row ? ypx + ymx : ypx + L.p2 - ymx));
+    u32 v = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, SLOT_KDI));
+#pragma unroll 1
+    for (int m = 0; m < WB_STEP; m++) {
+        if (m) v = ge_dbl(lds, L, v);
+#pragma unroll 1
+        for (int t = m ? 0 : 1; t < WB_NT; t++)
+            v = ge_add(lds, L, v, lds[ROWQ_OFF + (m * WB_NT + t) * 64 + lane]);
+    }
+    return v;
+}
+
 // canonical (x, y) words of the point in the rows: one inversion of Z, two products, the batch kernels' encoding
 C25519_DEV void ge_affine_words(u32 (&xw)[8], u32 (&yw)[8], u32* lds, const Lane& L, u32 v)
 {

@@ -568,6 +568,7 @@ C25519_DEV void coop_setup_one(u32* lds, const coop::Lane& L)
     coop::put_y(lds, L, coop::SLOT_ONE, coop::my_limb(lds, L, one));
 }
 
+template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u32* __restrict__ g_tbl)
 {
@@ -580,7 +581,7 @@ k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u3
     load32(seed, sk, e);
     ed_expand_seed(a, b_words, seed);
     coop_setup_one(lds, L);
-    const u32 v = coop::ge_base_mult(lds, L, a, g_tbl);
+    const u32 v = WIDE ? coop::ge_base_mult_wide(lds, L, a, g_tbl) : coop::ge_base_mult(lds, L, a, g_tbl);
     coop::ge_affine_words(xw, yw, lds, L, v);
     ge_pack(enc, xw, yw);
     if (threadIdx.x == 0) {
@@ -591,6 +592,7 @@ k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u3
 }
 
 // curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189): S = clamp(sk) * B on the Edwards side, u = (Z + Y) / (Z - Y)
+template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ g_tbl)
 {
@@ -603,7 +605,7 @@ k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ 
     clamp_words(k);
     if (threadIdx.x == 0) store32(sk, e, k);
     coop_setup_one(lds, L);
-    const u32 v = coop::ge_base_mult(lds, L, k, g_tbl);
+    const u32 v = WIDE ? coop::ge_base_mult_wide(lds, L, k, g_tbl) : coop::ge_base_mult(lds, L, k, g_tbl);
     u32 ev, od, y, z, t;
     coop::pair_exchange(ev, od, v);                       // lower pair: X, Y; upper pair: Z, T
     coop::half_exchange(y, t, od);                        // y: Y in every row
@@ -618,6 +620,7 @@ k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ 
     if (threadIdx.x == 0) store32(pk, e, wds);
 }
 
+template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32* __restrict__ g_tbl)
 {
@@ -630,7 +633,7 @@ k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32*
     load32(pkw, priv, 2 * e + 1);
     ed_sign_nonce(a, r, seed, msgs.ptr(e), msgs.len(e));
     coop_setup_one(lds, L);
-    const u32 v = coop::ge_base_mult(lds, L, r, g_tbl);
+    const u32 v = WIDE ? coop::ge_base_mult_wide(lds, L, r, g_tbl) : coop::ge_base_mult(lds, L, r, g_tbl);
     coop::ge_affine_words(xw, yw, lds, L, v);
     ge_pack(enc, xw, yw);
     ed_sign_s(s, enc, pkw, msgs.ptr(e), msgs.len(e), a, r);
@@ -717,6 +720,7 @@ struct FastScratch {
     u32 *order;             // the walk's lane j takes element order[j]: elements whose scalars start at digit 32 or below
                             // from the front, the few longer ones from the back, so that a wave of 64 rarely holds one
     u32 *slow_report;       // a word that outlives the call's scratch: the count again, for c25519_amd_verify_last_slow_elements
+    int lat_cap_bits;       // longest short vector the walk takes (LAT_CAP_BITS; lower only under the test knob VERIFY_LAT_CAP_BITS)
 };
 constexpr size_t FAST_TABLE_WORDS = 2 * WTABLE_WORDS;
 constexpr int FS_BLOCK = 256;
@@ -746,7 +750,7 @@ __global__ void __launch_bounds__(FS_BLOCK) k_ed25519_verify_fast_scalars(FastSc
     load32(pkw, pk, i);
     load32(Rw, sig, 2 * i);
     load32(Sw, sig, 2 * i + 1);
-    const u32 lat_ok = ed_verify_fast_scalars(cols, rho, tau, tau_neg, pkw, Rw, Sw, msgs.ptr(i), msgs.len(i));
+    const u32 lat_ok = ed_verify_fast_scalars(cols, rho, tau, tau_neg, pkw, Rw, Sw, msgs.ptr(i), msgs.len(i), fs.lat_cap_bits);
 #pragma unroll
     for (int w = 0; w < SIGMA_WORDS; w++) fs.sigma[(size_t)w * n + i] = cols[w];
 #pragma unroll
@@ -1257,6 +1261,10 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
         fs.order = fs.slow_list + round_up(n, 4);
         fs.slow_count = fs.order + round_up(n, 4);
         fs.slow_report = report;
+        {   // test knob: a lower cap sends ordinary signatures down the over-long-vector branch (slow list, reference order)
+            const long cap = c25519_host::tunable_or(c25519_host::T_VERIFY_LAT_CAP_BITS, LAT_CAP_BITS);
+            fs.lat_cap_bits = cap >= 100 && cap < LAT_CAP_BITS ? (int)cap : LAT_CAP_BITS;
+        }
         k_ed25519_verify_fast_scalars<<<grid_for(n, FS_BLOCK), FS_BLOCK, 0, stream>>>(fs, sig, pk, msgs, n);
         C25519_TRY(hipGetLastError());
         k_ed25519_verify_fast_points<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
@@ -1457,7 +1465,11 @@ int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     if (fixed_base_coop_for(n)) {                             // a few elements: one operation per wave
-        k_x25519_public_fast_coop<<<(unsigned)n, 64, 0, stream>>>(pk, sk, n, tbl);
+        if (base_comb_wide()) {
+            const u32* wide = nullptr;
+            C25519_RC(wide_tables(&wide));
+            k_x25519_public_fast_coop<true><<<(unsigned)n, 64, 0, stream>>>(pk, sk, n, wide);
+        } else k_x25519_public_fast_coop<false><<<(unsigned)n, 64, 0, stream>>>(pk, sk, n, tbl);
         C25519_TRY(hipGetLastError());
         return 0;
     }
@@ -1485,7 +1497,11 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     if (!blinding && fixed_base_coop_for(n)) {                // a few elements: one operation per wave
-        k_ed25519_keypair_coop<<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, tbl);
+        if (base_comb_wide()) {
+            const u32* wide = nullptr;
+            C25519_RC(wide_tables(&wide));
+            k_ed25519_keypair_coop<true><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, wide);
+        } else k_ed25519_keypair_coop<false><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, tbl);
         C25519_TRY(hipGetLastError());
         return 0;
     }
@@ -1526,7 +1542,11 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     if (!blinding && fixed_base_coop_for(n)) {                // a few elements: one operation per wave
-        k_ed25519_sign_coop<<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, tbl);
+        if (base_comb_wide()) {
+            const u32* wide = nullptr;
+            C25519_RC(wide_tables(&wide));
+            k_ed25519_sign_coop<true><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, wide);
+        } else k_ed25519_sign_coop<false><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, tbl);
         C25519_TRY(hipGetLastError());
         return 0;
     }
@@ -1970,9 +1990,17 @@ int ed25519_Verify_Check_batch(int* verdict, const void* ctx, const unsigned cha
     if (n == 0) return 0;
     ThreadState& t = tls();
     C25519_RC(t.ensure());
-    C25519_RC(t.reserve_dev(ThreadState::LANES - 1, ThreadState::SLOTS - 1, 2080));
-    void* dctx = t.dbuf[ThreadState::LANES - 1][ThreadState::SLOTS - 1];
-    C25519_TRY(hipMemcpy(dctx, ctx, 2080, hipMemcpyHostToDevice));
+    // the reference's two-phase use is one Verify_Init and MANY Verify_Check calls on the same context
+    // (ed25519_verify.c:282-286): the context has a device buffer of its own per calling thread and is uploaded only when
+    // its bytes differ from what the thread uploaded last (a 2080-byte memcmp against a synchronous ~12 us copy per call)
+    if (!t.vctx) C25519_TRY(hipMalloc(&t.vctx, 2080));
+    void* dctx = t.vctx;
+    if (!t.vctx_valid || memcmp(t.vctx_host, ctx, 2080) != 0) {
+        t.vctx_valid = false;
+        C25519_TRY(hipMemcpy(dctx, ctx, 2080, hipMemcpyHostToDevice));
+        memcpy(t.vctx_host, ctx, 2080);
+        t.vctx_valid = true;
+    }
     return run_batch(n, { Arr{ sig, nullptr, 64 }, Arr{ msg, nullptr, msg_size }, Arr{ nullptr, verdict, sizeof(int) } },
                      [&](void** d, size_t c, size_t, hipStream_t st) -> int {
                          return ed25519_Verify_Check_dev(d[2], dctx, d[0], d[1], msg_size, c, st);

@@ -257,8 +257,9 @@ C25519_DEV bool lat_lehmer_step(u32 (&r0)[LAT_R], u32 (&t0)[LAT_T], u32 (&r1)[LA
 }
 
 // h (< 2^256, normally canonical mod L) -> rho (odd, > 0), |tau|, sign of tau, as 5-word little-endian magnitudes.
-// Returns all-ones if both fit the walk (bit length <= LAT_CAP_BITS), zero otherwise (the caller falls back).
-C25519_DEV u32 sc_lattice_short(u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative, const u32 (&h)[8])
+// Returns all-ones if both fit the walk (bit length <= cap_bits, which is LAT_CAP_BITS in production; a test lowers it
+// through the tunable VERIFY_LAT_CAP_BITS to send ordinary signatures down the fall-back), zero otherwise (the caller falls back).
+C25519_DEV u32 sc_lattice_short(u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative, const u32 (&h)[8], int cap_bits = LAT_CAP_BITS)
 {
     u32 r0[LAT_R], r1[LAT_R], t0[LAT_T] = { 0, 0, 0, 0, 0, 0 }, t1[LAT_T] = { 1, 0, 0, 0, 0, 0 };
     lat_modulus(r0);
@@ -361,7 +362,7 @@ C25519_DEV u32 sc_lattice_short(u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative,
     tau_negative = t_negative ? 0xffffffffu : 0u;
 #pragma unroll
     for (int i = 0; i < 5; i++) { rho[i] = t[i]; tau[i] = r[i]; }
-    const bool fits = sane && bitlen_words<LAT_R>(r) <= LAT_CAP_BITS && bitlen_words<LAT_T>(t) <= LAT_CAP_BITS && (t[0] & 1u);
+    const bool fits = sane && bitlen_words<LAT_R>(r) <= cap_bits && bitlen_words<LAT_T>(t) <= cap_bits && (t[0] & 1u);
     return fits ? 0xffffffffu : 0u;
 }
 
@@ -879,7 +880,7 @@ C25519_DEV u32 ge_walk_is_neutral(const WalkScalars& sc, const u32* tq, const u3
 // BIASED (bias_signed16) and sigma as its signed comb columns (sc_comb_columns), ready for the walk.  Returns all-ones if
 // the vector fits the walk.
 C25519_DEV u32 ed_verify_fast_scalars(u32 (&sigma_cols)[SIGMA_WORDS], u32 (&rho)[5], u32 (&tau)[5], u32& tau_negative, const u32 (&pkw)[8],
-                                      const u32 (&Rw)[8], const u32 (&Sw)[8], const uint8_t* msg, size_t len)
+                                      const u32 (&Rw)[8], const u32 (&Sw)[8], const uint8_t* msg, size_t len, int cap_bits = LAT_CAP_BITS)
 {
     u32 h[8], sigma[8];
     {
@@ -892,7 +893,7 @@ C25519_DEV u32 ed_verify_fast_scalars(u32 (&sigma_cols)[SIGMA_WORDS], u32 (&rho)
         sc_reduce512(h, le);
         sc_mod(h);
     }
-    const u32 lat_ok = sc_lattice_short(rho, tau, tau_negative, h);
+    const u32 lat_ok = sc_lattice_short(rho, tau, tau_negative, h, cap_bits);
     sc_mul_short(sigma, rho, Sw);
     sc_comb_columns(sigma_cols, sigma);
     u32 b[5];

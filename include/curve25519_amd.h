@@ -40,7 +40,9 @@ int  c25519_amd_set_device(int device);                /* device used by this ho
  * one fused launch 0), INV_K (elements per inverting lane, 1..16), VERIFY_REFERENCE_ORDER (1: every verification in the
  * reference's 4-fold + 8-fold order), MULTI_FORCE_GATHER (1: a one-device *_multi handle gathers too), MULTI_VIRTUAL (V: a
  * one-device list given to c25519_amd_multi_create becomes V virtual devices on it), BASE_COMB (fixed-base walks: 0 = the 8 x 32 comb staged in LDS,
- * 1 = the wide 13 x 20 comb read through L2, the default), HELPER_THREADS (cap on the staging helper threads; default: the CPUs this process may use).
+ * 1 = the wide 13 x 20 comb read through L2, the default), HELPER_THREADS (cap on the staging helper threads; default: the CPUs this process may use),
+ * VERIFY_LAT_CAP_BITS (test knob, 100..157: verification's lattice walk refuses longer short vectors, which then take the
+ * reference-order kernel).
  * _get returns -1 for "built-in choice", -2 for an unknown name. */
 int  c25519_amd_tunable_set(const char *name, long value);
 long c25519_amd_tunable_get(const char *name);

@@ -1123,6 +1123,45 @@ def test_degenerate_but_valid_signatures_on_both_paths(api):
         assert np.array_equal(api.ed25519_VerifySignature(s2, pub, m8), want)
 
 
+def test_overlong_lattice_vectors_take_the_reference_order_path(api, oracle):
+    """The walk of the lattice path takes short vectors up to LAT_CAP_BITS = 158 bits (verify_fast.cuh); a longer one -- 2^-33
+    per random h -- sends its element to the slow list and k_ed25519_verify_slow decides it in the reference's order
+    (ed25519_verify.c:287-313).  The test knob VERIFY_LAT_CAP_BITS lowers the cap INTO the typical range (127-131 bits), so
+    that about half of a batch of ordinary signatures takes that branch on the device -- on-curve keys on the slow list,
+    which garbage keys never exercise -- mixed with the corrupted entries and S + L: verdicts against the oracle, the
+    accounting hook counts the detour, and the same inputs under the production cap take no detour at all."""
+    from curve25519_amd import _lib
+    import vectors
+    L = _lib.load()
+    n = 1 << 14
+    sk, msg = synth.random_bytes((n, 32), 0x6a1), synth.random_bytes((n, 21), 0x6a2)
+    pub, priv = api.ed25519_CreateKeyPair(sk)
+    sig = api.ed25519_SignMessage(priv, msg)
+    bsig, bmsg, bad = synth.corrupt_for_verify(sig, msg)
+    for i in range(0, 300, 3):                                           # S + L: accepted by the reference
+        S = int.from_bytes(bsig[i, 32:].tobytes(), "little")
+        if S + vectors.L < 2**256:
+            bsig[i, 32:] = vectors.le(S + vectors.L, 32)
+    exp = oracle.ed25519_verify(bsig, pub, bmsg, threads=THREADS)
+    assert np.array_equal(exp == 0, bad)
+    seen = []
+    for cap in (128, 126, 131):
+        with _lib.tunable("VERIFY_LAT_CAP_BITS", cap):
+            for knob in (-1, 0):                                         # both walk kernels around the slow list
+                with _lib.tunable("COOP_MAX", knob):
+                    ok = api.ed25519_VerifySignature(bsig, pub, bmsg)
+                    slow = L.c25519_amd_verify_last_slow_elements()
+                    assert np.array_equal(ok, exp), (cap, knob)
+            seen.append(slow)
+    assert n // 8 < seen[0] < n - n // 8 and seen[1] > seen[0] > seen[2] > 0, seen    # roughly half at 128 bits, monotone in the cap
+    # a few elements only (the per-wave kernels' shapes) with the cap lowered
+    with _lib.tunable("VERIFY_LAT_CAP_BITS", 127):
+        for m in (1, 5, 64):
+            assert np.array_equal(api.ed25519_VerifySignature(bsig[:m], pub[:m], bmsg[:m]), exp[:m]), m
+    ok = api.ed25519_VerifySignature(bsig, pub, bmsg)
+    assert L.c25519_amd_verify_last_slow_elements() == 0 and np.array_equal(ok, exp)
+
+
 def test_lattice_fast_path_and_reference_order_agree(api, oracle):
     """ed25519_VerifySignature's default path decides every element whose key is on the curve with the exact lattice-shortened walk
     (csrc/verify_fast.cuh) and runs the reference's operation order for the rest.  Every class of input where the two
