@@ -5,6 +5,7 @@
 #include "capi_common.hpp"
 
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <initializer_list>
@@ -89,6 +90,86 @@ private:
     bool stop_ = false, failed_ = false;
 };
 
+// ---- one pool of copy threads for the whole process, used when SEVERAL pipelines run beside each other (the multi-GPU
+// layer: one pipeline per device) -- so that whichever phase the call is in, staging in on eight devices or handing the
+// gathered rows to the caller on the root, every copy thread the CPU budget allows is copying, and the thread count does
+// not grow with the number of devices.  copy() cuts its ranges into 512 KiB tasks, queues them and blocks until they are
+// done; the threads that call it (a pipeline's helper, the root's copier) only wait.  Size: the CPUs this process may use
+// (usable_cpus() / C25519_AMD_HELPER_THREADS) minus four for the threads that enqueue and wait, at least 2, at most 12.
+class SharedCopyPool {
+public:
+    struct Range { void* dst; const void* src; size_t bytes; };
+    static SharedCopyPool& instance()
+    {
+        static SharedCopyPool pool;
+        return pool;
+    }
+    int size() const { return (int)th_.size(); }
+    void copy(const Range* r, int count)
+    {
+        constexpr size_t CHUNK = (size_t)512 << 10;
+        Batch b;
+        size_t tasks = 0;
+        for (int i = 0; i < count; i++) tasks += (r[i].bytes + CHUNK - 1) / CHUNK;
+        if (!tasks) return;
+        if (th_.empty() || tasks == 1) {                  // nobody to share with (or nothing to share)
+            for (int i = 0; i < count; i++) if (r[i].bytes) memcpy(r[i].dst, r[i].src, r[i].bytes);
+            return;
+        }
+        b.pending = tasks;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (int i = 0; i < count; i++)
+                for (size_t o = 0; o < r[i].bytes; o += CHUNK)
+                    q_.push_back(Task{ (char*)r[i].dst + o, (const char*)r[i].src + o, r[i].bytes - o < CHUNK ? r[i].bytes - o : CHUNK, &b });
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> lk(b.mu);
+        b.cv.wait(lk, [&] { return b.pending == 0; });
+    }
+    void copy(void* dst, const void* src, size_t bytes) { const Range r{ dst, src, bytes }; copy(&r, 1); }
+
+private:
+    struct Batch { std::mutex mu; std::condition_variable cv; size_t pending = 0; };
+    struct Task { char* dst; const char* src; size_t bytes; Batch* batch; };
+    SharedCopyPool()
+    {
+        long n = tunable_or(T_HELPER_THREADS, usable_cpus()) - 4;
+        n = n < 2 ? 2 : n > 12 ? 12 : n;
+        try {
+            for (long i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
+        } catch (const std::system_error&) {              // fewer threads than asked for: still a pool; none: copy() copies inline
+        }
+    }
+    ~SharedCopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) if (t.joinable()) t.join();
+    }
+    void loop()
+    {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                t = q_.front();
+                q_.pop_front();
+            }
+            memcpy(t.dst, t.src, t.bytes);
+            bool last;
+            { std::lock_guard<std::mutex> lk(t.batch->mu); last = --t.batch->pending == 0; if (last) t.batch->cv.notify_all(); }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Task> q_;
+    bool stop_ = false;
+};
+
 // ---- host-pointer pipeline used by the *_batch entry points -------------------------------------------------------
 // A call is cut into pieces; piece c uses buffer set c % SETS (pinned host + device staging), and these roles work on
 // different pieces at the same time:
@@ -127,12 +208,14 @@ inline int env_count(const char* name, int dflt, int max)
 // quota, not the host's thread count; C25519_AMD_HELPER_THREADS overrides) and the number of pipelines running beside each
 // other (the multi-GPU layer runs one per device and says so through concurrent_pipelines()): 4 + 2 with cores to spare
 // (sign moves 160 B per 1.8 ns of kernel time: one copier per direction cannot keep up), 2 + 1, 1 + 1, or ONE helper that
-// stages and drains in turn -- so that eight devices' pipelines on a 16-CPU container park 8 helpers, not 48.
+// stages and drains in turn.  SEVERAL pipelines beside each other always take the last shape, and that one helper only
+// orchestrates: its copies are cut into tasks for the process-wide SharedCopyPool above -- eight devices' pipelines on a
+// 16-CPU container run 12 copy threads in all, not 48, and all twelve work on whichever device has something to copy.
 inline int& concurrent_pipelines() { thread_local int n = 1; return n; }
-inline int& reserved_helper_threads() { thread_local int n = 0; return n; }
 struct HelperPlan { int stagers, drainers; bool combined; int total() const { return combined ? 1 : stagers + drainers; } };
 inline HelperPlan pipeline_helpers(int concurrent, int reserved = 0)
 {
+    if (concurrent > 1) return HelperPlan{ 0, 0, true };   // one orchestrating helper per pipeline; the copies go to SharedCopyPool
     const long budget = tunable_or(T_HELPER_THREADS, usable_cpus());
     const long share = (budget - reserved) / (concurrent < 1 ? 1 : concurrent);
     HelperPlan p = share >= (concurrent > 1 ? 6 : 16) ? HelperPlan{ 4, 2, false }
@@ -233,6 +316,11 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
             if (!direct[a]) C25519_RC(t.reserve_host(l, a, arr[a].elem * chunk));
         }
     auto span = [&](size_t c, size_t& lo, size_t& cnt) { lo = c * chunk; cnt = (n - lo < chunk) ? n - lo : chunk; };
+    const bool shared_copies = concurrent_pipelines() > 1;
+    auto copy_bytes = [&](void* dst, const void* src, size_t bytes) {
+        if (shared_copies) SharedCopyPool::instance().copy(dst, src, bytes);
+        else memcpy(dst, src, bytes);
+    };
     auto stage_in = [&](size_t c, int part, int parts) {   // rows [part, part+1) / parts of piece c
         size_t lo, cnt;
         span(c, lo, cnt);
@@ -240,7 +328,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
         const int l = (int)(c % sets);
         for (int a = 0; a < na; a++)
             if (arr[a].in && !direct[a] && (r1 - r0) * arr[a].elem)
-                memcpy((char*)t.hbuf[l][a] + r0 * arr[a].elem, (const char*)arr[a].in + (lo + r0) * arr[a].elem, (r1 - r0) * arr[a].elem);
+                copy_bytes((char*)t.hbuf[l][a] + r0 * arr[a].elem, (const char*)arr[a].in + (lo + r0) * arr[a].elem, (r1 - r0) * arr[a].elem);
     };
     // one piece: upload on the upload stream, kernels on one of the two kernel streams, download on the download
     // stream, chained by events -- so the upload of a later piece never queues behind an earlier piece's kernels, and
@@ -281,7 +369,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
         const int l = (int)(c % sets);
         C25519_TRY(hipEventSynchronize(t.done[l]));
         for (int a = 0; a < na; a++)
-            if (arr[a].out && !direct[a] && cnt * arr[a].elem) memcpy((char*)arr[a].out + lo * arr[a].elem, t.hbuf[l][a], cnt * arr[a].elem);
+            if (arr[a].out && !direct[a] && cnt * arr[a].elem) copy_bytes((char*)arr[a].out + lo * arr[a].elem, t.hbuf[l][a], cnt * arr[a].elem);
         return 0;
     };
 
@@ -316,7 +404,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
     int failed = 0;                                       // first error of any role; everybody stops
     std::string failed_text;                              // ... and its text: last_error() is thread-local, helpers have their own
     // helper threads: pipeline_helpers() above; parked in the calling thread's pool between calls
-    const HelperPlan plan = pipeline_helpers(concurrent_pipelines(), reserved_helper_threads());
+    const HelperPlan plan = pipeline_helpers(concurrent_pipelines());
     const int STAGERS = plan.combined ? 1 : plan.stagers, DRAINERS = plan.combined ? 0 : plan.drainers;
     HelperPool& pool = helper_pool(plan.total());
     if (!pool.ok()) return sequential();                  // the process cannot have more threads: do without them

@@ -11,7 +11,7 @@
 //      ever leaves from or lands in pageable memory.  Gathered results stay on the device (Arr::dev);
 //   3. the one exchange step: a grouped ncclGather of every device's result rows to devices[0] (rows padded to the
 //      largest shard, every rank sends the same count), and a second thread on the root streams the gathered rows to the
-//      caller.  All of it PIECE BY PIECE: every device cuts its shard at the same rows, a piece is gathered as soon
+//      caller (the copies themselves: the process-wide copy threads of host_pipeline.hpp).  All of it PIECE BY PIECE: every device cuts its shard at the same rows, a piece is gathered as soon
 //      as every device has enqueued its kernels (the gather streams wait for the pieces' events on the device; no worker
 //      ever stops for it) and handed to the caller while the devices compute the next pieces, so only the last
 //      piece's gather and download are not hidden (round 3 ran the three phases strictly one after the other).
@@ -172,9 +172,8 @@ struct c25519_amd_multi {
     std::vector<std::unique_ptr<Worker>> worker;
     // the root's hand-over of gathered pieces to the caller, beside worker[0]'s compute: `drain` enqueues a piece's
     // device-to-host copy on drain_stream (into a pinned slot, or straight into a page-locked destination), `copier`
-    // waits for the slot and copies it out to the caller's pageable rows with copy_pool's threads
+    // waits for the slot and copies it out to the caller's pageable rows (the process-wide copy threads, host_pipeline.hpp)
     std::unique_ptr<Worker> drain, copier;
-    std::unique_ptr<c25519_host::HelperPool> copy_pool;
     hipStream_t drain_stream = nullptr;
     static constexpr int SLOTS = 4;
     struct Slot { void* pinned = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; } slot[SLOTS];
@@ -299,8 +298,7 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
                         }
                     }
                     if (!cnt) return 0;
-                    c25519_host::concurrent_pipelines() = D;              // D pipelines share this process' CPUs ...
-                    c25519_host::reserved_helper_threads() = m->copy_threads;   // ... with the root's copy-out threads
+                    c25519_host::concurrent_pipelines() = D;              // D pipelines share this process' copy threads
                     c25519_host::PieceHook hook;
                     hook.chunk = chunk;
                     if (gathers)
@@ -415,19 +413,15 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
                         c25519_amd_multi::Slot& s2 = m->slot[k];
                         const hipError_t e = hipEventSynchronize(s2.ev);   // also when skipped: the DMA into the slot must have ended
                         if (e == hipSuccess && !skipped) {
-                            // D blocks, each cut into parts: every copy thread takes its share of every block
-                            const int parts = m->copy_pool->ok() ? m->copy_pool->size() : 1;
-                            auto copy = [&](int part) {
-                                for (int d = 0; d < D; d++) {
-                                    const size_t cnt_d = lo[d + 1] - lo[d];
-                                    const size_t real = r0 >= cnt_d ? 0 : (r0 + cnt < cnt_d ? cnt : cnt_d - r0);
-                                    const size_t a0 = real * part / parts, a1 = real * (part + 1) / parts;
-                                    if (a1 > a0)
-                                        memcpy(out + (lo[d] + r0 + a0) * elem, (const char*)s2.pinned + (cnt * d + a0) * elem, (a1 - a0) * elem);
-                                }
-                            };
-                            if (parts > 1) { m->copy_pool->run(parts, copy); m->copy_pool->wait(); }
-                            else copy(0);
+                            // D blocks of real (not pad) rows, all of them to the process-wide copy threads at once
+                            c25519_host::SharedCopyPool::Range rg[64];
+                            int cntr = 0;
+                            for (int d = 0; d < D && cntr < 64; d++) {
+                                const size_t cnt_d = lo[d + 1] - lo[d];
+                                const size_t real = r0 >= cnt_d ? 0 : (r0 + cnt < cnt_d ? cnt : cnt_d - r0);
+                                if (real) rg[cntr++] = { out + (lo[d] + r0) * elem, (const char*)s2.pinned + cnt * d * elem, real * elem };
+                            }
+                            c25519_host::SharedCopyPool::instance().copy(rg, cntr);
                         }
                         { std::lock_guard<std::mutex> lk(m->slot_mu); s2.busy = false; }
                         m->slot_cv.notify_all();
@@ -508,9 +502,7 @@ int c25519_amd_multi_create(c25519_amd_multi** out, const int* devices, int n_de
         m->drain->start(list[0]);
         m->copier.reset(new Worker());
         m->copier->start(list[0]);
-        // the root's copy-out threads come out of the same CPU budget as the devices' staging helpers (host_pipeline.hpp)
-        m->copy_threads = c25519_host::tunable_or(c25519_host::T_HELPER_THREADS, c25519_host::usable_cpus()) >= 16 + 2 * n_dev ? 4 : 2;
-        m->copy_pool.reset(new c25519_host::HelperPool(m->copy_threads));
+        m->copy_threads = c25519_host::SharedCopyPool::instance().size();   // the process-wide copy threads (host_pipeline.hpp)
         return 0;
     };
     int rc = 0;
@@ -529,7 +521,6 @@ void c25519_amd_multi_destroy(c25519_amd_multi* m)
     for (auto& w : m->worker) w->shutdown();
     if (m->drain) m->drain->shutdown();
     if (m->copier) m->copier->shutdown();
-    m->copy_pool.reset();
     if (!m->dev.empty()) {
         (void)hipSetDevice(m->dev[0]);
         for (hipEvent_t e : m->gathered_ev) (void)hipEventDestroy(e);
@@ -562,8 +553,10 @@ int c25519_amd_multi_device_count(const c25519_amd_multi* m) { return m ? (int)m
 int c25519_amd_multi_helper_threads(const c25519_amd_multi* m)
 {
     if (!m) return 0;
+    // a one-device handle's pipeline parks stagers and drainers of its own; several devices share the process-wide copy
+    // threads (their pipelines' one helper each, like the workers, the drain and the copier thread, only enqueues and waits)
     const int D = (int)m->dev.size();
-    return D * c25519_host::pipeline_helpers(D, m->copy_threads).total() + m->copy_threads;
+    return D == 1 ? c25519_host::pipeline_helpers(1).total() : m->copy_threads;
 }
 
 int c25519_amd_multi_set_gather(c25519_amd_multi* m, int on)
