@@ -21,9 +21,14 @@
 // (lanes 9 / 8,9 wrap into lanes 0 / 0,1 times 19), then one more single-bit pass -- the result is "reduced" in the sense
 // of fe25519.cuh's bound contract, so the formulas' bounds are those tools/fe_bounds.py checks for the batch kernels.
 //
-// Constant time like the batch kernels: no secret-dependent branch or address (the ladder's per-bit choice is a
-// v_cndmask on register values).  Results are the reference's bytes (the final inversion, multiplication and
-// canonical encoding are the batch kernels' own code, run by every lane redundantly).
+// Side channels: no secret-dependent branch anywhere, and in the LADDER no secret-dependent address either (the per-bit choice
+// is a v_cndmask on register values).  The FIXED-BASE walk (sign, key pair, public_fast) fetches table rows from global memory
+// by the secret comb column, exactly as the reference indexes its table (ed25519_sign.c:239-243) and as the batch kernels'
+// wide comb does: which cache lines of the 2 MiB table a call touches depends on the nonce / key (the LDS comb of the batch
+// kernels shows bank conflicts only) -- the reference's own exposure, stated in INTEGRATION.md; a blinding context runs the batch
+// kernels.  The secret-derived LDS contents (operand slots, the fetched rows) are wiped before a kernel returns (wipe()).
+// Results are the reference's bytes (the final inversion, multiplication and canonical encoding are the batch kernels' own
+// code, run by every lane redundantly).
 #pragma once
 #include "fe25519.cuh"
 #include "ge25519.cuh"
@@ -116,6 +121,14 @@ C25519_DEV u32 carry_small(const Lane& L, u64 S)
 {
     const u32 l1 = (u32)(S >> L.w);
     return ((u32)S & L.mask) + row_shr1(l1) + row_ror7(l1) * L.m1;
+}
+
+// zero `words` words of the kernel's LDS (operand forms of secret intermediates, fetched table rows) before it returns
+C25519_DEV void wipe(u32* lds, int words)
+{
+    wave_fence();
+    for (int i = (int)threadIdx.x; i < words; i += 64) lds[i] = 0;
+    wave_fence();
 }
 
 // a value's word offset in LDS for this lane's stores (idle lanes: the dump slot)

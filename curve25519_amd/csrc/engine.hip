@@ -329,6 +329,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
     u32 wds[8];
     fe_to_words(wds, R);
     if (threadIdx.x == 0) store32(out, e, wds);         // written last: `out` may alias `pk`
+    coop::wipe(lds, coop::ROWQ_OFF);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -589,6 +590,7 @@ k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u3
         store32(priv, 2 * e + 1, enc);
         store32(pub, e, enc);
     }
+    coop::wipe(lds, coop::LDS_WORDS);
 }
 
 // curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189): S = clamp(sk) * B on the Edwards side, u = (Z + Y) / (Z - Y)
@@ -618,6 +620,7 @@ k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ 
     coop::get_fe(R, lds, 0);
     fe_to_words(wds, R);
     if (threadIdx.x == 0) store32(pk, e, wds);
+    coop::wipe(lds, coop::LDS_WORDS);
 }
 
 template <bool WIDE>
@@ -641,6 +644,7 @@ k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32*
         store32(sig, 2 * e, enc);
         store32(sig, 2 * e + 1, s);
     }
+    coop::wipe(lds, coop::LDS_WORDS);
 }
 
 // ed25519_Blinding_Init (ed25519_sign.c:289-331) for one context: digest = SHA-512(domain || seed),

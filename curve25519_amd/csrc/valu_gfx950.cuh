@@ -4,11 +4,13 @@
 // these primitives, so the CPU unit tests can run that same source against a C model of them
 // (tests/host_emul/valu_model.h).  This header is the only one with inline assembly.
 //
-// Measured issue classes on MI355X at 8 waves per SIMD (tools/ubench/mad_peak.hip, profiles/r02_mad_peak.txt):
-//   v_mad_u64_u32                      one per 4.0 cycles per SIMD: plain half rate (32x32+64 -> 64, carry-out to an
-//                                      SGPR pair); 4.4-4.5 when every MAD waits for the previous one, as in a column
-//   v_lshrrev_b64 / v_mul_lo_u32 / ... one per 4.0 cycles   ("half-rate" class: shifts, 64-bit, every VOP3 integer op)
-//   v_add_u32 / v_and_b32 / v_sub_u32  one per 2.1-2.3 cycles   ("full-rate" class, VOP2 encodings)
+// Measured issue costs on MI355X, in SIMD cycles per wave-instruction at the kernels' FOUR waves per SIMD (in-kernel s_memtime,
+// tools/ubench/mad_peak.hip, profiles/r04_mad_peak.txt; one wave: ~5.1 for everything, two: 4.5):
+//   v_mad_u64_u32                      4.26 -- 4.0 of execution and a 0.26 issue bubble -- whether the MADs are independent or
+//                                      one dependent column chain (32x32+64 -> 64, carry-out to an SGPR pair)
+//   v_lshrrev_b64 / v_mul_lo_u32 / ... 4.26 (every other VOP3 / 64-bit integer instruction)
+//   v_add_u32 / v_and_b32 / v_sub_u32  2.13 (VOP2 encodings) when ANOTHER wave's VOP2 shares the issue slot, ~4.2 alone between
+//                                      other waves' MADs: hence the low-priority runs below (C25519_VOP2_RUN_*)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
