@@ -1015,8 +1015,8 @@ def test_a_late_rank_does_not_change_the_timed_region():
     for name in ("x25519", "verify", "sign"):
         a = res["0"]["ms_per_step"] if name == "x25519" else res["0"][name]["ms_per_step"]
         b = res["0.5"]["ms_per_step"] if name == "x25519" else res["0.5"][name]["ms_per_step"]
-        # (run-to-run noise of a 20-step block is ~2 %; on the ramp a block reads 10-19 % slow)
-        assert abs(a - b) / a < 0.05, (name, a, b)
+        # (run-to-run noise of a 20-step block is ~2 %; timed on the ramp X25519 reads 11 %, verification 10 %, signing 19 % slow)
+        assert abs(a - b) / a < (0.08 if name == "sign" else 0.06), (name, a, b)
 
 
 def test_small_calls_run_one_operation_per_wave_and_agree_with_the_batch_kernels(api, oracle, monkeypatch):

@@ -35,6 +35,14 @@ if has probe; then                                     # in-kernel s_memtime pro
   timeout 300 python tools/single_call_latency.py > $OUT/single_call.txt 2>&1; timeout 300 python tools/single_call_breakdown.py >> $OUT/single_call.txt 2>&1
   timeout 600 python tools/small_batch_sweep.py > $OUT/small_batch_sweep.txt 2>&1; echo "sweep rc=$?"
 fi
+if has longdiff; then                                  # millions of fresh random operations against the reference's own C code
+  timeout 900 python tests/long_differential.py --rounds ${LD_ROUNDS:-16} --seed ${LD_SEED:-51} > $OUT/long_differential.txt 2>&1; echo "longdiff rc=$?"
+  tail -3 $OUT/long_differential.txt
+fi
+if has virt; then
+  timeout 300 python tools/multi_virtual_rate.py > $OUT/multi_virtual_q4.txt 2>&1; echo "virt rc=$?"
+  GPU_MAX_HW_QUEUES=16 timeout 300 python tools/multi_virtual_rate.py > $OUT/multi_virtual_q16.txt 2>&1; echo "virt16 rc=$?"
+fi
 if has comb; then                                      # A/B of the fixed-base combs, interleaved in one process (tunable BASE_COMB)
   L=curve25519_amd/libcurve25519_amd.so
   timeout 600 python tools/ab_bench.py $L $L@BASE_COMB=1 --ops sign,keypair --rounds ${AB_ROUNDS:-6} > $OUT/ab_base_comb.txt 2>&1
