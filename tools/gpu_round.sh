@@ -45,7 +45,7 @@ if has virt; then
 fi
 if has comb; then                                      # A/B of the fixed-base combs, interleaved in one process (tunable BASE_COMB)
   L=curve25519_amd/libcurve25519_amd.so
-  timeout 600 python tools/ab_bench.py $L $L@BASE_COMB=1 --ops sign,keypair --rounds ${AB_ROUNDS:-6} > $OUT/ab_base_comb.txt 2>&1
+  timeout 600 python tools/ab_bench.py $L@BASE_COMB=0 $L@BASE_COMB=1 --ops sign,keypair --rounds ${AB_ROUNDS:-6} > $OUT/ab_base_comb.txt 2>&1
   echo "comb rc=$?"; cat $OUT/ab_base_comb.txt
 fi
 if has ab && ls build_ab/*.so >/dev/null 2>&1; then
