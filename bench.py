@@ -778,6 +778,12 @@ def main():
         ms = timeit(chk)
         extra["ed25519_verify_check_one_key_per_s"] = round(n / (ms * 1e-3), 1)
         extra["ed25519_verify_check_one_key_all_valid"] = bool(int(ok.sum().item()) == n)
+        # (a big batch under one on-curve key walks two wide combs, the key's built per call: engine.hip,
+        # k_ed25519_verify_check_wide; the reference's own operation order for the same batch, tunable ONE_KEY_WIDE = 0:)
+        with _lib.tunable("ONE_KEY_WIDE", 0):
+            ms = timeit(chk)
+        extra["ed25519_verify_check_one_key_reference_order_per_s"] = round(n / (ms * 1e-3), 1)
+        extra["ed25519_verify_check_one_key_reference_order_all_valid"] = bool(int(ok.sum().item()) == n)
         # BASELINE.json configs[3] AS WORDED ("double-scalar, 4-fold"): every element through the reference's own operation
         # order -- Verify_Init's 16-row 4-fold table per key, then the 4-fold + 8-fold walk and one shared inversion
         # (ed25519_verify.c:179-313) -- instead of the shipped lattice-shortened walk; same verdicts, public data

@@ -905,8 +905,10 @@ struct QTableLds {
 
 __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(ProjScratch scr, const void* sig,
                                                                               const u32* __restrict__ ctx, Msgs msgs,
-                                                                              size_t n, const u32* __restrict__ g_tbl)
+                                                                              size_t n, const u32* __restrict__ g_tbl,
+                                                                              const u32* __restrict__ wide_ok)
 {
+    if (wide_ok && *wide_ok) return;                       // k_ed25519_verify_check_wide decides this batch
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
     __shared__ u32 lds_q[PE_WORDS * 16];
     if (threadIdx.x < 64) {                                // 16 rows x 4 field elements
@@ -927,6 +929,89 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(Pro
     for (int j = 0; j < 8; j++) pkw[j] = ctx[j];
     const QTableLds tbl{ lds_q };
     verify_check_lane(scr, n, i, sig, pkw, msgs, tbl, lds_tbl);
+}
+
+// ---- one key, a big batch: both scalars over wide combs ------------------------------------------------------------------
+// With ONE key for the whole batch the double-scalar product T = s*B + h*(-A) is two FIXED-base products: the base point's
+// wide comb (ge25519.cuh) and one built for -A the same way, walked together -- 39 additions and 4 doublings per signature
+// instead of the reference order's 255 doublings and 95 additions (ed25519_verify.c:243-280).  For a key ON the curve any
+// evaluation of the group law gives the same point T, hence the same enc(T) and the same verdict; so this path decides
+// a batch only when (a) the context is byte for byte what Verify_Init computes for its key bytes (a context is caller
+// storage: one that was written by anything else keeps the kernel above, which reads its rows as they are, like the
+// reference) and (b) the key decompresses onto the curve.  k_ed25519_verify_ctx_prepare establishes both in block 0 -- one
+// lane rebuilds the 16 rows, as Verify_Init did -- while the other blocks generate the key's comb rows (the work of
+// k_gen_wide_table, 0.6 ms); worth it from 2^16 signatures per call (tunable ONE_KEY_WIDE).
+__global__ void __launch_bounds__(128) k_ed25519_verify_ctx_prepare(u32* wide_key /*[WB_NT][WB_ROWS][WB_ROW_WORDS]*/, u32* check_rows /*[16][32]*/,
+                                                                     u32* wide_ok, const u32* __restrict__ ctx)
+{
+    if (blockIdx.x == 0) {
+        if (threadIdx.x != 0) return;
+        u32 pkw[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) pkw[j] = ctx[j];
+        ge_ext Q;
+        u32 yw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) yw[i] = pkw[i];
+        const u32 parity = yw[7] >> 31;
+        yw[7] &= 0x7fffffffu;
+        fe_from_words(Q.Y, yw);
+        const u32 on_curve = ge_calc_x_checked(Q.X, Q.Y, ~parity);     // ed_decode_neg_key, keeping the square root's verdict
+        fe_mul(Q.T, Q.X, Q.Y);
+        fe_set_u32(Q.Z, 1);
+        qtable_build(QTableCanon{ check_rows }, Q);
+        u32 diff = 0;
+        for (int w = 0; w < 16 * 32; w++) diff |= check_rows[w] ^ ctx[8 + w];
+        *wide_ok = (on_curve && diff == 0) ? 1u : 0u;
+        return;
+    }
+    const u32 g = (blockIdx.x - 1) * 128 + threadIdx.x;       // table * WB_ROWS + row
+    const int table = (int)(g / WB_ROWS);
+    // -A in affine precomputed form = row 1 of the context (Verify_Init stores the decompressed key with Z = 1); if the context
+    // is not Verify_Init's, block 0 says so and nobody reads these rows
+    ge_pa P;
+    {
+        u32 w[8];
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) w[j] = ctx[8 + 32 + 8 * f + j];
+            fe_from_words(f == 0 ? P.ypx : f == 1 ? P.ymx : P.t2d, w);
+        }
+    }
+    u32 rows[3][8];
+    ge_signed_comb_row_of(rows, P, g % WB_ROWS, (WB_NT - 1 - table) * WB_STEP, WB_TEETH, WB_COLS);
+    uint4* out = reinterpret_cast<uint4*>(wide_key + (size_t)g * WB_ROW_WORDS);
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        out[2 * f] = make_uint4(rows[f][0], rows[f][1], rows[f][2], rows[f][3]);
+        out[2 * f + 1] = make_uint4(rows[f][4], rows[f][5], rows[f][6], rows[f][7]);
+    }
+    out[6] = out[7] = make_uint4(0, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(WB_BLOCK, 4) k_ed25519_verify_check_wide(ProjScratch scr, const void* sig, const u32* __restrict__ ctx,
+                                                                          Msgs msgs, size_t n, const u32* __restrict__ wide_base,
+                                                                          const u32* __restrict__ wide_key, const u32* __restrict__ wide_ok)
+{
+    if (!*wide_ok) return;                                 // k_ed25519_verify_check_shared decides this batch
+    __shared__ unsigned short cols[2 * WB_COLS * WB_BLOCK];
+    const size_t i = (size_t)blockIdx.x * WB_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u32 pkw[8], Sw[8], h[8], Rw[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) pkw[j] = ctx[j];
+    load32(Rw, sig, 2 * i);
+    ed_hram(h, Rw, pkw, msgs.ptr(i), msgs.len(i));
+    sc_mod(h);
+    load32(Sw, sig, 2 * i + 1);                            // raw 256 bits: no s < L check (ed25519_verify.c:308)
+    unsigned short* cs = cols + threadIdx.x;
+    unsigned short* ch = cols + WB_COLS * WB_BLOCK + threadIdx.x;
+    wb_columns(cs, WB_BLOCK, Sw);                          // s + L when even: L * B = O
+    const u32 h_even = wb_columns<false>(ch, WB_BLOCK, h);    // h + 1 when even: -A may carry torsion, one -A comes off again
+    ge_ext T;                                              // (-A = row 1 of the context, affine: Verify_Init's Z is 1)
+    ge_double_base_mult_wide(T, wide_base, cs, wide_key, ch, WB_BLOCK, h_even, ctx + 8 + 32);
+    store_proj(scr, n, i, T);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1690,12 +1775,30 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
     hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
+    // a big batch under one key: both scalars over wide combs, if the context is Verify_Init's own and the key is on the
+    // curve (k_ed25519_verify_check_wide); decided on the device, the reference-order kernel behind it takes the batch otherwise
+    const bool try_wide = n >= (size_t)c25519_host::tunable_or(c25519_host::T_ONE_KEY_WIDE, 1 << 16) &&
+                          c25519_host::tunable_or(c25519_host::T_ONE_KEY_WIDE, 1) != 0;
+    const size_t extra_words = try_wide ? WB_TBL_WORDS + 16 * 32 + 64 : 0;
     void* w = nullptr;
     c25519_host::WorkLease lease;
-    C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
+    C25519_RC(lease.acquire(&w, (proj_words(n) + extra_words) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
+    u32* wide_ok = nullptr;
+    if (try_wide) {
+        const u32* wide_base = nullptr;
+        C25519_RC(wide_tables(&wide_base));
+        u32* wide_key = (u32*)w + proj_words(n);               // (proj_words is a multiple of 4 words: 16-byte aligned rows)
+        u32* check_rows = wide_key + WB_TBL_WORDS;
+        wide_ok = check_rows + 16 * 32;
+        k_ed25519_verify_ctx_prepare<<<1 + WB_NT * WB_ROWS / 128, 128, 0, stream>>>(wide_key, check_rows, wide_ok, (const u32*)ctx);
+        C25519_TRY(hipGetLastError());
+        k_ed25519_verify_check_wide<<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(
+            scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, wide_base, wide_key, wide_ok);
+        C25519_TRY(hipGetLastError());
+    }
     k_ed25519_verify_check_shared<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
-        scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl);
+        scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl, wide_ok);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
     return lease.release();

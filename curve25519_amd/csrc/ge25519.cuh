@@ -350,16 +350,19 @@ constexpr int WB_ROW_WORDS = 32;                             // one 128-byte lin
 constexpr size_t WB_TBL_WORDS = (size_t)WB_NT * WB_ROWS * WB_ROW_WORDS;    // 2 MiB
 static_assert(WB_NT * WB_STEP == WB_COLS && WB_TEETH * WB_COLS >= 256, "the wide comb covers 256 + bits");
 
-// the 20 columns of k in the order the walk consumes them (s = m * WB_NT + t), 16 bits each, to cols[s * stride]
-template <typename ColT>
-C25519_DEV void wb_columns(ColT* cols, int stride, const u32 (&k)[8])
+// the 20 columns of k in the order the walk consumes them (s = m * WB_NT + t), 16 bits each, to cols[s * stride].
+// The all-digits-+-1 form needs an ODD value.  ADD_L: an even k becomes k + L -- the same multiple of any point of order L
+// (the base point).  !ADD_L, for a point that may carry a torsion component (a public key: L * P != O): an even k becomes
+// k + 1 and the caller takes one P off again (returns all-ones in that case).
+template <bool ADD_L = true, typename ColT>
+C25519_DEV u32 wb_columns(ColT* cols, int stride, const u32 (&k)[8])
 {
     const u32 even = (k[0] & 1u) - 1u;                       // all-ones when k is even
     u32 t[9], w[9];
-    u64 c = 0;
+    u64 c = ADD_L ? 0 : (even & 1u);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        c += (u64)k[i] + (K_L[i] & even);
+        c += (u64)k[i] + (ADD_L ? (K_L[i] & even) : 0u);
         t[i] = (u32)c;
         c >>= 32;
     }
@@ -382,6 +385,7 @@ C25519_DEV void wb_columns(ColT* cols, int stride, const u32 (&k)[8])
             }
             cols[(m * WB_NT + tt) * stride] = (ColT)idx;
         }
+    return even;
 }
 
 // the row a 13-bit column c selects in table `tbl` (4096 packed rows): tooth 12 is the sign
@@ -426,6 +430,56 @@ C25519_DEV void ge_base_mult_wide(ge_ext& S, const u32* __restrict__ g_wide, con
         if (FINAL_T) ge_add_pa_rt(S, q, m == WB_STEP - 1);
         else ge_add_pa<false>(S, q);
     }
+}
+
+// S = s * B + h * P over TWO wide combs walked together -- the base point's and one built for a point P (the two-phase
+// verification's key, -A: engine.hip, k_ed25519_verify_check_wide): 39 additions and the same 4 doublings.  colsB / colsP:
+// the lane's parked columns of s and h (wb_columns, the latter without "+ L": P may have a torsion component);
+// h_was_even: h's columns encode h + 1, so one P comes off at the end (p_words: P's affine precomputed form, fetched then).
+template <typename ColT>
+C25519_DEV void ge_double_base_mult_wide(ge_ext& S, const u32* __restrict__ wideB, const ColT* colsB, const u32* __restrict__ wideP,
+                                         const ColT* colsP, int stride, u32 h_was_even, const u32* __restrict__ p_words /* Y+X | Y-X | 2dT of P, 8 words each */)
+{
+    ge_pa q;
+    wb_load_pa_signed(q, wideB, colsB[0]);
+    ge_from_pa(S, q);
+    wb_load_pa_signed(q, wideP, colsP[0]);
+    C25519_SCHED_FENCE();
+    ge_add_pa<true>(S, q);
+#pragma unroll 1
+    for (int m = 0; m < WB_STEP; m++) {
+        if (m) ge_double(S);
+#pragma unroll 1
+        for (int t = m ? 0 : 1; t < WB_NT; t++) {
+            const size_t off = (size_t)t * WB_ROWS * WB_ROW_WORDS;
+            wb_load_pa_signed(q, wideB + off, colsB[(m * WB_NT + t) * stride]);
+            C25519_SCHED_FENCE();
+            ge_add_pa<true>(S, q);
+            wb_load_pa_signed(q, wideP + off, colsP[(m * WB_NT + t) * stride]);
+            C25519_SCHED_FENCE();
+            ge_add_pa_rt(S, q, t != WB_NT - 1 || m == WB_STEP - 1);   // T where another addition follows (a doubling does not read it)
+        }
+    }
+    // - P if h was even, + O otherwise: one more addition either way (the neutral element's row is (1, 1, 0))
+    fe one, zero, n, f;
+    u32 w[8];
+    fe_set_u32(one, 1);
+    fe_set_u32(zero, 0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = p_words[8 + j];
+    fe_from_words(f, w);
+    fe_select(q.ypx, h_was_even, f, one);                    // -P swaps Y+X and Y-X ...
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = p_words[j];
+    fe_from_words(f, w);
+    fe_select(q.ymx, h_was_even, f, one);
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = p_words[16 + j];
+    fe_from_words(f, w);
+    fe_neg(n, f);                                            // ... and negates 2dxy
+    fe_select(q.t2d, h_was_even, n, zero);
+    C25519_SCHED_FENCE();
+    ge_add_pa<false>(S, q);
 }
 
 // affine canonical words of S: x = X/Z, y = Y/Z   (tail of edp_BasePointMultiply, ed25519_sign.c:265-267)

@@ -226,20 +226,15 @@ C25519_DEV void ge_base_table_row(u32 (&rows)[3][8], u32 k, int extra)
 // 2^extra * (2^(spacing*(teeth-1)) + sum over j < teeth-1 of (bit j of idx ? + : -) 2^(spacing j)) * B, as canonical words
 // of (Y+X, Y-X, 2dT) -- what the signed recodings (ge_base_mult: 8 x 32; the verification walk: SC_TEETH x SC_COLS) select
 // for a column whose top digit is +1
-C25519_DEV void ge_signed_comb_row(u32 (&rows)[3][8], u32 idx, int extra, int teeth = 8, int spacing = 32)
+// ... of ANY point P given in affine precomputed form (ge_signed_comb_row below: the base point; the two-phase
+// verification's per-key comb: -A)
+C25519_DEV void ge_signed_comb_row_of(u32 (&rows)[3][8], const ge_pa& B, u32 idx, int extra, int teeth, int spacing)
 {
-    ge_pa B, Bn;
-    B.ypx = fe_const(K_BY); B.ymx = fe_const(K_BY);
-    {
-        fe t;
-        fe_add(t, B.ypx, fe_const(K_BX)); fe_carry32(B.ypx, t);
-        fe_sub(t, B.ymx, fe_const(K_BX)); fe_carry32(B.ymx, t);
-    }
-    B.t2d = fe_const(K_BT2D);
-    Bn.ypx = B.ymx; Bn.ymx = B.ypx;                          // -B
+    ge_pa Bn;
+    Bn.ypx = B.ymx; Bn.ymx = B.ypx;                          // -P
     { fe t; fe_neg(t, B.t2d); fe_carry32(Bn.t2d, t); }
 
-    ge_ext S;                                                // top tooth: + B
+    ge_ext S;                                                // top tooth: + P
     fe_set_u32(S.X, 0); fe_set_u32(S.Y, 1); fe_set_u32(S.Z, 1); fe_set_u32(S.T, 0);
     ge_add_pa(S, B);
 #pragma unroll 1
@@ -261,6 +256,19 @@ C25519_DEV void ge_signed_comb_row(u32 (&rows)[3][8], u32 idx, int extra, int te
     fe_mul(row[2], t, fe_const(K_2D));
 #pragma unroll
     for (int f = 0; f < 3; f++) fe_to_words(rows[f], row[f]);
+}
+
+C25519_DEV void ge_signed_comb_row(u32 (&rows)[3][8], u32 idx, int extra, int teeth = 8, int spacing = 32)
+{
+    ge_pa B;
+    B.ypx = fe_const(K_BY); B.ymx = fe_const(K_BY);
+    {
+        fe t;
+        fe_add(t, B.ypx, fe_const(K_BX)); fe_carry32(B.ypx, t);
+        fe_sub(t, B.ymx, fe_const(K_BX)); fe_carry32(B.ymx, t);
+    }
+    B.t2d = fe_const(K_BT2D);
+    ge_signed_comb_row_of(rows, B, idx, extra, teeth, spacing);
 }
 
 // ed25519_Blinding_Init (ed25519_sign.c:289-331) for one context: digest = SHA-512(domain || seed),

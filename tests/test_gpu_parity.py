@@ -442,6 +442,78 @@ def test_two_phase_verification(api, oracle):
                               oracle.ed25519_verify(gs, np.repeat(gp[k:k + 1], 256, axis=0), gm))
 
 
+def test_one_key_batches_walk_two_wide_combs_with_the_reference_verdicts(api, oracle):
+    """ed25519_Verify_Check over a BIG batch under one key (the reference's amortisation: Verify_Init once, many Verify_Check,
+    ed25519_verify.c:282-286) evaluates T = s*B + h*(-A) over two wide fixed-base combs -- the base point's and one built for
+    -A on the spot (k_ed25519_verify_ctx_prepare / _check_wide) -- when the context is Verify_Init's own and the key is on
+    the curve; any other context keeps the reference-order kernel.  Same verdicts as that kernel (tunable ONE_KEY_WIDE = 0) and
+    as the oracle for: honest keys with corrupted entries and S + L; every small-order key (torsion: an even h must not
+    become h + L) with the degenerate-but-valid vectors the real reference accepts for it; a mixed-order key; an off-curve
+    key; a context with one byte changed (which the reference-order kernel reads as it is)."""
+    from curve25519_amd import _lib
+    import vectors
+    n = (1 << 16) + 37
+    rng_sig, rng_msg = synth.random_bytes((n, 64), 0x7301), synth.random_bytes((n, 24), 0x7302)
+    d = np.load(os.path.join(GOLD, "degenerate_verify.npz"))
+    dsig, dpk, dmsg, dver = (np.ascontiguousarray(d[k]) for k in ("sig", "pk", "msg", "verdict"))
+
+    def both_paths(ctx, sig, msg):
+        wide = api.ed25519_Verify_Check(ctx, sig, msg)
+        with _lib.tunable("ONE_KEY_WIDE", 0):
+            ref_order = api.ed25519_Verify_Check(ctx, sig, msg)
+        assert np.array_equal(wide, ref_order), int((wide != ref_order).sum())
+        return wide
+
+    # honest keys
+    sk = synth.random_bytes((2, 32), 0x7303)
+    pub, priv = oracle.ed25519_keypair(sk)
+    ctx = api.ed25519_Verify_Init(pub)
+    for k in range(2):
+        msg = rng_msg.copy()
+        sig = oracle.ed25519_sign(np.repeat(priv[k:k + 1], n, axis=0), msg, threads=THREADS)
+        sig[::7, 3] ^= 0x20
+        msg[1::7, 23] ^= 1
+        sig[2::7, 33] ^= 2
+        for i in range(3, 600, 7):                                      # S + L: accepted by the reference
+            S = int.from_bytes(sig[i, 32:].tobytes(), "little")
+            if S + vectors.L < 2**256:
+                sig[i, 32:] = vectors.le(S + vectors.L, 32)
+        got = both_paths(ctx[k], sig, msg)
+        assert np.array_equal(got, oracle.ed25519_verify(sig, np.repeat(pub[k:k + 1], n, axis=0), msg, threads=THREADS))
+        assert n // 2 < got.sum() < n
+    # small-order and mixed-order keys: every degenerate vector of the fixture (8-byte messages) under its own key, inside a
+    # batch of garbage signatures for that key -- the real reference's verdicts where the fixture has them, the oracle's elsewhere
+    sig8, msg8 = synth.random_bytes((n, 64), 0x7304), synth.random_bytes((n, dmsg.shape[1]), 0x7305)
+    valid_seen = 0
+    for key in np.unique(dpk, axis=0):
+        at = np.nonzero((dpk == key).all(axis=1))[0]
+        sig, msg = sig8.copy(), msg8.copy()
+        pos = np.arange(len(at)) * 13 + 5
+        sig[pos], msg[pos] = dsig[at], dmsg[at]
+        cx = api.ed25519_Verify_Init(key.reshape(1, 32))[0]
+        got = both_paths(cx, sig, msg)
+        assert np.array_equal(got[pos], dver[at]), key.tobytes().hex()
+        assert np.array_equal(got, oracle.ed25519_verify(sig, np.repeat(key.reshape(1, 32), n, axis=0), msg, threads=THREADS)), key.tobytes().hex()
+        valid_seen += int(dver[at].sum())
+    assert valid_seen == int(dver.sum()) > 300
+    # an off-curve key, and a context somebody wrote into: the reference-order kernel decides, reading the rows as they are
+    off = next(k for k in synth.random_bytes((64, 32), 0x999) if vectors.ed_decode(int.from_bytes(k.tobytes(), "little") & (2**255 - 1), 0) is None)
+    cx = api.ed25519_Verify_Init(off.reshape(1, 32))[0]
+    got = both_paths(cx, rng_sig, rng_msg)
+    assert np.array_equal(got, oracle.ed25519_verify(rng_sig, np.repeat(off.reshape(1, 32), n, axis=0), rng_msg, threads=THREADS))
+    msg = rng_msg.copy()
+    sig = oracle.ed25519_sign(np.repeat(priv[:1], n, axis=0), msg, threads=THREADS)
+    tampered = ctx[0].copy()
+    tampered[32 + 128 * 5 + 7] ^= 0x40                                   # one byte of row 5
+    honest = both_paths(ctx[0], sig, msg)
+    assert honest.all()
+    bent = both_paths(tampered, sig, msg)
+    assert not bent.all()                                                # about one signature in sixteen meets row 5 with a nonzero ... and fails
+    # small batches stay on the reference-order kernel unless asked (ONE_KEY_WIDE = 1: every batch)
+    with _lib.tunable("ONE_KEY_WIDE", 1):
+        assert np.array_equal(api.ed25519_Verify_Check(ctx[0], sig[:300], msg[:300]), honest[:300])
+
+
 def test_concurrent_host_threads(api, oracle):
     """The shim is re-entrant like the reference (SURVEY.md 8(b) Threading): host threads calling the batch API
     at the same time each get their own stream, staging buffers and scratch."""
@@ -908,6 +980,48 @@ def test_multi_device_code_with_eight_virtual_devices(api, gather_mode):
             assert np.array_equal(shared, R1024["x_shared"][:n])
         finally:
             L.c25519_amd_multi_destroy(h)
+
+
+def test_two_multi_handles_in_two_threads_share_the_copy_threads(api):
+    """Two *_multi handles (three and two virtual devices) driven from two host threads at the same time: five pipelines, two
+    gathers and two hand-overs feed ONE process-wide pool of copy threads (host_pipeline.hpp: SharedCopyPool) -- every call
+    still gets its own bytes (the fixture's, i.e. the reference's), whichever thread's chunks the pool serves first."""
+    import threading
+    from curve25519_amd import _lib
+    L = _lib.load()
+    n = (1 << 17) + 3
+    sk, pk = synth.x25519_inputs(n)
+    esk, msg = synth.ed25519_inputs(n)
+    pub, priv = api.ed25519_CreateKeyPair(esk)
+    exp_shared, exp_sk = api.curve25519_dh_CreateSharedKey(pk, sk)
+    exp_sig = api.ed25519_SignMessage(priv, msg)
+    errors = []
+
+    def run(D, which):
+        try:
+            h = C.c_void_p()
+            _lib.check(L.c25519_amd_multi_create(C.byref(h), (C.c_int * D)(*([0] * D)), D), "create")
+            try:
+                for rep in range(3):
+                    if which == "x25519":
+                        out, s2 = np.zeros((n, 32), np.uint8), sk.copy()
+                        _lib.check(L.curve25519_dh_CreateSharedKey_multi(h, out.ctypes.data, pk.ctypes.data, s2.ctypes.data, n), "x25519 multi")
+                        assert np.array_equal(out, exp_shared) and np.array_equal(s2, exp_sk), (D, rep)
+                    else:
+                        out = np.zeros((n, 64), np.uint8)
+                        _lib.check(L.ed25519_SignMessage_multi(h, out.ctypes.data, priv.ctypes.data, msg.ctypes.data, 32, n), "sign multi")
+                        assert np.array_equal(out, exp_sig), (D, rep)
+            finally:
+                L.c25519_amd_multi_destroy(h)
+        except BaseException as e:            # noqa: B902 -- carried to the main thread
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=run, args=(3, "x25519")), threading.Thread(target=run, args=(2, "sign"))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=240)
+    assert not errors and not any(t.is_alive() for t in ts), errors
 
 
 def test_host_pointer_api_keeps_up_with_the_device_rate(api):
