@@ -82,7 +82,8 @@ std::vector<u32> g_wide;
 std::once_flag g_wide_once;
 int g_base_comb = 0;                    // emul_set_base_comb: 1 = the fixed-base operations below walk the wide comb
 
-void build_wide()
+// the four packed tables of the wide comb of ANY point given in affine precomputed form
+void build_wide_of(std::vector<u32>& g_wide, const ge_pa& b)
 {
     g_wide.assign(WB_TBL_WORDS, 0);
     for (int table = 0; table < WB_NT; table++) {
@@ -90,10 +91,6 @@ void build_wide()
         // P[j] = 2^(20 j + extra) B, j = 0 .. 12
         ge_ext P[WB_TEETH];
         {
-            u32 rows[3][8];
-            ge_base_table_row(rows, 1, 0);                           // B as (y+x, y-x, 2dxy)
-            ge_pa b;
-            fe_from_words(b.ypx, rows[0]); fe_from_words(b.ymx, rows[1]); fe_from_words(b.t2d, rows[2]);
             ge_from_pa(P[0], b);
             for (int j = 0; j < extra; j++) ge_double(P[0]);
             for (int j = 1; j < WB_TEETH; j++) {
@@ -146,6 +143,15 @@ void build_wide()
             for (int f = 0; f < 3; f++) { u32 w[8]; fe_to_words(w, row[f]); memcpy(out + 8 * f, w, 32); }
         }
     }
+}
+
+void build_wide()
+{
+    u32 rows[3][8];
+    ge_base_table_row(rows, 1, 0);                                   // B as (y+x, y-x, 2dxy)
+    ge_pa b;
+    fe_from_words(b.ypx, rows[0]); fe_from_words(b.ymx, rows[1]); fe_from_words(b.t2d, rows[2]);
+    build_wide_of(g_wide, b);
 }
 
 const u32* wide_tables()
@@ -484,6 +490,49 @@ void emul_lattice_waves(unsigned char* rho_out, unsigned char* tau_out, int* tau
         pthread_mutex_destroy(&w.mu);
         pthread_cond_destroy(&w.cv);
     }
+}
+
+// ed25519_Verify_Check over two wide combs (engine.hip: k_ed25519_verify_ctx_prepare / k_ed25519_verify_check_wide), one
+// key for the batch: the key's comb built here with one addition per row, then per signature the kernel's lane code.
+// Returns 1 if the path applies (key on the curve), 0 otherwise (verdicts untouched: the reference-order kernel's batch).
+int emul_ed25519_verify_check_wide(int* verdict, const unsigned char* sig, const unsigned char* pk, const unsigned char* msg, size_t len,
+                                   size_t n)
+{
+    u32 pkw[8], yw[8];
+    rd32(pkw, pk, 0);
+    for (int i = 0; i < 8; i++) yw[i] = pkw[i];
+    const u32 parity = yw[7] >> 31;
+    yw[7] &= 0x7fffffffu;
+    ge_ext Q;
+    fe_from_words(Q.Y, yw);
+    if (!ge_calc_x_checked(Q.X, Q.Y, ~parity)) return 0;
+    fe_mul(Q.T, Q.X, Q.Y);
+    fe_set_u32(Q.Z, 1);
+    ge_pe pe;
+    ge_to_pe(pe, Q);                                                 // row 1 of the context: -A, Z = 1
+    u32 row1[24];
+    { u32 w[8]; fe_to_words(w, pe.ypx); memcpy(row1, w, 32); fe_to_words(w, pe.ymx); memcpy(row1 + 8, w, 32); fe_to_words(w, pe.t2d); memcpy(row1 + 16, w, 32); }
+    ge_pa P;
+    { u32 w[8]; memcpy(w, row1, 32); fe_from_words(P.ypx, w); memcpy(w, row1 + 8, 32); fe_from_words(P.ymx, w); memcpy(w, row1 + 16, 32); fe_from_words(P.t2d, w); }
+    std::vector<u32> wide_key;
+    build_wide_of(wide_key, P);
+    for (size_t i = 0; i < n; i++) {
+        u32 Rw[8], Sw[8], h[8], enc[8];
+        rd32(Rw, sig, 2 * i);
+        rd32(Sw, sig, 2 * i + 1);
+        ed_hram(h, Rw, pkw, msg + len * i, len);
+        sc_mod(h);
+        unsigned short cs[WB_COLS], ch[WB_COLS];
+        wb_columns(cs, 1, Sw);
+        const u32 h_even = wb_columns<false>(ch, 1, h);
+        ge_ext T;
+        ge_double_base_mult_wide(T, wide_tables(), cs, wide_key.data(), ch, 1, h_even, row1);
+        affine_pack_host(enc, T);
+        u32 diff = 0;
+        for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
+        verdict[i] = diff == 0;
+    }
+    return 1;
 }
 
 // ed25519_Verify_Init: the 2080-byte context (pk || 16 canonical rows)

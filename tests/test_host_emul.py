@@ -246,3 +246,50 @@ def test_wide_fixed_base_comb(dev, emul):
         assert np.array_equal(dev.sign(g["ed_priv"][:48], g["ed_msg"][:48], blinding=ctx), g["ed_sig"][:48])
     finally:
         emul.emul_set_base_comb(0)
+
+
+def test_one_key_verification_over_two_wide_combs(dev, emul, oracle):
+    """The device source of the two-phase fast path (engine.hip: k_ed25519_verify_check_wide; ge25519.cuh:
+    ge_double_base_mult_wide, wb_columns<false>) on the CPU model: T = s*B + h*(-A) over the base point's wide comb and one
+    built for the key, against the reference-order emulation and the oracle -- an honest key with corrupted entries and
+    S + L, every small-order key with garbage and with the degenerate vectors the real reference accepts (an even h must
+    become h + 1 with one -A taken off again, never h + L: a small-order key is all torsion), and an off-curve key, which
+    the path must decline."""
+    emul.emul_ed25519_verify_check_wide.argtypes = [vp, vp, vp, vp, sz, sz]
+    emul.emul_ed25519_verify_check_wide.restype = C.c_int
+
+    def wide(sig, key, msg):
+        ok = np.full(sig.shape[0], -1, np.int32)
+        msg = np.ascontiguousarray(msg)
+        applies = emul.emul_ed25519_verify_check_wide(ptr(ok), ptr(np.ascontiguousarray(sig)), ptr(np.ascontiguousarray(key)),
+                                                      ptr(msg), msg.shape[1], sig.shape[0])
+        return applies, ok
+
+    n = 96
+    sk, msg = synth.random_bytes((1, 32), 0xC701), synth.random_bytes((n, 19), 0xC702)
+    pub, priv = dev.keypair(sk)
+    sig = dev.sign(np.repeat(priv, n, axis=0), msg)
+    sig[::7, 3] ^= 0x20
+    msg[1::7, 18] ^= 1
+    for i in range(2, n, 7):
+        S = int.from_bytes(sig[i, 32:].tobytes(), "little") + vectors.L
+        if S < 2**256:
+            sig[i, 32:] = vectors.le(S, 32)
+    keys = np.repeat(pub, n, axis=0)
+    applies, ok = wide(sig, pub, msg)
+    assert applies == 1 and np.array_equal(ok, dev.verify(sig, keys, msg)) and np.array_equal(ok, oracle.ed25519_verify(sig, keys, msg))
+    assert 0 < ok.sum() < n
+    d = np.load(os.path.join(GOLD, "degenerate_verify.npz"))
+    seen = 0
+    for key in np.unique(d["pk"], axis=0)[::3]:
+        at = np.nonzero((d["pk"] == key).all(axis=1))[0][:40]
+        gs, gm = synth.random_bytes((16, 64), 0xC703), synth.random_bytes((16, d["msg"].shape[1]), 0xC704)
+        s2, m2 = np.concatenate([d["sig"][at], gs]), np.concatenate([d["msg"][at], gm])
+        applies, ok = wide(s2, key.reshape(1, 32), m2)
+        assert applies == 1, key.tobytes().hex()
+        assert np.array_equal(ok[: len(at)], d["verdict"][at]), key.tobytes().hex()
+        assert np.array_equal(ok, oracle.ed25519_verify(s2, np.repeat(key.reshape(1, 32), len(s2), axis=0), m2))
+        seen += int(d["verdict"][at].sum())
+    assert seen > 20
+    off = next(k for k in synth.random_bytes((64, 32), 0x999) if vectors.ed_decode(int.from_bytes(k.tobytes(), "little") & (2**255 - 1), 0) is None)
+    assert wide(sig, off.reshape(1, 32), msg)[0] == 0
