@@ -183,6 +183,8 @@ struct ThreadState {
     unsigned long work_clock = 0;
     unsigned long generation = 0;          // bumped whenever streams / slabs / report words are destroyed: a handle to one of
                                            // them remembered across calls (engine.hip: LastVerify) is stale afterwards
+    WorkSlab keep[MAX_DEV];                // per device: a buffer whose CONTENT outlives the call (the comb of the last one-key
+                                           // verification batch's key, engine.hip); same stream-order rules as a work slab
     WorkSlab lane_work[LANES];             // ... and one per pipeline lane, so that the pieces of a *_batch call do not
                                            // wait for each other's kernels (they belong to the staging device)
 
@@ -281,6 +283,40 @@ struct ThreadState {
         *out = w.ptr;
         return 0;
     }
+    // the persistent buffer of the current device, at least `bytes` (zero-filled when it is (re)allocated: *fresh says so);
+    // a call on another stream than the last one first waits for that one's use (release_keep)
+    int acquire_keep(void** out, size_t bytes, hipStream_t s, bool* fresh)
+    {
+        int dev = 0;
+        C25519_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= MAX_DEV) return bad_arg("device ordinal out of range");
+        arm_exit_guard();
+        WorkSlab& w = keep[dev];
+        *fresh = false;
+        if (w.ptr && bytes > w.cap) {
+            C25519_TRY(hipDeviceSynchronize());
+            C25519_TRY(hipFree(w.ptr));
+            w.ptr = nullptr; w.cap = 0; w.used = false;
+        }
+        if (!w.ptr) {
+            C25519_TRY(hipMalloc(&w.ptr, bytes));
+            C25519_TRY(hipMemset(w.ptr, 0, bytes));
+            w.cap = bytes;
+            *fresh = true;
+        }
+        if (!w.done) C25519_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+        if (w.used && s != w.last) C25519_TRY(hipStreamWaitEvent(s, w.done, 0));
+        w.last = s; w.used = true;
+        *out = w.ptr;
+        return 0;
+    }
+    int release_keep(hipStream_t s)
+    {
+        int dev = 0;
+        C25519_TRY(hipGetDevice(&dev));
+        C25519_TRY(hipEventRecord(keep[dev].done, s));
+        return 0;
+    }
     // the report word of the slab acquire_work(…, s) handed out (call between acquire_work and release_work)
     int report_word_for(unsigned** out, hipStream_t s)
     {
@@ -343,10 +379,12 @@ struct ThreadState {
         for (int d = 0; d < MAX_DEV; d++) {
             bool any = false;
             for (const WorkSlab& w : work[d]) any = any || w.ptr || w.done || w.report;
+            any = any || keep[d].ptr || keep[d].done;
             if (!any) continue;
             (void)hipSetDevice(d);
             (void)hipDeviceSynchronize();
             for (WorkSlab& w : work[d]) free_slab(w);
+            free_slab(keep[d]);
         }
         (void)hipGetLastError();
         if (cur >= 0) (void)hipSetDevice(cur);

@@ -941,9 +941,24 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(Pro
 // reference) and (b) the key decompresses onto the curve.  k_ed25519_verify_ctx_prepare establishes both in block 0 -- one
 // lane rebuilds the 16 rows, as Verify_Init did -- while the other blocks generate the key's comb rows (the work of
 // k_gen_wide_table, 0.6 ms); worth it from 2^16 signatures per call (tunable ONE_KEY_WIDE).
+// `remembered` (KEEP_CTX_WORDS + 1 words behind the key's comb, in a buffer that outlives the call): the context the comb was
+// built for and a state word -- 0 nothing yet, 1 remembered but not eligible, 2 remembered and eligible.  The reference's use is
+// ONE Verify_Init and MANY Verify_Check calls (ed25519_verify.c:282-286): a call whose context equals the remembered bytes skips
+// all of the preparation (every block finds that out for itself: 2080 bytes out of L2); k_ed25519_verify_ctx_remember, behind
+// this kernel on the stream, writes the bytes down.
+constexpr int KEEP_CTX_WORDS = 2080 / 4;
 __global__ void __launch_bounds__(128) k_ed25519_verify_ctx_prepare(u32* wide_key /*[WB_NT][WB_ROWS][WB_ROW_WORDS]*/, u32* check_rows /*[16][32]*/,
-                                                                     u32* wide_ok, const u32* __restrict__ ctx)
+                                                                     u32* wide_ok, const u32* __restrict__ ctx,
+                                                                     const u32* __restrict__ remembered)
 {
+    {
+        int same = remembered[KEEP_CTX_WORDS] != 0;
+        for (int w = threadIdx.x; w < KEEP_CTX_WORDS; w += 128) same = same && remembered[w] == ctx[w];
+        if (__syncthreads_and(same)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) *wide_ok = remembered[KEEP_CTX_WORDS] == 2 ? 1u : 0u;
+            return;
+        }
+    }
     if (blockIdx.x == 0) {
         if (threadIdx.x != 0) return;
         u32 pkw[8];
@@ -988,6 +1003,12 @@ __global__ void __launch_bounds__(128) k_ed25519_verify_ctx_prepare(u32* wide_ke
         out[2 * f + 1] = make_uint4(rows[f][4], rows[f][5], rows[f][6], rows[f][7]);
     }
     out[6] = out[7] = make_uint4(0, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(128) k_ed25519_verify_ctx_remember(u32* remembered, const u32* __restrict__ ctx, const u32* __restrict__ wide_ok)
+{
+    for (int w = threadIdx.x; w < KEEP_CTX_WORDS; w += 128) remembered[w] = ctx[w];
+    if (threadIdx.x == 0) remembered[KEEP_CTX_WORDS] = 1u + (*wide_ok ? 1u : 0u);
 }
 
 __global__ void __launch_bounds__(WB_BLOCK, 4) k_ed25519_verify_check_wide(ProjScratch scr, const void* sig, const u32* __restrict__ ctx,
@@ -1779,19 +1800,27 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
     // curve (k_ed25519_verify_check_wide); decided on the device, the reference-order kernel behind it takes the batch otherwise
     const bool try_wide = n >= (size_t)c25519_host::tunable_or(c25519_host::T_ONE_KEY_WIDE, 1 << 16) &&
                           c25519_host::tunable_or(c25519_host::T_ONE_KEY_WIDE, 1) != 0;
-    const size_t extra_words = try_wide ? WB_TBL_WORDS + 16 * 32 + 64 : 0;
     void* w = nullptr;
     c25519_host::WorkLease lease;
-    C25519_RC(lease.acquire(&w, (proj_words(n) + extra_words) * sizeof(u32), stream));
+    C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     u32* wide_ok = nullptr;
     if (try_wide) {
         const u32* wide_base = nullptr;
         C25519_RC(wide_tables(&wide_base));
-        u32* wide_key = (u32*)w + proj_words(n);               // (proj_words is a multiple of 4 words: 16-byte aligned rows)
+        // the key's comb, the context it was built for and the verdict on that context live in a buffer of the calling thread
+        // that outlives the call (ThreadState::keep): the next call with the same context bytes finds them there
+        void* keep = nullptr;
+        bool fresh = false;
+        constexpr size_t KEEP_WORDS = WB_TBL_WORDS + 16 * 32 + KEEP_CTX_WORDS + 1 + 3 + 4;
+        C25519_RC(tls().acquire_keep(&keep, KEEP_WORDS * sizeof(u32), stream, &fresh));
+        u32* wide_key = (u32*)keep;
         u32* check_rows = wide_key + WB_TBL_WORDS;
-        wide_ok = check_rows + 16 * 32;
-        k_ed25519_verify_ctx_prepare<<<1 + WB_NT * WB_ROWS / 128, 128, 0, stream>>>(wide_key, check_rows, wide_ok, (const u32*)ctx);
+        u32* remembered = check_rows + 16 * 32;
+        wide_ok = remembered + KEEP_CTX_WORDS + 1 + 3;         // (its own 16 bytes)
+        k_ed25519_verify_ctx_prepare<<<1 + WB_NT * WB_ROWS / 128, 128, 0, stream>>>(wide_key, check_rows, wide_ok, (const u32*)ctx, remembered);
+        C25519_TRY(hipGetLastError());
+        k_ed25519_verify_ctx_remember<<<1, 128, 0, stream>>>(remembered, (const u32*)ctx, wide_ok);
         C25519_TRY(hipGetLastError());
         k_ed25519_verify_check_wide<<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(
             scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, wide_base, wide_key, wide_ok);
@@ -1801,6 +1830,7 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
         scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl, wide_ok);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
+    if (try_wide) C25519_RC(tls().release_keep(stream));     // (the shared kernel reads wide_ok out of the kept buffer too)
     return lease.release();
 }
 

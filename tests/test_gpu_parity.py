@@ -509,6 +509,30 @@ def test_one_key_batches_walk_two_wide_combs_with_the_reference_verdicts(api, or
     assert honest.all()
     bent = both_paths(tampered, sig, msg)
     assert not bent.all()                                                # about one signature in sixteen meets row 5 with a nonzero ... and fails
+    # the key's comb is remembered between calls (one Verify_Init, many Verify_Check): the same context again, another key in
+    # between, the first one again, a tampered copy of the remembered context -- each call gets its own key's verdicts
+    sig_b = oracle.ed25519_sign(np.repeat(priv[1:2], n, axis=0), msg, threads=THREADS)
+    for cx, sg, want_all in ((ctx[0], sig, True), (ctx[0], sig, True), (ctx[1], sig_b, True), (ctx[1], sig, False), (ctx[0], sig, True),
+                             (tampered, sig, False), (ctx[0], sig, True)):
+        got = api.ed25519_Verify_Check(cx, sg, msg)
+        assert bool(got.all()) == want_all and (want_all or got.sum() < n // 8)
+    # ... and on two streams of one thread, two keys alternating, nothing synchronised in between (the kept buffer follows the
+    # work slabs' stream-order rule)
+    import torch
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    d_ctx, d_sig, d_msg = [up(ctx[0]), up(ctx[1])], [up(sig), up(sig_b)], up(msg)
+    outs = [torch.full((n, 1), -1, dtype=torch.int32, device=dev) for _ in range(6)]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    torch.cuda.synchronize()
+    L = _lib.load()
+    for j in range(6):
+        k = j & 1
+        _lib.check(L.ed25519_Verify_Check_dev(C.c_void_p(outs[j].data_ptr()), C.c_void_p(d_ctx[k].data_ptr()), C.c_void_p(d_sig[k].data_ptr()),
+                                              C.c_void_p(d_msg.data_ptr()), msg.shape[1], n, C.c_void_p(streams[(j // 2) & 1].cuda_stream)),
+                   "ed25519_Verify_Check_dev")
+    torch.cuda.synchronize()
+    assert all(bool((o == 1).all().item()) for o in outs)
     # small batches stay on the reference-order kernel unless asked (ONE_KEY_WIDE = 1: every batch)
     with _lib.tunable("ONE_KEY_WIDE", 1):
         assert np.array_equal(api.ed25519_Verify_Check(ctx[0], sig[:300], msg[:300]), honest[:300])
