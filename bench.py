@@ -747,6 +747,10 @@ def main():
 
         def timeit(fn, reps=5):
             fn(); torch.cuda.synchronize()
+            w0 = time.perf_counter()                  # the clock ramp of run_timed, for the same reason
+            while time.perf_counter() - w0 < CLOCK_RAMP_S:
+                fn()
+                torch.cuda.synchronize()
             tot = 0.0
             for _ in range(reps):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
