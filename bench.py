@@ -732,6 +732,9 @@ def main():
                                                           if use_dist else "")},
             "roofline": roof, "timing": primary.get("timing"),
         }
+        for k in ("rejected", "rejects_exactly_the_corrupted"):        # --workload verify: the primary pass's own check
+            if k in primary:
+                result[k] = primary[k]
         if primary.get("per_rank"):
             result["per_rank"] = primary["per_rank"]
         if wl == "mixed" and parts[0].get("per_rank"):
