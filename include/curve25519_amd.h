@@ -149,7 +149,13 @@ size_t ed25519_VerifySignature_scratch_bytes(size_t n);
  * 4-fold table of 2^(64i)*(-A) subset sums, four canonical 32-byte field elements per row.
  *   Verify_Init_batch / _dev : n keys -> n contexts (n x 2080 bytes)
  *   Verify_Check_batch / _dev: ONE context, n (signature, message) pairs -> n verdicts; this is the
- *                              amortised path, the per-key table is staged in LDS. */
+ *                              amortised path, the per-key table is staged in LDS.  From 2^16 pairs per call (tunable
+ *                              ONE_KEY_WIDE) a context that is byte for byte Verify_Init's, for a key on the curve, is
+ *                              verified over two wide fixed-base combs instead -- the base point's and one generated for the
+ *                              key (0.6 ms; kept, with the context it belongs to, in 2 MiB of device memory per calling
+ *                              thread until the thread exits or calls c25519_amd_thread_release(), so the next call with
+ *                              the same context skips it): the same verdicts at 2.6 x the rate; any other context keeps
+ *                              the first kernel, which reads the context's rows as they are, as the reference does. */
 int ed25519_Verify_Init_batch(void *ctx, const unsigned char *pk, size_t n);
 int ed25519_Verify_Init_dev(void *ctx, const void *pk, size_t n, void *stream);
 int ed25519_Verify_Check_batch(int *verdict, const void *ctx, const unsigned char *sig,
