@@ -42,8 +42,8 @@ constexpr int SLOT_WORDS = 80;
 constexpr int A_OFF = 0, YO_OFF = 16, YE_OFF = 48;
 // slots: 0-3 / 4-7 the two values a row may publish per phase, 8 the base point's x (stays for the whole ladder),
 // 9 the constant 1, 10 a dump for the six idle lanes of a row, 11 where a whole element is laid down for my_limb,
-// 12 the constant 1 / (2d) of the fixed-base walk's starting point
-constexpr int SLOT_X1 = 8, SLOT_ONE = 9, SLOT_DUMP = 10, SLOT_TMP = 11, SLOT_KDI = 12, NSLOTS = 13;
+// 12 the constant 1 / (2d) of the fixed-base walk's starting point, 13 the constant 2d (window-table rows)
+constexpr int SLOT_X1 = 8, SLOT_ONE = 9, SLOT_DUMP = 10, SLOT_TMP = 11, SLOT_KDI = 12, SLOT_K2D = 13, NSLOTS = 14;
 // ... and, behind the slots, the 32 table-row limbs a lane has fetched for the fixed-base walk (word j of lane l at j * 64 + l)
 constexpr int ROWQ_OFF = NSLOTS * SLOT_WORDS, LDS_WORDS = ROWQ_OFF + 32 * 64;
 
@@ -498,16 +498,56 @@ C25519_DEV u32 comb_limb_for_add(const u32* __restrict__ tbl, const Lane& L, u32
     return (f == 2 && neg) ? L.p2 - wd : wd;
 }
 
+// The window table of ONE point -- rows 0 .. 8 times P in precomputed form (Y+X, Y-X, 2dT, 2Z), what wtable_build
+// (verify_fast.cuh) packs into global memory one lane at a time -- built by the whole wave straight into the LDS multiplier
+// forms the walk reads (slots VSLOT0 + (t * WTABLE_ROWS + r) * 4 + f): the same points by the same chain of doublings and "+ P"
+// (2P, 3P, 4P = 2 (2P), 5P, 6P = 2 (3P), 7P, 8P = 2 (4P)), two product levels per operation and one per row for the
+// conversion (2d T is a product; the other three fields ride the level times one, for its carry).  xl, yl: limb L.c of the
+// point's affine x and y (the same in every row).  SLOT_ONE must hold one.
+C25519_DEV void wtable_build_lds(u32* lds, const Lane& L, int t, u32 xl, u32 yl)
+{
+    const u32 one = L.c == 0 ? 1u : 0u;
+    put_y(lds, L, SLOT_K2D, my_limb(lds, L, fe_const(K_2D)));
+    const int base = VSLOT0 + t * WTABLE_ROWS * 4;
+    auto store_row = [&](int r, u32 v) {
+        u32 ev, od;
+        pair_exchange(ev, od, v);                         // lower pair: X, Y; upper pair: Z, T
+        const u32 val = L.upper ? (L.odd_row ? od : ev + ev) : (L.odd_row ? od + L.p2 - ev : ev + od);
+        put_a(lds, L, L.row, val);                        // Y+X, Y-X, 2Z, T
+        const u32 w = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, SLOT_K2D));
+        put_y(lds, L, base + r * 4 + by_row(L, 0, 1, 3, 2), w);          // fields: ypx, ymx, t2d, z2
+    };
+    // row 0, the neutral element: (1, 1, 0, 2)
+    put_y(lds, L, base + by_row(L, 0, 1, 3, 2), L.upper ? (L.odd_row ? 0u : one + one) : one);
+    // P = (x : y : 1 : x y)
+    put_a(lds, L, L.row, L.upper ? (L.odd_row ? xl : one) : (L.odd_row ? yl : xl));
+    put_y(lds, L, 4 + L.row, yl);
+    const u32 v1 = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, 7));
+    store_row(1, v1);
+    const u32 v2 = ge_dbl(lds, L, v1);
+    store_row(2, v2);
+    const u32 v3 = ge_add_pe(lds, L, v2, base + 4, 0u);
+    store_row(3, v3);
+    const u32 v4 = ge_dbl(lds, L, v2);
+    store_row(4, v4);
+    store_row(5, ge_add_pe(lds, L, v4, base + 4, 0u));
+    const u32 v6 = ge_dbl(lds, L, v3);
+    store_row(6, v6);
+    store_row(7, ge_add_pe(lds, L, v6, base + 4, 0u));
+    store_row(8, ge_dbl(lds, L, v4));
+}
+
 // all-ones iff sigma*B + tau*Q + rho*Rn is the neutral element.  tq / tr: the element's packed window tables;
 // sigma_w(w), tau_w(w), rho_w(w): words of its scalars; sc_tbl: the walk's comb table; top: first digit (>= SC_ROUNDS).
-template <typename Words>
+// TABLES_IN_LDS: the window tables' multiplier forms are in their slots already (wtable_build_lds), tq / tr are not read.
+template <bool TABLES_IN_LDS = false, typename Words>
 C25519_DEV u32 walk_is_neutral(u32* lds, const Lane& L, const Words& sc, const u32* __restrict__ tq, const u32* __restrict__ tr,
                                const u32* __restrict__ sc_tbl, int top)
 {
     const u32 lane = L.row * 16 + L.c;
     // tables -> LDS multiplier forms
 #pragma unroll 1
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < (TABLES_IN_LDS ? 0 : 2); t++)
 #pragma unroll 1
         for (int r = 0; r < WTABLE_ROWS; r++)
 #pragma unroll

@@ -839,24 +839,89 @@ __global__ void __launch_bounds__(WALK_BLOCK, C25519_VW_WAVES) k_ed25519_verify_
     verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
 }
 
-// step 3 for a call of a few elements: the walk with ONE element per wave (coop25519.cuh: walk_is_neutral), reading what
-// the scalar and points kernels left in the element's scratch.  Two product levels per point operation instead of one
-// lane's ~800 instructions: the walk of a lone element takes ~70 us instead of ~380.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
-k_ed25519_verify_walk_coop(FastScratch fs, int* verdict, size_t n, const u32* __restrict__ g_tbl)
+// The whole lattice path of ONE element in ONE launch, for a call of a few elements: a workgroup of two waves per element.
+// Wave 0 hashes and reduces (step 1, every lane on the same values) WHILE wave 1 decodes the key in lane 0 and R in lane 1 (the
+// two square roots of step 2, which do not need the scalars); behind a barrier wave 1 gives the key's point the sign of tau and
+// builds the two window tables with the whole wave, straight into the LDS forms the walk reads (coop::wtable_build_lds: 46
+// product levels instead of one lane's seven point operations per table and a round trip through global memory), behind a
+// second one wave 0 walks them (coop::walk_is_neutral).  Three launches ran these phases one after the other (40 + 83 + 91 us
+// for one signature); here the hashing hides under the square roots and two launch gaps go.  Elements the path cannot decide go on the slow list exactly as in the batch kernels
+// (the host zeroes the list's counter in front of the launch: no block can do it for the others).
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_ed25519_verify_one_per_group(FastScratch fs, int* verdict, const void* sig, const void* pk, Msgs msgs, size_t n,
+                               const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::V_LDS_WORDS];
-    const coop::Lane L = coop::make_lane(threadIdx.x);
-    const size_t i = blockIdx.x;
-    if (i >= n) return;
-    const u32 f = fs.flags[i];
-    if (f & FLAG_SLOW) return;
+    __shared__ u32 hand[4];                                 // [0] tau < 0, [1] flag bits from wave 0, [2] from wave 1
+    const size_t e = blockIdx.x;
+    if (e >= n) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) hand[2] = 0;
+    fe X, Y;
+    u32 point_ok = 0;
+    if (wave == 0) {
+        u32 pkw[8], Rw[8], Sw[8], cols[SIGMA_WORDS], rho[5], tau[5], tau_neg;
+        load32(pkw, pk, e);
+        load32(Rw, sig, 2 * e);
+        load32(Sw, sig, 2 * e + 1);
+        const u32 lat_ok = ed_verify_fast_scalars(cols, rho, tau, tau_neg, pkw, Rw, Sw, msgs.ptr(e), msgs.len(e), fs.lat_cap_bits);
+        if (lane == 0) {
+#pragma unroll
+            for (int w = 0; w < SIGMA_WORDS; w++) fs.sigma[(size_t)w * n + e] = cols[w];
+#pragma unroll
+            for (int w = 0; w < 5; w++) { fs.rho[(size_t)w * n + e] = rho[w]; fs.tau[(size_t)w * n + e] = tau[w]; }
+            const int top = lat_ok ? walk_top_digit(tau, rho) : 0;
+            hand[0] = tau_neg;
+            hand[1] = (lat_ok & FLAG_FITS) | (tau_neg & FLAG_TAU_NEG) | ((u32)top << 8);
+        }
+    } else if (lane < 2) {
+        u32 w[8];
+        if (lane) load32(w, sig, 2 * e); else load32(w, pk, e);
+        point_ok = ed_verify_fast_decode(X, Y, w, lane ? 0xffffffffu : 0u, 0u);   // the key's sign of tau: behind the barrier
+    }
+    __syncthreads();
+    if (wave == 1) {
+        if (lane < 2) {
+            if (lane == 0) {
+                fe t;
+                fe_neg(t, X);
+                fe_carry32(t, t);
+                fe_select(X, hand[0], t, X);               // tau < 0: the walk uses |tau| on -Q (ed_verify_fast_decode)
+            }
+            if (point_ok) atomicOr(&hand[2], lane ? FLAG_R_OK : FLAG_KEY_OK);
+            u32* park = lds + coop::V_ROWQ_OFF + lane * 20;     // (the walk's row queue: nobody's yet)
+#pragma unroll
+            for (int i = 0; i < 10; i++) { park[i] = X.v[i]; park[10 + i] = Y.v[i]; }
+        }
+        // the two window tables, by the whole wave, straight into the multiplier forms the walk reads
+        const coop::Lane L = coop::make_lane(lane);
+        coop::wave_fence();
+        const u32 c = L.c < 10 ? L.c : 0;
+        const u32 qx = lds[coop::V_ROWQ_OFF + c], qy = lds[coop::V_ROWQ_OFF + 10 + c];
+        const u32 rx = lds[coop::V_ROWQ_OFF + 20 + c], ry = lds[coop::V_ROWQ_OFF + 30 + c];
+        coop::wave_fence();
+        coop_setup_one(lds, L);
+        coop::wtable_build_lds(lds, L, 0, qx, qy);
+        coop::wtable_build_lds(lds, L, 1, rx, ry);
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const u32 f = hand[1] | hand[2];
+    if ((f & (FLAG_KEY_OK | FLAG_FITS)) != (FLAG_KEY_OK | FLAG_FITS)) {      // off-curve key / over-long vector: the slow list
+        if (lane == 0) {
+            fs.flags[e] = f | FLAG_SLOW;
+            fs.slow_list[atomicAdd(fs.slow_count, 1u)] = (u32)e;
+        }
+        return;
+    }
+    if (lane == 0) fs.flags[e] = f;
+    const coop::Lane L = coop::make_lane(lane);
     const int top = (int)((f >> 8) & 63u);
     coop_setup_one(lds, L);
-    const u32* tq = fs.tables + i * FAST_TABLE_WORDS;
-    const WalkScalars sc{ fs.sigma, fs.tau, fs.rho, n, i };
-    const u32 neutral = coop::walk_is_neutral(lds, L, sc, tq, tq + WTABLE_WORDS, g_tbl + SC_TBL_OFFSET, top < 8 ? 8 : top);
-    if (threadIdx.x == 0) verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
+    const u32* tq = fs.tables + e * FAST_TABLE_WORDS;
+    const WalkScalars sc{ fs.sigma, fs.tau, fs.rho, n, e };
+    const u32 neutral = coop::walk_is_neutral<true>(lds, L, sc, tq, tq + WTABLE_WORDS, g_tbl + SC_TBL_OFFSET, top < 8 ? 8 : top);
+    if (lane == 0) verdict[e] = (neutral & f & FLAG_R_OK) ? 1 : 0;
 }
 
 // step 5: the elements on the slow list (off-curve keys -- the reference does not reject them, so neither may we -- and
@@ -1277,6 +1342,7 @@ int check_dev_args(size_t n, std::initializer_list<const void*> ptrs)
             (void)hipGetLastError();
             return bad_arg("*_dev entry points take device pointers (this one is unknown to the HIP runtime)");
         }
+        if (attr.type == hipMemoryTypeHost && c25519_host::zero_copy_call()) continue;   // the pinned staging of a tiny *_batch call (host_pipeline.hpp)
         if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)
             return bad_arg("*_dev entry points take device pointers (got host memory)");
         if (attr.type == hipMemoryTypeDevice && attr.device != dev)
@@ -1375,13 +1441,18 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
             const long cap = c25519_host::tunable_or(c25519_host::T_VERIFY_LAT_CAP_BITS, LAT_CAP_BITS);
             fs.lat_cap_bits = cap >= 100 && cap < LAT_CAP_BITS ? (int)cap : LAT_CAP_BITS;
         }
-        k_ed25519_verify_fast_scalars<<<grid_for(n, FS_BLOCK), FS_BLOCK, 0, stream>>>(fs, sig, pk, msgs, n);
-        C25519_TRY(hipGetLastError());
-        k_ed25519_verify_fast_points<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
-        C25519_TRY(hipGetLastError());
-        if (verify_coop_for(n)) k_ed25519_verify_walk_coop<<<(unsigned)n, 64, 0, stream>>>(fs, verdict, n, tbl);
-        else k_ed25519_verify_fast_walk<<<grid_for(n, WALK_BLOCK), WALK_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
-        C25519_TRY(hipGetLastError());
+        if (verify_coop_for(n)) {                          // a few elements: one launch, two waves per element
+            C25519_TRY(hipMemsetAsync(fs.slow_count, 0, 3 * sizeof(u32), stream));
+            k_ed25519_verify_one_per_group<<<(unsigned)n, 128, 0, stream>>>(fs, verdict, sig, pk, msgs, n, tbl);
+            C25519_TRY(hipGetLastError());
+        } else {
+            k_ed25519_verify_fast_scalars<<<grid_for(n, FS_BLOCK), FS_BLOCK, 0, stream>>>(fs, sig, pk, msgs, n);
+            C25519_TRY(hipGetLastError());
+            k_ed25519_verify_fast_points<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
+            C25519_TRY(hipGetLastError());
+            k_ed25519_verify_fast_walk<<<grid_for(n, WALK_BLOCK), WALK_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
+            C25519_TRY(hipGetLastError());
+        }
         k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
         C25519_TRY(hipGetLastError());
         tl_last_verify.count = report; tl_last_verify.stream = stream;

@@ -277,6 +277,14 @@ inline size_t piece_rows(size_t n, size_t row)
     return chunk > cap ? cap : chunk;
 }
 
+// A call of a few elements -- the reference's own prototypes are calls of ONE -- does not copy at all: the kernels read their
+// operands straight out of the pinned staging buffers (page-locked host memory is mapped into the device's address space) and
+// write their results into them.  Four copy commands of ~4 us each on the device, and their submission, cost a single call
+// more than the few hundred bytes cost over PCIe.  The *_dev entry points, which refuse host pointers from callers, accept them
+// while this flag is up (engine.hip: check_dev_args).
+constexpr size_t ZERO_COPY_MAX_ROWS = 64;
+inline bool& zero_copy_call() { thread_local bool on = false; return on; }
+
 // What the multi-GPU layer hangs on a device's pipeline: the piece size (so that every device cuts its shard at the same
 // rows) and a call per piece once its kernels are enqueued -- `computed` is the event behind them on this device (null:
 // the piece has already completed), which another stream can wait for while this pipeline keeps going.
@@ -305,14 +313,18 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
         if (arr[a].in && arr[a].out && arr[a].in != arr[a].out) direct[a] = false;
     }
     bool resident_result = false;                          // a device-resident array nobody downloads: synchronise at the end
+    bool any_dev = false;
     for (int a = 0; a < na; a++)
         if (arr[a].dev) {
             if (arr[a].in) return bad_arg("internal: a device-resident array has no host source");
             resident_result = resident_result || !arr[a].out;
+            any_dev = true;
         }
+    static const bool zero_copy_on = [] { const char* e = getenv("C25519_AMD_ZERO_COPY"); return !(e && atoi(e) == 0); }();
+    const bool zero_copy = zero_copy_on && n <= ZERO_COPY_MAX_ROWS && nchunks == 1 && !any_dev;
     for (int l = 0; l < sets; l++)
         for (int a = 0; a < na; a++) {
-            if (!arr[a].dev) C25519_RC(t.reserve_dev(l, a, arr[a].elem * chunk));
+            if (!arr[a].dev && !zero_copy) C25519_RC(t.reserve_dev(l, a, arr[a].elem * chunk));
             if (!direct[a]) C25519_RC(t.reserve_host(l, a, arr[a].elem * chunk));
         }
     auto span = [&](size_t c, size_t& lo, size_t& cnt) { lo = c * chunk; cnt = (n - lo < chunk) ? n - lo : chunk; };
@@ -340,6 +352,15 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
         hipStream_t kern = t.stream[c & 1];
         hipStream_t up = one_stream ? kern : t.stream[2], down = one_stream ? kern : t.stream[3];
         void* dptr[ThreadState::SLOTS] = {};
+        if (zero_copy) {                                   // (one piece, one stream: `sequential` below)
+            for (int a = 0; a < na; a++) dptr[a] = t.hbuf[l][a];
+            zero_copy_call() = true;
+            const int rc = launch(dptr, cnt, lo, kern);
+            zero_copy_call() = false;
+            C25519_RC(rc);
+            C25519_TRY(hipEventRecord(t.done[l], kern));
+            return 0;
+        }
         for (int a = 0; a < na; a++) {
             dptr[a] = arr[a].dev ? (void*)((char*)arr[a].dev + lo * arr[a].elem) : t.dbuf[l][a];
             if (arr[a].in && cnt * arr[a].elem)

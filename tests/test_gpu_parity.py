@@ -1232,7 +1232,7 @@ def test_warm_device_calls_can_be_captured_into_a_hip_graph(api, oracle):
 
 def test_degenerate_but_valid_signatures_on_both_paths(api):
     """tests/golden/degenerate_verify.npz through ed25519_VerifySignature on the device: the default pass (lattice path +
-    slow list) with BOTH walk kernels forced explicitly -- k_ed25519_verify_walk_coop (one element per wave: tunable
+    slow list) with BOTH shapes forced explicitly -- k_ed25519_verify_one_per_group (one element per two-wave workgroup: tunable
     COOP_MAX large) and k_ed25519_verify_fast_walk (one per lane: COOP_MAX 0) -- and with VERIFY_REFERENCE_ORDER = 1 (every
     element through the reference-order kernels).  Expected verdicts are the real reference's: 336 of these 1024
     signatures over small-order / mixed-order keys, small-order R in every encoding and S in {0, L, 2L, 15L} are VALID
