@@ -537,6 +537,111 @@ C25519_DEV void wtable_build_lds(u32* lds, const Lane& L, int t, u32 xl, u32 yl)
     store_row(8, ge_dbl(lds, L, v4));
 }
 
+// ---- the three products of the lattice equation, one wave each (engine.hip: k_ed25519_verify_one_per_group) -------------
+// sigma*B + tau*Q + rho*Rn = O is three independent scalar products; a workgroup of three waves computes them side by side
+// -- each wave with an LDS region of its own (operand slots, its point's window table) -- and one wave adds them up.
+
+// k * P for one biased 160-bit scalar (signed radix-16 digits, verify_fast.cuh) over P's window table in slots tbase ...
+// (wtable_build_lds): the first digit's row as an extended point, then per digit four doublings and one row.
+// word(w): word w of the scalar.  SLOT_ONE and SLOT_KDI must be set.
+template <typename WordFn>
+C25519_DEV u32 walk_point(u32* lds, const Lane& L, WordFn word, int tbase, int top)
+{
+    u32 v;
+    {
+        u32 neg;
+        const u32 m = signed16_of(neg, word(top >> 3), top & 7);
+        const u32* row = lds + (tbase + m * 4) * SLOT_WORDS + YO_OFF + 10 + (L.c < 10 ? L.c : 9);      // plain limbs of a field
+        const u32 a = row[(neg ? 1 : 0) * SLOT_WORDS], b = row[(neg ? 0 : 1) * SLOT_WORDS];             // Y+X, Y-X of +-row
+        const u32 t2d = row[2 * SLOT_WORDS], z2 = row[3 * SLOT_WORDS];
+        wave_fence();
+        put_a(lds, L, L.row, L.upper ? (L.odd_row ? (neg ? L.p2 - t2d : t2d) : z2) : (L.odd_row ? a + b : a + L.p2 - b));
+        v = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, SLOT_KDI));                 // 2x, 2y, 2z, 2xy
+    }
+#pragma unroll 1
+    for (int i = top - 1; i >= 0; i--) {
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) v = ge_dbl(lds, L, v);
+        u32 neg;
+        const u32 m = signed16_of(neg, word(i >> 3), i & 7);
+        v = ge_add_pe(lds, L, v, tbase + m * 4, neg);
+    }
+    return v;
+}
+
+// limb L.c of field f (0 ypx, 1 ymx, 2 2dxy) of the row column c of the walk's signed comb selects (sign included)
+C25519_DEV u32 comb_limb(const u32* __restrict__ tbl, const Lane& L, u32 c, u32 f)
+{
+    const u32 neg = ((c >> (SC_TEETH - 1)) & 1u) - 1u;
+    const u32 r = (c ^ neg) & (u32)(SC_ROWS - 1);
+    const u32 ff = (f < 2 && neg) ? 1u - f : f;
+    const u32 lc = L.c < 10 ? L.c : 9;
+    const u32 wd = tbl[(ff * 10 + lc) * SC_ROWS + r];
+    return (f == 2 && neg) ? L.p2 - wd : wd;
+}
+
+// sigma * B over the walk's signed comb by Horner's rule: column SC_COLS - 1 first, then per column a doubling and a row
+// (column c has weight 2^c).  sigma_word(w): the columns as sc_comb_columns packs them.  rowq: SC_ROUNDS * 4 * 64 words.
+template <typename WordFn>
+C25519_DEV u32 walk_comb(u32* lds, u32* rowq, const Lane& L, WordFn sigma_word, const u32* __restrict__ sc_tbl)
+{
+    const u32 lane = L.row * 16 + L.c;
+    u32 top_col = 0;
+#pragma unroll 1
+    for (int i = 0; i < SC_ROUNDS; i++) {                  // every row fetch up front (the addresses depend on sigma alone)
+        u64 cols = (u64)sigma_word(2 * i) | ((u64)sigma_word(2 * i + 1) << 32);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int c = 4 * i + 3 - j;
+            if (c < SC_COLS) rowq[c * 64 + lane] = comb_limb(sc_tbl, L, (u32)cols & 0xffffu, by_row(L, 1, 0, 2, 2));
+            if (c == SC_COLS - 1) top_col = (u32)cols & 0xffffu;
+            cols >>= 16;
+        }
+    }
+    const u32 ypx = comb_limb(sc_tbl, L, top_col, 0), ymx = comb_limb(sc_tbl, L, top_col, 1), t2d = comb_limb(sc_tbl, L, top_col, 2);
+    const u32 two = L.c == 0 ? 2u : 0u;
+    wave_fence();
+    put_a(lds, L, L.row, L.upper ? (L.odd_row ? t2d : two) : (L.odd_row ? ypx + ymx : ypx + L.p2 - ymx));
+    u32 v = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, SLOT_KDI));   // (2x, 2y, 2, 2xy) of the top column's row
+#pragma unroll 1
+    for (int c = SC_COLS - 2; c >= 0; c--) {
+        v = ge_dbl(lds, L, v);
+        v = ge_add(lds, L, v, rowq[c * 64 + lane]);
+    }
+    return v;
+}
+
+// the point in the rows -> its precomputed form (Y+X, Y-X, 2dT, 2Z) as multiplier forms in slots `slot` .. `slot + 3` of the region
+// `out` (another wave's, for the final sum); SLOT_K2D of `lds` must be set
+C25519_DEV void store_pe(u32* lds, u32* out, const Lane& L, int slot, u32 v)
+{
+    u32 ev, od;
+    pair_exchange(ev, od, v);                             // lower pair: X, Y; upper pair: Z, T
+    const u32 val = L.upper ? (L.odd_row ? od : ev + ev) : (L.odd_row ? od + L.p2 - ev : ev + od);
+    put_a(lds, L, L.row, val);                            // Y+X, Y-X, 2Z, T
+    const u32 w = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, SLOT_K2D));
+    put_y(out, L, slot + by_row(L, 0, 1, 3, 2), w);       // fields: ypx, ymx, t2d, z2
+}
+
+// all-ones iff the point in the rows is the neutral element: X == 0 and Y == Z
+C25519_DEV u32 is_neutral(u32* lds, const Lane& L, u32 v)
+{
+    put_a(lds, L, L.row, v);
+    wave_fence();
+    fe X, Y, Z, d;
+    get_fe(X, lds, 0);
+    get_fe(Y, lds, 1);
+    get_fe(Z, lds, 2);
+    wave_fence();
+    fe_sub(d, Y, Z);
+    u32 xw[8], dw[8], acc = 0;
+    fe_to_words(xw, X);
+    fe_to_words(dw, d);
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc |= xw[i] | dw[i];
+    return acc == 0 ? 0xffffffffu : 0u;
+}
+
 // all-ones iff sigma*B + tau*Q + rho*Rn is the neutral element.  tq / tr: the element's packed window tables;
 // sigma_w(w), tau_w(w), rho_w(w): words of its scalars; sc_tbl: the walk's comb table; top: first digit (>= SC_ROUNDS).
 // TABLES_IN_LDS: the window tables' multiplier forms are in their slots already (wtable_build_lds), tq / tr are not read.

@@ -839,26 +839,33 @@ __global__ void __launch_bounds__(WALK_BLOCK, C25519_VW_WAVES) k_ed25519_verify_
     verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
 }
 
-// The whole lattice path of ONE element in ONE launch, for a call of a few elements: a workgroup of two waves per element.
-// Wave 0 hashes and reduces (step 1, every lane on the same values) WHILE wave 1 decodes the key in lane 0 and R in lane 1 (the
-// two square roots of step 2, which do not need the scalars); behind a barrier wave 1 gives the key's point the sign of tau and
-// builds the two window tables with the whole wave, straight into the LDS forms the walk reads (coop::wtable_build_lds: 46
-// product levels instead of one lane's seven point operations per table and a round trip through global memory), behind a
-// second one wave 0 walks them (coop::walk_is_neutral).  Three launches ran these phases one after the other (40 + 83 + 91 us
-// for one signature); here the hashing hides under the square roots and two launch gaps go.  Elements the path cannot decide go on the slow list exactly as in the batch kernels
-// (the host zeroes the list's counter in front of the launch: no block can do it for the others).
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2)))
+// The whole lattice path of ONE element in ONE launch, for a call of a few elements: a workgroup of THREE waves per element.
+//   phase 1   wave 0 hashes and reduces (step 1: every lane on the same values) WHILE wave 1 decodes the key in lane 0 and R in
+//             lane 1 (the two square roots of step 2, which do not need the scalars);
+//   phase 2   the equation sigma*B + tau*Q + rho*(-R) = O is three independent products, one wave each, every wave in an LDS
+//             region of its own: wave 0 builds the key's window table with the whole wave (coop::wtable_build_lds: straight into
+//             the forms the walk reads, no round trip through memory) and walks tau over it, wave 1 does the same for R and rho,
+//             wave 2 runs sigma*B over the comb by Horner's rule -- each needs the ~129 doublings the joint walk shared, but
+//             side by side on three SIMDs: 330 product levels in a row instead of 440;
+//   phase 3   waves 1 and 2 hand their points to wave 0 in precomputed form; two additions and the neutral-element test.
+// Three launches ran 40 + 83 + 91 us one after the other for one signature; this is ~60 + ~60.  Elements the path cannot
+// decide go on the slow list exactly as in the batch kernels (the host zeroes the list's counter in front of the launch).
+__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_ed25519_verify_one_per_group(FastScratch fs, int* verdict, const void* sig, const void* pk, Msgs msgs, size_t n,
                                const u32* __restrict__ g_tbl)
 {
-    __shared__ __attribute__((aligned(16))) u32 lds[coop::V_LDS_WORDS];
-    __shared__ u32 hand[4];                                 // [0] tau < 0, [1] flag bits from wave 0, [2] from wave 1
+    // wave 0: operand slots, one window table, eight hand-over slots; wave 1: operand slots, one table; wave 2: operand slots, the
+    // comb's row queue: 45 KiB per workgroup, three workgroups per CU
+    constexpr int TABLE_SLOTS = WTABLE_ROWS * 4, HANDOVER = coop::VSLOT0 + TABLE_SLOTS;
+    constexpr int BASE1 = (HANDOVER + 8) * coop::SLOT_WORDS, BASE2 = BASE1 + (coop::VSLOT0 + TABLE_SLOTS) * coop::SLOT_WORDS;
+    constexpr int ROWQ2 = coop::NSLOTS * coop::SLOT_WORDS;
+    __shared__ __attribute__((aligned(16))) u32 lds_all[BASE2 + ROWQ2 + SC_ROUNDS * 4 * 64];
+    __shared__ u32 park[40];                                // limbs of the key's x, y (0 .. 19) and of R's (20 .. 39)
+    __shared__ u32 hand[4];                                 // tau < 0; wave 0's flag bits; key on the curve; R decodes canonically
     const size_t e = blockIdx.x;
     if (e >= n) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) hand[2] = 0;
-    fe X, Y;
-    u32 point_ok = 0;
+    u32* lds = lds_all + (wave == 0 ? 0 : wave == 1 ? BASE1 : BASE2);
     if (wave == 0) {
         u32 pkw[8], Rw[8], Sw[8], cols[SIGMA_WORDS], rho[5], tau[5], tau_neg;
         load32(pkw, pk, e);
@@ -874,53 +881,49 @@ k_ed25519_verify_one_per_group(FastScratch fs, int* verdict, const void* sig, co
             hand[0] = tau_neg;
             hand[1] = (lat_ok & FLAG_FITS) | (tau_neg & FLAG_TAU_NEG) | ((u32)top << 8);
         }
-    } else if (lane < 2) {
+    } else if (wave == 1 && lane < 2) {
         u32 w[8];
+        fe X, Y;
         if (lane) load32(w, sig, 2 * e); else load32(w, pk, e);
-        point_ok = ed_verify_fast_decode(X, Y, w, lane ? 0xffffffffu : 0u, 0u);   // the key's sign of tau: behind the barrier
-    }
-    __syncthreads();
-    if (wave == 1) {
-        if (lane < 2) {
-            if (lane == 0) {
-                fe t;
-                fe_neg(t, X);
-                fe_carry32(t, t);
-                fe_select(X, hand[0], t, X);               // tau < 0: the walk uses |tau| on -Q (ed_verify_fast_decode)
-            }
-            if (point_ok) atomicOr(&hand[2], lane ? FLAG_R_OK : FLAG_KEY_OK);
-            u32* park = lds + coop::V_ROWQ_OFF + lane * 20;     // (the walk's row queue: nobody's yet)
+        const u32 ok = ed_verify_fast_decode(X, Y, w, lane ? 0xffffffffu : 0u, 0u);   // (the key's sign of tau: wave 0, below)
+        hand[2 + lane] = ok ? 1u : 0u;
 #pragma unroll
-            for (int i = 0; i < 10; i++) { park[i] = X.v[i]; park[10 + i] = Y.v[i]; }
-        }
-        // the two window tables, by the whole wave, straight into the multiplier forms the walk reads
-        const coop::Lane L = coop::make_lane(lane);
-        coop::wave_fence();
-        const u32 c = L.c < 10 ? L.c : 0;
-        const u32 qx = lds[coop::V_ROWQ_OFF + c], qy = lds[coop::V_ROWQ_OFF + 10 + c];
-        const u32 rx = lds[coop::V_ROWQ_OFF + 20 + c], ry = lds[coop::V_ROWQ_OFF + 30 + c];
-        coop::wave_fence();
-        coop_setup_one(lds, L);
-        coop::wtable_build_lds(lds, L, 0, qx, qy);
-        coop::wtable_build_lds(lds, L, 1, rx, ry);
+        for (int i = 0; i < 10; i++) { park[20 * lane + i] = X.v[i]; park[20 * lane + 10 + i] = Y.v[i]; }
     }
     __syncthreads();
-    if (wave != 0) return;
-    const u32 f = hand[1] | hand[2];
+    const u32 f = hand[1] | (hand[2] ? FLAG_KEY_OK : 0u) | (hand[3] ? FLAG_R_OK : 0u);
     if ((f & (FLAG_KEY_OK | FLAG_FITS)) != (FLAG_KEY_OK | FLAG_FITS)) {      // off-curve key / over-long vector: the slow list
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             fs.flags[e] = f | FLAG_SLOW;
             fs.slow_list[atomicAdd(fs.slow_count, 1u)] = (u32)e;
         }
         return;
     }
-    if (lane == 0) fs.flags[e] = f;
+    if (threadIdx.x == 0) fs.flags[e] = f;
     const coop::Lane L = coop::make_lane(lane);
     const int top = (int)((f >> 8) & 63u);
+    const u32 c = L.c < 10 ? L.c : 0;
     coop_setup_one(lds, L);
-    const u32* tq = fs.tables + e * FAST_TABLE_WORDS;
-    const WalkScalars sc{ fs.sigma, fs.tau, fs.rho, n, e };
-    const u32 neutral = coop::walk_is_neutral<true>(lds, L, sc, tq, tq + WTABLE_WORDS, g_tbl + SC_TBL_OFFSET, top < 8 ? 8 : top);
+    coop::put_y(lds, L, coop::SLOT_KDI, coop::my_limb(lds, L, fe_const(K_DI)));
+    u32 v;
+    if (wave == 0) {                                        // |tau| * (+-Q)
+        const u32 xl = hand[0] ? L.p2 - park[c] : park[c]; // tau < 0: the table of -Q (ed_verify_fast_decode)
+        coop::wtable_build_lds(lds, L, 0, xl, park[10 + c]);
+        v = coop::walk_point(lds, L, [&](int w) -> u32 { return fs.tau[(size_t)w * n + e]; }, coop::VSLOT0, top);
+    } else if (wave == 1) {                                 // rho * (-R)
+        coop::wtable_build_lds(lds, L, 0, park[20 + c], park[30 + c]);
+        v = coop::walk_point(lds, L, [&](int w) -> u32 { return fs.rho[(size_t)w * n + e]; }, coop::VSLOT0, top);
+        coop::store_pe(lds, lds_all, L, HANDOVER, v);
+    } else {                                                // sigma * B
+        coop::put_y(lds, L, coop::SLOT_K2D, coop::my_limb(lds, L, fe_const(K_2D)));
+        v = coop::walk_comb(lds, lds + ROWQ2, L, [&](int w) -> u32 { return fs.sigma[(size_t)w * n + e]; }, g_tbl + SC_TBL_OFFSET);
+        coop::store_pe(lds, lds_all, L, HANDOVER + 4, v);
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    v = coop::ge_add_pe(lds, L, v, HANDOVER, 0u);
+    v = coop::ge_add_pe(lds, L, v, HANDOVER + 4, 0u);
+    const u32 neutral = coop::is_neutral(lds, L, v);
     if (lane == 0) verdict[e] = (neutral & f & FLAG_R_OK) ? 1 : 0;
 }
 
@@ -1441,9 +1444,9 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
             const long cap = c25519_host::tunable_or(c25519_host::T_VERIFY_LAT_CAP_BITS, LAT_CAP_BITS);
             fs.lat_cap_bits = cap >= 100 && cap < LAT_CAP_BITS ? (int)cap : LAT_CAP_BITS;
         }
-        if (verify_coop_for(n)) {                          // a few elements: one launch, two waves per element
+        if (verify_coop_for(n)) {                          // a few elements: one launch, three waves per element
             C25519_TRY(hipMemsetAsync(fs.slow_count, 0, 3 * sizeof(u32), stream));
-            k_ed25519_verify_one_per_group<<<(unsigned)n, 128, 0, stream>>>(fs, verdict, sig, pk, msgs, n, tbl);
+            k_ed25519_verify_one_per_group<<<(unsigned)n, 192, 0, stream>>>(fs, verdict, sig, pk, msgs, n, tbl);
             C25519_TRY(hipGetLastError());
         } else {
             k_ed25519_verify_fast_scalars<<<grid_for(n, FS_BLOCK), FS_BLOCK, 0, stream>>>(fs, sig, pk, msgs, n);
@@ -1491,11 +1494,11 @@ bool coop_for(size_t n, size_t dflt)
     return n <= max && c25519_host::batch_shape_hint() <= max;
 }
 // crossovers measured on MI355X (tools/small_batch_sweep.py, profiles/r04_small_batch_sweep.txt): the ladder one per wave
-// wins up to 4096 elements (0.49 against 0.66 ms), the fixed-base operations and verification's walk up to 2048
-// (0.10-0.16 against 0.15-0.19 ms; 0.38 against 0.60 ms)
+// wins up to 4096 elements (0.49 against 0.66 ms), the fixed-base operations up to 2048 (0.10-0.16 against 0.15-0.19 ms),
+// verification (three waves per element, profiles/r05_small_batch_sweep.txt) up to 1024
 bool x25519_coop_for(size_t n) { return coop_for(n, 4096); }
 bool fixed_base_coop_for(size_t n) { return coop_for(n, 2048); }
-bool verify_coop_for(size_t n) { return coop_for(n, 2048); }       // the walk alone: 0.25-0.38 against 0.60 ms
+bool verify_coop_for(size_t n) { return coop_for(n, 1024); }       // three waves per element: 0.15-0.34 against 0.60 ms (0.67 at 2048)
 
 // a batch that fills the chip runs the ladder and the shared inversion as two launches (k_x25519_ladder's comment);
 // tunable XF_SPLIT = 0 / 1 forces either shape (A/B knob)
