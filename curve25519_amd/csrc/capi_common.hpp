@@ -161,6 +161,9 @@ struct ThreadState {
     void* vctx = nullptr;                  // the 2080-byte context of this thread's last ed25519_Verify_Check_batch (nothing else writes it)
     unsigned char vctx_host[2080] = {};    // ... and the bytes that were uploaded into it
     bool vctx_valid = false;
+    void* bctx = nullptr;                  // the same for the 192-byte blinding context of this thread's last blinded *_batch call
+    unsigned char bctx_host[192] = {};
+    bool bctx_valid = false;
     void* hbuf[SETS][SLOTS] = {};          // pinned host staging (hipHostMalloc)
     size_t hcap[SETS][SLOTS] = {};
     // work scratch of the *_dev entry points: grow-only slabs, CALLER_SLABS PER DEVICE (a thread may drive several GPUs, see
@@ -361,6 +364,9 @@ struct ThreadState {
         }
         if (vctx) { (void)hipMemset(vctx, 0, 2080); (void)hipFree(vctx); vctx = nullptr; }
         vctx_valid = false;
+        if (bctx) { (void)hipMemset(bctx, 0, 192); (void)hipFree(bctx); bctx = nullptr; }
+        memset(bctx_host, 0, sizeof bctx_host);
+        bctx_valid = false;
         for (int l = 0; l < LANES; l++) {
             free_slab(lane_work[l]);
             if (stream[l]) (void)hipStreamDestroy(stream[l]);

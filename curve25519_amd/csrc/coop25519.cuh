@@ -421,8 +421,21 @@ C25519_DEV u32 wide_row_limb(const u32* __restrict__ tbl, const Lane& L, u32 col
     return (f == 2 && neg) ? L.p2 - wd : wd;
 }
 
-C25519_DEV u32 ge_base_mult_wide(u32* lds, const Lane& L, const u32 (&k)[8], const u32* __restrict__ wide)
+// blind (or null): a blinding context's 48 words (lanes.cuh: bl, zr, BP) -- the walk then runs on (k + bl) mod L from a starting
+// point spread over its projective class by zr, and BP comes on top (edp_BasePointMultiply with a context, ed25519_sign.c:254-259)
+C25519_DEV u32 ge_base_mult_wide(u32* lds, const Lane& L, const u32 (&k_in)[8], const u32* __restrict__ wide,
+                                 const u32* __restrict__ blind = nullptr)
 {
+    u32 k[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = k_in[i];
+    if (blind) {
+        u32 bl[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) bl[i] = blind[i];
+        sc_add(k, k_in, bl);                              // 256 bits, congruent to k + bl mod L (eco_AddReduce :255)
+        sc_mod(k);
+    }
     u32 cols[WB_COLS];                                    // (compile-time indices below: registers)
     wb_columns(cols, 1, k);
     const u32 lane = L.row * 16 + L.c;
@@ -435,12 +448,22 @@ C25519_DEV u32 ge_base_mult_wide(u32* lds, const Lane& L, const u32 (&k)[8], con
     const u32 two = L.c == 0 ? 2u : 0u;
     put_a(lds, L, L.row, L.upper ? (L.odd_row ? t2d : two) : (L.odd_row ? ypx + ymx : ypx + L.p2 - ymx));
     u32 v = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, SLOT_KDI));
+    if (blind) {                                          // (2x, 2y, 2, 2xy) * zr: the same point, another representative
+        put_a(lds, L, L.row, v);
+        put_y(lds, L, 4, packed_limb(blind + 8, L));
+        v = mul_level(lds, L, L.row, 4);
+    }
 #pragma unroll 1
     for (int m = 0; m < WB_STEP; m++) {
         if (m) v = ge_dbl(lds, L, v);
 #pragma unroll 1
         for (int t = m ? 0 : 1; t < WB_NT; t++)
             v = ge_add(lds, L, v, lds[ROWQ_OFF + (m * WB_NT + t) * 64 + lane]);
+    }
+    if (blind) {                                          // + BP, a precomputed projective point (Y+X, Y-X, 2dT, 2Z)
+#pragma unroll
+        for (int f = 0; f < 4; f++) put_y(lds, L, 4 + f, packed_limb(blind + 16 + 8 * f, L));
+        v = ge_add_pe(lds, L, v, 4, 0u);
     }
     return v;
 }

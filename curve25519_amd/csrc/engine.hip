@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_finish(void* sig, 
 
 // The same three operations for a call of a few elements, ONE operation per wave (coop25519.cuh): hashing and scalar
 // arithmetic by every lane on the same values, the fixed-base walk, the inversion and the affine conversion cooperative.
-// (No blinding here: a blinded call runs the batch kernels.)
+// (A blinding context: over the wide comb only -- with the LDS comb a blinded call runs the batch kernels.)
 C25519_DEV void coop_setup_one(u32* lds, const coop::Lane& L)
 {
     fe one;
@@ -571,7 +571,8 @@ C25519_DEV void coop_setup_one(u32* lds, const coop::Lane& L)
 
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
-k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u32* __restrict__ g_tbl)
+k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u32* __restrict__ g_tbl,
+                       const u32* __restrict__ blind_ctx)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
     const coop::Lane L = coop::make_lane(threadIdx.x);
@@ -582,7 +583,7 @@ k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u3
     load32(seed, sk, e);
     ed_expand_seed(a, b_words, seed);
     coop_setup_one(lds, L);
-    const u32 v = WIDE ? coop::ge_base_mult_wide(lds, L, a, g_tbl) : coop::ge_base_mult(lds, L, a, g_tbl);
+    const u32 v = WIDE ? coop::ge_base_mult_wide(lds, L, a, g_tbl, blind_ctx) : coop::ge_base_mult(lds, L, a, g_tbl);
     coop::ge_affine_words(xw, yw, lds, L, v);
     ge_pack(enc, xw, yw);
     if (threadIdx.x == 0) {
@@ -625,7 +626,8 @@ k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ 
 
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
-k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32* __restrict__ g_tbl)
+k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32* __restrict__ g_tbl,
+                    const u32* __restrict__ blind_ctx)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
     const coop::Lane L = coop::make_lane(threadIdx.x);
@@ -636,7 +638,7 @@ k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32*
     load32(pkw, priv, 2 * e + 1);
     ed_sign_nonce(a, r, seed, msgs.ptr(e), msgs.len(e));
     coop_setup_one(lds, L);
-    const u32 v = WIDE ? coop::ge_base_mult_wide(lds, L, r, g_tbl) : coop::ge_base_mult(lds, L, r, g_tbl);
+    const u32 v = WIDE ? coop::ge_base_mult_wide(lds, L, r, g_tbl, blind_ctx) : coop::ge_base_mult(lds, L, r, g_tbl);
     coop::ge_affine_words(xw, yw, lds, L, v);
     ge_pack(enc, xw, yw);
     ed_sign_s(s, enc, pkw, msgs.ptr(e), msgs.len(e), a, r);
@@ -1680,12 +1682,12 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
     if (n == 0) return 0;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
-    if (!blinding && fixed_base_coop_for(n)) {                // a few elements: one operation per wave
+    if ((!blinding || base_comb_wide()) && fixed_base_coop_for(n)) {   // a few elements: one operation per wave
         if (base_comb_wide()) {
             const u32* wide = nullptr;
             C25519_RC(wide_tables(&wide));
-            k_ed25519_keypair_coop<true><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, wide);
-        } else k_ed25519_keypair_coop<false><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, tbl);
+            k_ed25519_keypair_coop<true><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, wide, (const u32*)blinding);
+        } else k_ed25519_keypair_coop<false><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, tbl, nullptr);
         C25519_TRY(hipGetLastError());
         return 0;
     }
@@ -1725,12 +1727,12 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
     if (n == 0) return 0;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
-    if (!blinding && fixed_base_coop_for(n)) {                // a few elements: one operation per wave
+    if ((!blinding || base_comb_wide()) && fixed_base_coop_for(n)) {   // a few elements: one operation per wave
         if (base_comb_wide()) {
             const u32* wide = nullptr;
             C25519_RC(wide_tables(&wide));
-            k_ed25519_sign_coop<true><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, wide);
-        } else k_ed25519_sign_coop<false><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, tbl);
+            k_ed25519_sign_coop<true><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, wide, (const u32*)blinding);
+        } else k_ed25519_sign_coop<false><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, tbl, nullptr);
         C25519_TRY(hipGetLastError());
         return 0;
     }
@@ -1985,9 +1987,16 @@ static int upload_blinding(void** dctx, const void* blinding)
 {
     ThreadState& t = tls();
     C25519_RC(t.ensure());
-    C25519_RC(t.reserve_dev(ThreadState::LANES - 1, ThreadState::SLOTS - 1, 4 * BLIND_WORDS));
-    *dctx = t.dbuf[ThreadState::LANES - 1][ThreadState::SLOTS - 1];
-    C25519_TRY(hipMemcpy(*dctx, blinding, 4 * BLIND_WORDS, hipMemcpyHostToDevice));
+    // a caller signs many times with one context (the reference's C++ wrapper keeps two static ones, C++/ed25519.cpp): it
+    // is uploaded when its bytes differ from what this thread uploaded last, not with a synchronous copy per call
+    if (!t.bctx) C25519_TRY(hipMalloc(&t.bctx, 4 * BLIND_WORDS));
+    if (!t.bctx_valid || memcmp(t.bctx_host, blinding, 4 * BLIND_WORDS) != 0) {
+        t.bctx_valid = false;
+        C25519_TRY(hipMemcpy(t.bctx, blinding, 4 * BLIND_WORDS, hipMemcpyHostToDevice));
+        memcpy(t.bctx_host, blinding, 4 * BLIND_WORDS);
+        t.bctx_valid = true;
+    }
+    *dctx = t.bctx;
     return 0;
 }
 

@@ -16,12 +16,25 @@ esk, pub, priv, sig, msg = buf(32, 3), buf(32), buf(64), buf(64), buf(32, 5)
 L.ed25519_CreateKeyPair(pub, priv, None, esk)
 L.ed25519_SignMessage(sig, priv, None, msg, 32)
 assert L.ed25519_VerifySignature(sig, pub, msg, 32) == 1
+ctx = buf(2080)
+L.ed25519_Verify_Init.restype = C.c_void_p
+L.ed25519_Verify_Init(ctx, pub)
+assert L.ed25519_Verify_Check(ctx, sig, msg, 32) == 1
+bctx = buf(192)
+L.ed25519_Blinding_Init.restype = C.c_void_p
+L.ed25519_Blinding_Init(bctx, msg, 32)
 ops = {
     "curve25519_dh_CreateSharedKey": lambda: L.curve25519_dh_CreateSharedKey(shared, pk, sk),
     "curve25519_dh_CalculatePublicKey": lambda: L.curve25519_dh_CalculatePublicKey(shared, sk),
     "ed25519_CreateKeyPair": lambda: L.ed25519_CreateKeyPair(pub, priv, None, esk),
     "ed25519_SignMessage": lambda: L.ed25519_SignMessage(sig, priv, None, msg, 32),
     "ed25519_VerifySignature": lambda: L.ed25519_VerifySignature(sig, pub, msg, 32),
+    "curve25519_dh_CalculatePublicKey_fast": lambda: L.curve25519_dh_CalculatePublicKey_fast(shared, sk),
+    "ed25519_Verify_Init": lambda: L.ed25519_Verify_Init(ctx, pub),
+    "ed25519_Verify_Check": lambda: L.ed25519_Verify_Check(ctx, sig, msg, 32),
+    "ed25519_SignMessage (blinded)": lambda: L.ed25519_SignMessage(sig, priv, bctx, msg, 32),
+    "ed25519_CreateKeyPair (blinded)": lambda: L.ed25519_CreateKeyPair(pub, priv, bctx, esk),
+    "ed25519_Blinding_Init": lambda: L.ed25519_Blinding_Init(bctx, msg, 32),
 }
 for name, fn in ops.items():
     for _ in range(20):
