@@ -665,6 +665,50 @@ C25519_DEV u32 is_neutral(u32* lds, const Lane& L, u32 v)
     return acc == 0 ? 0xffffffffu : 0u;
 }
 
+// ---- the two-phase API, one operation per wave ------------------------------------------------------------------------
+// ed25519_Verify_Check for one (signature, message) pair in the REFERENCE's own operation order (edp_PolyPointMultiply,
+// ed25519_verify.c:243-280: a context is caller storage and, for an off-curve key, the value of the sum depends on the order
+// it is formed in): T = s*B + h*Q with Q's 16-row 4-fold table in LDS multiplier forms (slots QSLOT0 + row * 4 + field, unpacked from
+// the context's canonical words) and the 8-fold base table's rows fetched from device memory before the walk starts.
+constexpr int QSLOT0 = NSLOTS;
+constexpr int Q_ROWQ_OFF = (QSLOT0 + 16 * 4) * SLOT_WORDS, Q_LDS_WORDS = Q_ROWQ_OFF + 32 * 64;
+
+// limb L.c of the field an addition's first level multiplies THIS row by, row idx of the reference's table T (limb-major [30][256])
+C25519_DEV u32 ref_limb_for_add(const u32* __restrict__ tbl, const Lane& L, u32 idx)
+{
+    const u32 f = by_row(L, 1, 0, 2, 2);
+    return tbl[(f * 10 + (L.c < 10 ? L.c : 9)) * 256 + idx];
+}
+
+// s and h are consumed
+C25519_DEV u32 poly_mult(u32* lds, const Lane& L, u32 (&s)[8], u32 (&h)[8], const u32* __restrict__ ref_tbl)
+{
+    const u32 lane = L.row * 16 + L.c;
+#pragma unroll 1
+    for (int i = 0; i < 32; i++) lds[Q_ROWQ_OFF + i * 64 + lane] = ref_limb_for_add(ref_tbl, L, fold8_next(s));
+    u32 v;
+    {   // S = row h_0 of Q's table as an extended point (ge_from_pe)
+        const u32 m = fold4_next(h, false);
+        const u32* row = lds + (QSLOT0 + m * 4) * SLOT_WORDS + YO_OFF + 10 + (L.c < 10 ? L.c : 9);
+        const u32 a = row[0], b = row[SLOT_WORDS], t2d = row[2 * SLOT_WORDS], z2 = row[3 * SLOT_WORDS];
+        wave_fence();
+        put_a(lds, L, L.row, L.upper ? (L.odd_row ? t2d : z2) : (L.odd_row ? a + b : a + L.p2 - b));
+        v = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, SLOT_KDI));
+    }
+#pragma unroll 1
+    for (int i = 1; i < 32; i++) {
+        v = ge_dbl(lds, L, v);
+        v = ge_add_pe(lds, L, v, QSLOT0 + fold4_next(h, false) * 4, 0u);
+    }
+#pragma unroll 1
+    for (int i = 0; i < 32; i++) {
+        v = ge_dbl(lds, L, v);
+        v = ge_add(lds, L, v, lds[Q_ROWQ_OFF + i * 64 + lane]);
+        v = ge_add_pe(lds, L, v, QSLOT0 + fold4_next(h, true) * 4, 0u);
+    }
+    return v;
+}
+
 // all-ones iff sigma*B + tau*Q + rho*Rn is the neutral element.  tq / tr: the element's packed window tables;
 // sigma_w(w), tau_w(w), rho_w(w): words of its scalars; sc_tbl: the walk's comb table; top: first digit (>= SC_ROUNDS).
 // TABLES_IN_LDS: the window tables' multiplier forms are in their slots already (wtable_build_lds), tq / tr are not read.

@@ -1001,6 +1001,38 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(Pro
     verify_check_lane(scr, n, i, sig, pkw, msgs, tbl, lds_tbl);
 }
 
+// ed25519_Verify_Check for a call of a few pairs (the reference's prototype is a call of ONE): one pair per wave, the
+// reference's own operation order (coop::poly_mult), one shared-nothing inversion per pair.  454 us per call in the per-lane
+// kernel above (a lone lane walks 63 doublings and 96 additions); ~125 here.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
+k_ed25519_verify_check_coop(int* verdict, const void* sig, const u32* __restrict__ ctx, Msgs msgs, size_t n, const u32* __restrict__ g_tbl)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds[coop::Q_LDS_WORDS];
+    const coop::Lane L = coop::make_lane(threadIdx.x);
+    const size_t e = blockIdx.x;
+    if (e >= n) return;
+    u32 pkw[8], Rw[8], Sw[8], h[8], xw[8], yw[8], enc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) pkw[j] = ctx[j];
+    load32(Rw, sig, 2 * e);
+    ed_hram(h, Rw, pkw, msgs.ptr(e), msgs.len(e));
+    sc_mod(h);
+    load32(Sw, sig, 2 * e + 1);                            // raw 256 bits: no s < L check (ed25519_verify.c:308)
+    coop_setup_one(lds, L);
+    coop::put_y(lds, L, coop::SLOT_KDI, coop::my_limb(lds, L, fe_const(K_DI)));
+#pragma unroll 1
+    for (int r = 0; r < 16; r++)
+#pragma unroll
+        for (int f = 0; f < 4; f++) coop::put_y(lds, L, coop::QSLOT0 + r * 4 + f, coop::packed_limb(ctx + 8 + r * 32 + 8 * f, L));
+    const u32 v = coop::poly_mult(lds, L, Sw, h, g_tbl + REF_TBL_OFFSET);
+    coop::ge_affine_words(xw, yw, lds, L, v);
+    ge_pack(enc, xw, yw);
+    u32 diff = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
+    if (threadIdx.x == 0) verdict[e] = diff == 0 ? 1 : 0;
+}
+
 // ---- one key, a big batch: both scalars over wide combs ------------------------------------------------------------------
 // With ONE key for the whole batch the double-scalar product T = s*B + h*(-A) is two FIXED-base products: the base point's
 // wide comb (ge25519.cuh) and one built for -A the same way, walked together -- 39 additions and 4 doublings per signature
@@ -1876,6 +1908,12 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
     // curve (k_ed25519_verify_check_wide); decided on the device, the reference-order kernel behind it takes the batch otherwise
     const bool try_wide = n >= (size_t)c25519_host::tunable_or(c25519_host::T_ONE_KEY_WIDE, 1 << 16) &&
                           c25519_host::tunable_or(c25519_host::T_ONE_KEY_WIDE, 1) != 0;
+    if (!try_wide && coop_for(n, 1024)) {                   // a few pairs: one per wave, the reference's order
+        k_ed25519_verify_check_coop<<<(unsigned)n, 64, 0, stream>>>((int*)verdict, sig, (const u32*)ctx,
+                                                                    Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl);
+        C25519_TRY(hipGetLastError());
+        return 0;
+    }
     void* w = nullptr;
     c25519_host::WorkLease lease;
     C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
