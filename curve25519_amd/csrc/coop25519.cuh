@@ -709,6 +709,63 @@ C25519_DEV u32 poly_mult(u32* lds, const Lane& L, u32 (&s)[8], u32 (&h)[8], cons
     return v;
 }
 
+// ed25519_Verify_Init for ONE key (ed25519_verify.c:179-232; ge25519.cuh: qtable_build): the 16-row 4-fold table of Q = -A
+// -- row r = sum over the set bits i of r of 2^(64 i) Q, as (Y+X, Y-X, 2dT, 2Z) -- by the whole wave, in the reference's order
+// (three times 64 doublings; row top + s = Q_blk + row s with Q_blk the extended and row s the precomputed operand), every row
+// written to `rows_out` as four canonical 32-byte fields, byte for byte what the per-lane kernel writes (the one-key fast path
+// compares a context with that).  xl, yl: limb L.c of Q's affine x and y.  Uses the slots QSLOT0 .. for the rows.
+C25519_DEV void qtable_build_coop(u32* lds, const Lane& L, u32 xl, u32 yl, u32* __restrict__ rows_out /* 16 x 32 words */)
+{
+    const u32 one = L.c == 0 ? 1u : 0u;
+    put_y(lds, L, SLOT_K2D, my_limb(lds, L, fe_const(K_2D)));
+    // a row's precomputed form into its slots AND, canonical, into the context
+    auto store_row = [&](int r, u32 v) {
+        u32 ev, od;
+        pair_exchange(ev, od, v);                         // lower pair: X, Y; upper pair: Z, T
+        const u32 val = L.upper ? (L.odd_row ? od : ev + ev) : (L.odd_row ? od + L.p2 - ev : ev + od);
+        put_a(lds, L, L.row, val);                        // Y+X, Y-X, 2Z, T
+        const u32 w = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, SLOT_K2D));
+        put_y(lds, L, QSLOT0 + r * 4 + by_row(L, 0, 1, 3, 2), w);
+        put_a(lds, L, by_row(L, 0, 1, 3, 2), w);          // fields in context order: ypx, ymx, t2d, z2
+        wave_fence();
+        const u32 lane = L.row * 16 + L.c;
+        if (lane < 4) {                                   // lane f: field f, canonical
+            fe t;
+            get_fe(t, lds, lane);
+            u32 w8[8];
+            fe_to_words(w8, t);
+            uint4* out = reinterpret_cast<uint4*>(rows_out + r * 32 + 8 * lane);
+            out[0] = make_uint4(w8[0], w8[1], w8[2], w8[3]);
+            out[1] = make_uint4(w8[4], w8[5], w8[6], w8[7]);
+        }
+        wave_fence();
+    };
+    // row 0: the neutral element (1, 1, 0, 2)
+    {
+        const u32 lane = L.row * 16 + L.c;
+        put_y(lds, L, QSLOT0 + by_row(L, 0, 1, 3, 2), L.upper ? (L.odd_row ? 0u : one + one) : one);
+        if (lane < 4) {
+            uint4* out = reinterpret_cast<uint4*>(rows_out + 8 * lane);
+            out[0] = make_uint4(lane == 2 ? 0u : lane == 3 ? 2u : 1u, 0, 0, 0);
+            out[1] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    // Q = (x : y : 1 : x y)
+    put_a(lds, L, L.row, L.upper ? (L.odd_row ? xl : one) : (L.odd_row ? yl : xl));
+    put_y(lds, L, 4 + L.row, yl);
+    u32 q = mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_ONE, SLOT_ONE, 7));
+    store_row(1, q);
+#pragma unroll 1
+    for (int blk = 1; blk < 4; blk++) {                   // Q <- 2^64 Q, then rows [2^blk, 2^(blk+1))
+#pragma unroll 1
+        for (int i = 0; i < 64; i++) q = ge_dbl(lds, L, q);
+        const int top = 1 << blk;
+        store_row(top, q);
+#pragma unroll 1
+        for (int s = 1; s < top; s++) store_row(top + s, ge_add_pe(lds, L, q, QSLOT0 + s * 4, 0u));
+    }
+}
+
 // all-ones iff sigma*B + tau*Q + rho*Rn is the neutral element.  tq / tr: the element's packed window tables;
 // sigma_w(w), tau_w(w), rho_w(w): words of its scalars; sc_tbl: the walk's comb table; top: first digit (>= SC_ROUNDS).
 // TABLES_IN_LDS: the window tables' multiplier forms are in their slots already (wtable_build_lds), tq / tr are not read.

@@ -1001,6 +1001,25 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(Pro
     verify_check_lane(scr, n, i, sig, pkw, msgs, tbl, lds_tbl);
 }
 
+// ed25519_Verify_Init for a call of a few keys: one key per wave.  The square root by every lane on the same value (one lane's
+// code: a cooperative one would be no faster), the table by the whole wave (coop::qtable_build_coop).  501 us per call in the
+// per-lane kernel (a lone lane's 192 doublings), ~130 here.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
+k_ed25519_verify_init_coop(const void* pk, size_t n, u32* ctx_rows /* n contexts, stride_words apart, the 16 rows of each */, size_t stride_words)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds[coop::Q_LDS_WORDS];
+    const coop::Lane L = coop::make_lane(threadIdx.x);
+    const size_t e = blockIdx.x;
+    if (e >= n) return;
+    u32 pkw[8];
+    load32(pkw, pk, e);
+    ge_ext Q;
+    ed_decode_neg_key(Q, pkw);                              // -A, no validation (ed25519_verify.c:191-197)
+    coop_setup_one(lds, L);
+    const u32 xl = coop::my_limb(lds, L, Q.X), yl = coop::my_limb(lds, L, Q.Y);
+    coop::qtable_build_coop(lds, L, xl, yl, ctx_rows + e * stride_words);
+}
+
 // ed25519_Verify_Check for a call of a few pairs (the reference's prototype is a call of ONE): one pair per wave, the
 // reference's own operation order (coop::poly_mult), one shared-nothing inversion per pair.  454 us per call in the per-lane
 // kernel above (a lone lane walks 63 doublings and 96 additions); ~125 here.
@@ -1889,8 +1908,11 @@ int ed25519_Verify_Init_dev(void* ctx, const void* pk, size_t n, void* stream)
     if (int rc = check_dev_args(n, { ctx, pk })) return rc;
     if (n == 0) return 0;
     C25519_TRY(hipMemcpy2DAsync(ctx, 2080, pk, 32, 32, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    k_ed25519_verify_init<QTableCanon><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
-        pk, n, (u32*)ctx + 8, 2080 / 4);
+    if (coop_for(n, 1024))                                  // a few keys: one per wave
+        k_ed25519_verify_init_coop<<<(unsigned)n, 64, 0, (hipStream_t)stream>>>(pk, n, (u32*)ctx + 8, 2080 / 4);
+    else
+        k_ed25519_verify_init<QTableCanon><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
+            pk, n, (u32*)ctx + 8, 2080 / 4);
     C25519_TRY(hipGetLastError());
     return 0;
 }

@@ -436,8 +436,16 @@ def test_two_phase_verification(api, oracle):
                 for f in range(3):
                     assert (g[f] * e[3] - e[f] * g[3]) % P == 0, (k, r, f)
                 assert (g[3] == 0) == (e[3] == 0)
+    # calls of a few keys / pairs run one operation per wave (k_ed25519_verify_init_coop, _check_coop): the same BYTES as the
+    # per-lane kernels' contexts (the one-key fast path recognises a context by them) and the same verdicts
+    from curve25519_amd import _lib
+    with _lib.tunable("COOP_MAX", 0):
+        assert np.array_equal(api.ed25519_Verify_Init(gp), gctx) and np.array_equal(api.ed25519_Verify_Init(pub), ctx)
     gs, gm = synth.random_bytes((256, 64), 0x7201), synth.random_bytes((256, 16), 0x7202)
     for k in range(4):
+        with _lib.tunable("COOP_MAX", 0):
+            per_lane = api.ed25519_Verify_Check(gctx[k], gs, gm)
+        assert np.array_equal(api.ed25519_Verify_Check(gctx[k], gs, gm), per_lane)
         assert np.array_equal(api.ed25519_Verify_Check(gctx[k], gs, gm),
                               oracle.ed25519_verify(gs, np.repeat(gp[k:k + 1], 256, axis=0), gm))
 
