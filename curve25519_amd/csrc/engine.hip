@@ -661,6 +661,22 @@ __global__ void __launch_bounds__(256) k_ed25519_blinding_init(u32* ctx, const u
     if (threadIdx.x == 0) ed_blinding_init_lane(ctx, seed, seed_len, lds_tbl);
 }
 
+// ... and with the whole wave (the wide comb's rows fetched from device memory, t * B and its affine conversion cooperative): what
+// ed25519_Blinding_Init runs unless the LDS comb is selected -- 196 -> ~70 us per context
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
+k_ed25519_blinding_init_coop(u32* ctx, const uint8_t* seed, size_t seed_len, const u32* __restrict__ wide)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
+    const coop::Lane L = coop::make_lane(threadIdx.x);
+    u32 t[8], bl[8], zr[8], xw[8], yw[8];
+    ed_blinding_scalars(t, bl, zr, seed, seed_len);
+    coop_setup_one(lds, L);
+    const u32 v = coop::ge_base_mult_wide(lds, L, t, wide);
+    coop::ge_affine_words(xw, yw, lds, L, v);
+    if (threadIdx.x == 0) ed_blinding_store(ctx, bl, zr, xw, yw);
+    coop::wipe(lds, coop::LDS_WORDS);
+}
+
 // ed25519_Verify_Init (ed25519_verify.c:179-232): decompress -A (inverted parity :192-195, no validation) and
 // fill the key's 16-row 4-fold table.  `tables` holds n tables of Tbl's format, `stride_words` apart.
 template <typename Tbl>
@@ -1842,7 +1858,13 @@ int ed25519_Blinding_Init_dev(void* ctx, const void* seed, size_t seed_len, void
     if (int rc = check_dev_args(1, { ctx })) return rc;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
-    k_ed25519_blinding_init<<<1, 256, 0, (hipStream_t)stream>>>((u32*)ctx, (const uint8_t*)seed, seed_len, tbl);
+    if (base_comb_wide()) {
+        const u32* wide = nullptr;
+        C25519_RC(wide_tables(&wide));
+        k_ed25519_blinding_init_coop<<<1, 64, 0, (hipStream_t)stream>>>((u32*)ctx, (const uint8_t*)seed, seed_len, wide);
+    } else {
+        k_ed25519_blinding_init<<<1, 256, 0, (hipStream_t)stream>>>((u32*)ctx, (const uint8_t*)seed, seed_len, tbl);
+    }
     C25519_TRY(hipGetLastError());
     return 0;
 }

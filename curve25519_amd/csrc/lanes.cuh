@@ -275,30 +275,31 @@ C25519_DEV void ge_signed_comb_row(u32 (&rows)[3][8], u32 idx, int extra, int te
 // t = digest[0..31] mod L, bl = L - t, zr = digest[32..63], BP = PE(t*B) (affine, Z2 = 2).  The 32-byte domain string
 // "c25519_amd_blinding_cxv1--------" takes the place of the reference's compiled-in custom blinder (custom_blind.c),
 // which likewise only seeds the derivation.  lds_tbl: the BASE_NT staged signed comb tables.
-C25519_DEV void ed_blinding_init_lane(u32* ctx, const uint8_t* seed, size_t seed_len, const u32* lds_tbl)
+// the context's scalars: t = digest[0..31] mod L (canonical; BP = t * B), bl = L - t, zr = digest[32..63]
+C25519_DEV void ed_blinding_scalars(u32 (&t)[8], u32 (&bl)[8], u32 (&zr)[8], const uint8_t* seed, size_t seed_len)
 {
     const u32 domain[8] = { 0x35353263u, 0x615f3931u, 0x625f646du, 0x646e696cu, 0x5f676e69u, 0x31767863u, 0x2d2d2d2du, 0x2d2d2d2du };
     u64 pre[4], dg[8];
-    u32 le[16], t[8], bl[8];
+    u32 le[16];
     sha512_words_from_le32(pre, domain);
     sha512_prefixed<4>(dg, pre, seed, seed_len);
     sha512_digest_le_words(le, dg);
 #pragma unroll
-    for (int i = 0; i < 8; i++) t[i] = le[i];
+    for (int i = 0; i < 8; i++) { t[i] = le[i]; zr[i] = le[8 + i]; }
     sc_mod(t);                                            // eco_Mod (:316)
-    {
-        u32 borrow = 0;                                   // bl = L - t (:317)
+    u32 borrow = 0;                                       // bl = L - t (:317)
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const u64 d = (u64)K_L[i] - t[i] - borrow;
-            bl[i] = (u32)d;
-            borrow = (u32)(d >> 63);
-        }
+    for (int i = 0; i < 8; i++) {
+        const u64 d = (u64)K_L[i] - t[i] - borrow;
+        bl[i] = (u32)d;
+        borrow = (u32)(d >> 63);
     }
-    ge_ext S;
-    ge_base_mult(S, t, lds_tbl);                          // T = t*B (:319-321 without the bootstrap blinder)
-    u32 xw[8], yw[8], w[8];
-    ge_to_affine_words(xw, yw, S);
+}
+
+// the 48 context words from the scalars and the canonical affine coordinates of BP = t * B: BP as (y+x, y-x, 2dxy, 2)
+C25519_DEV void ed_blinding_store(u32* ctx, const u32 (&bl)[8], const u32 (&zr)[8], const u32 (&xw)[8], const u32 (&yw)[8])
+{
+    u32 w[8];
     fe x, y, ypx, ymx, t2d, tmp;
     fe_from_words(x, xw);
     fe_from_words(y, yw);
@@ -307,7 +308,7 @@ C25519_DEV void ed_blinding_init_lane(u32* ctx, const uint8_t* seed, size_t seed
     fe_mul(tmp, x, y);
     fe_mul(t2d, tmp, fe_const(K_2D));
 #pragma unroll
-    for (int i = 0; i < 8; i++) { ctx[i] = bl[i]; ctx[8 + i] = le[8 + i]; }
+    for (int i = 0; i < 8; i++) { ctx[i] = bl[i]; ctx[8 + i] = zr[i]; }
     fe_to_words(w, ypx);
 #pragma unroll
     for (int i = 0; i < 8; i++) ctx[16 + i] = w[i];
@@ -319,6 +320,16 @@ C25519_DEV void ed_blinding_init_lane(u32* ctx, const uint8_t* seed, size_t seed
     for (int i = 0; i < 8; i++) ctx[32 + i] = w[i];
 #pragma unroll
     for (int i = 0; i < 8; i++) ctx[40 + i] = i == 0 ? 2u : 0u;      // Z2 = 2 (affine BP)
+}
+
+C25519_DEV void ed_blinding_init_lane(u32* ctx, const uint8_t* seed, size_t seed_len, const u32* lds_tbl)
+{
+    u32 t[8], bl[8], zr[8], xw[8], yw[8];
+    ed_blinding_scalars(t, bl, zr, seed, seed_len);
+    ge_ext S;
+    ge_base_mult(S, t, lds_tbl);                          // T = t*B (:319-321 without the bootstrap blinder)
+    ge_to_affine_words(xw, yw, S);
+    ed_blinding_store(ctx, bl, zr, xw, yw);
 }
 
 // ---- unit-test operations ---------------------------------------------------------------------------------------
