@@ -89,6 +89,7 @@ int load_rccl(Rccl& r)
 }
 
 constexpr int MAX_ARR = 5;
+constexpr int MAX_DEVICES = 64;             // entries of a handle's device list (the copier hands one block per device to the copy threads)
 
 // One per device (plus one more on the root for the gathered rows): a thread bound to that device for the life of the
 // handle (its thread-local ThreadState -- streams, pinned and device staging, work scratch -- is created on first use and
@@ -414,9 +415,9 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
                         const hipError_t e = hipEventSynchronize(s2.ev);   // also when skipped: the DMA into the slot must have ended
                         if (e == hipSuccess && !skipped) {
                             // D blocks of real (not pad) rows, all of them to the process-wide copy threads at once
-                            c25519_host::SharedCopyPool::Range rg[64];
+                            c25519_host::SharedCopyPool::Range rg[MAX_DEVICES];
                             int cntr = 0;
-                            for (int d = 0; d < D && cntr < 64; d++) {
+                            for (int d = 0; d < D; d++) {
                                 const size_t cnt_d = lo[d + 1] - lo[d];
                                 const size_t real = r0 >= cnt_d ? 0 : (r0 + cnt < cnt_d ? cnt : cnt_d - r0);
                                 if (real) rg[cntr++] = { out + (lo[d] + r0) * elem, (const char*)s2.pinned + cnt * d * elem, real * elem };
@@ -460,7 +461,7 @@ extern "C" {
 
 int c25519_amd_multi_create(c25519_amd_multi** out, const int* devices, int n_dev)
 {
-    if (!out || !devices || n_dev < 1) return bad_arg("c25519_amd_multi_create: bad arguments");
+    if (!out || !devices || n_dev < 1 || n_dev > MAX_DEVICES) return bad_arg("c25519_amd_multi_create: bad arguments (1..64 devices)");
     int have = 0;
     C25519_TRY(hipGetDeviceCount(&have));
     for (int d = 0; d < n_dev; d++)
@@ -468,7 +469,7 @@ int c25519_amd_multi_create(c25519_amd_multi** out, const int* devices, int n_de
     // virtual devices: a list that names a device twice, or C25519_AMD_MULTI_VIRTUAL=V with a one-device list
     std::vector<int> list(devices, devices + n_dev);
     const long v = c25519_host::tunable_or(c25519_host::T_MULTI_VIRTUAL, 0);
-    if (n_dev == 1 && v > 1) list.assign((size_t)(v > 64 ? 64 : v), devices[0]);
+    if (n_dev == 1 && v > 1) list.assign((size_t)(v > MAX_DEVICES ? MAX_DEVICES : v), devices[0]);
     n_dev = (int)list.size();
     bool dup = false;
     for (int d = 0; d < n_dev; d++)

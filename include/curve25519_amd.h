@@ -179,7 +179,7 @@ int ed25519_Verify_Check_dev(void *verdict, const void *ctx, const void *sig, co
  * one RCCL communicator per device and grow-only result buffers (zeroed before they are freed); it is not thread-safe
  * (one call at a time per handle). */
 typedef struct c25519_amd_multi c25519_amd_multi;
-int  c25519_amd_multi_create(c25519_amd_multi **m, const int *devices, int n_dev);
+int  c25519_amd_multi_create(c25519_amd_multi **m, const int *devices, int n_dev);   /* 1 <= n_dev <= 64 */
 void c25519_amd_multi_destroy(c25519_amd_multi *m);
 int  c25519_amd_multi_device_count(const c25519_amd_multi *m);
 int  c25519_amd_multi_helper_threads(const c25519_amd_multi *m);  /* host threads that copy memory while a call runs */
