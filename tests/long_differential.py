@@ -2,7 +2,8 @@
 """tests/long_differential.py -- opt-in long run (not collected by pytest): the HIP path against the REAL reference
 (oracle/_ref, the reference's own C files compiled by oracle/Makefile) on fresh random inputs at volume, with the edge
 encodings of tests/vectors.py sprinkled through every batch.  Every round: 2^20 X25519 shared keys, 2^18 key pairs +
-signatures, 2^18 verifications with corrupted entries, garbage keys and S + L rewrites; and, for the one-operation-per-wave
+signatures (unblinded and with a fresh blinding context), 2^18 verifications with corrupted entries, garbage keys and S + L
+rewrites, three one-key two-phase batches (honest / garbage / edge key); and, for the one-operation-per-wave
 kernels small calls run (csrc/coop25519.cuh), --small-calls calls of 1..2048 elements of every operation built the same way.
 
     python tests/long_differential.py [--rounds 8] [--seed 1]
@@ -18,7 +19,9 @@ sys.path.insert(0, HERE)
 import numpy as np  # noqa: E402
 
 import vectors  # noqa: E402
-from curve25519_amd import api, synth  # noqa: E402
+import ctypes as C  # noqa: E402
+
+from curve25519_amd import _lib, api, synth  # noqa: E402
 from oracle_lib import Reference  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -29,6 +32,7 @@ ap.add_argument("--small-calls", type=int, default=12, help="calls of a few elem
 args = ap.parse_args()
 assert Reference.available(), "oracle/_ref is not built (make -C oracle ref)"
 ref = Reference()
+LIB = _lib.load()
 T = args.threads
 L = vectors.L
 
@@ -85,6 +89,38 @@ for r in range(args.rounds):
     rok = ref.ed25519_verify_threaded(bsig, vpk, bmsg, T)
     assert np.array_equal(ok, rok), f"round {r}: verdicts differ at rows {np.nonzero(ok != rok)[0][:5]}"
     total["verify"] += m
+    # blinded calls: a fresh context per round (ed25519_Blinding_Init on the device), the bytes of the unblinded calls
+    seed = rng.integers(0, 256, int(rng.integers(1, 130)), dtype=np.uint8)
+    bctx = np.zeros(192, np.uint8)
+    LIB.ed25519_Blinding_Init.restype = C.c_void_p
+    assert LIB.ed25519_Blinding_Init(bctx.ctypes.data, seed.ctypes.data, len(seed)) == bctx.ctypes.data
+
+    def blinded(lo, k):
+        bp, bq, bs = np.empty((k, 32), np.uint8), np.empty((k, 64), np.uint8), np.empty((k, 64), np.uint8)
+        e, q, mm = np.ascontiguousarray(esk[lo:lo + k]), np.ascontiguousarray(priv[lo:lo + k]), np.ascontiguousarray(msg[lo:lo + k])
+        _lib.check(LIB.ed25519_CreateKeyPair_blinded_batch(bp.ctypes.data, bq.ctypes.data, bctx.ctypes.data, e.ctypes.data, k), "keypair blinded")
+        _lib.check(LIB.ed25519_SignMessage_blinded_batch(bs.ctypes.data, q.ctypes.data, bctx.ctypes.data, mm.ctypes.data if mlen else None, mlen, k), "sign blinded")
+        return bp, bq, bs
+
+    bp, bq, bs = blinded(0, m)
+    assert np.array_equal(bp, pub) and np.array_equal(bq, priv) and np.array_equal(bs, rsig), f"round {r}: blinded calls differ"
+    total["blinded keypair + sign"] = total.get("blinded keypair + sign", 0) + m
+    # two-phase verification, ONE key for the batch (2^16 pairs and more: two wide combs; fewer: the reference's order): an
+    # honest key, a garbage one (about half are off the curve), an edge encoding (small order / non-canonical)
+    for kind in range(3):
+        j = int(rng.integers(0, m))
+        k1 = (1 << 16) + int(rng.integers(0, 1 << 14)) if kind == 0 or r % 2 == 0 else int(rng.integers(2049, 1 << 15))
+        lo = int(rng.integers(0, m - k1))
+        one_priv = np.ascontiguousarray(np.broadcast_to(priv[j], (k1, 64)))
+        s1 = api.ed25519_SignMessage(one_priv, msg[lo:lo + k1])
+        s1b, m1, _ = synth.corrupt_for_verify(s1, msg[lo:lo + k1]) if mlen else (s1.copy(), msg[lo:lo + k1], None)
+        key = pub[j].copy() if kind == 0 else rng.integers(0, 256, 32, dtype=np.uint8) if kind == 1 else edge32[int(rng.integers(0, len(edge32)))].copy()
+        ctx = api.ed25519_Verify_Init(key[None, :])[0]
+        v1 = api.ed25519_Verify_Check(ctx, s1b, m1)
+        v2 = api.ed25519_Verify_Check(ctx, s1b, m1)                     # the remembered context: no second preparation
+        rv = ref.ed25519_verify_threaded(s1b, np.ascontiguousarray(np.broadcast_to(key, (k1, 32))), m1, T)
+        assert np.array_equal(v1, rv) and np.array_equal(v2, rv), f"round {r}: one-key verdicts differ (kind {kind}, n = {k1}) at rows {np.nonzero(v1 != rv)[0][:5]}"
+        total["one-key verify"] = total.get("one-key verify", 0) + k1
     # calls of a few elements: other kernels (one operation per wave), same inputs' distribution
     for c in range(args.small_calls):
         k = int(rng.integers(1, 2049))
@@ -98,6 +134,14 @@ for r in range(args.rounds):
         assert np.array_equal(p2, pub[lo:lo + k]) and np.array_equal(q2, priv[lo:lo + k]), f"round {r}: small keypair call {c} (n = {k}) differs"
         assert np.array_equal(api.ed25519_SignMessage(priv[lo:lo + k], msg[lo:lo + k]), rsig[lo:lo + k]), f"round {r}: small sign call {c} (n = {k}) differs"
         assert np.array_equal(api.ed25519_VerifySignature(bsig[lo:lo + k], vpk[lo:lo + k], bmsg[lo:lo + k]), rok[lo:lo + k]), f"round {r}: small verify call {c} (n = {k}) differs"
+        bp, bq, bs = blinded(lo, k)
+        assert np.array_equal(bp, pub[lo:lo + k]) and np.array_equal(bq, priv[lo:lo + k]) and np.array_equal(bs, rsig[lo:lo + k]), f"round {r}: small blinded call {c} (n = {k}) differs"
+        kk = min(k, 1024)
+        ctxs = api.ed25519_Verify_Init(vpk[lo:lo + kk])
+        j = int(rng.integers(0, kk))
+        one = api.ed25519_Verify_Check(ctxs[j], bsig[lo:lo + kk], bmsg[lo:lo + kk])
+        want1 = ref.ed25519_verify_threaded(bsig[lo:lo + kk], np.ascontiguousarray(np.broadcast_to(vpk[lo + j], (kk, 32))), bmsg[lo:lo + kk], T)
+        assert np.array_equal(one, want1), f"round {r}: small two-phase call {c} (n = {kk}) differs"
         for key in ("x25519", "keypair", "sign", "verify"):
             total["small " + key] = total.get("small " + key, 0) + k
     print(f"round {r}: ok (msg {mlen} B, accepted {int(ok.sum())} of {m})   {time.time() - t0:.0f} s", flush=True)
