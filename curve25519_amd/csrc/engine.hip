@@ -18,6 +18,7 @@
 #include "lanes.cuh"
 #include "verify_fast.cuh"
 #include "coop25519.cuh"
+#include "coop_ops.cuh"
 
 #include "../../include/curve25519_amd.h"
 #include "../../include/curve25519_dh.h"
@@ -267,69 +268,8 @@ template <bool BASE9>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop(void* out, const void* pk, void* sk, size_t n)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::ROWQ_OFF];
-    const coop::Lane L = coop::make_lane(threadIdx.x);
-    const size_t e = blockIdx.x;
-    if (e >= n) return;
-    u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8];
-    if (!BASE9) load32(u, pk, e);
-    load32(k, sk, e);
-    clamp_words(k);
-    if (threadIdx.x == 0) store32(sk, e, k);            // the reference clamps in the caller's buffer
-    fe X1, one;
-    fe_from_words(X1, u);
-    fe_set_u32(one, 1);
-    const u32 x1 = coop::my_limb(lds, L, X1), o1 = coop::my_limb(lds, L, one);
-    coop::put_y(lds, L, coop::SLOT_X1, x1);
-    coop::put_y(lds, L, coop::SLOT_ONE, o1);
-    // P = (X1 : 1) in rows 0, 1 and Q = 2P in rows 2, 3; bit 254 is the leading one (curve25519_dh.c:123-125 with zr = 1)
-    u32 v = L.odd_row ? o1 : x1;
-    {
-        const u32 q = coop::mont_double(lds, L, v);
-        v = L.upper ? q : v;
-    }
-    u32 prev = 1;
-#pragma unroll 1
-    for (int w = 7; w >= 0; w--) {
-        u32 kw = k[7];                                   // the scalar's words as a queue (x25519.cuh)
-#pragma unroll
-        for (int t = 7; t > 0; t--) k[t] = k[t - 1];
-        const int top = (w == 7) ? 29 : 31, bottom = (w == 0) ? 3 : 0;
-        kw <<= (31 - top);
-#pragma unroll 1
-        for (int b = top; b >= bottom; b--) {
-            const u32 bit = kw >> 31;
-            kw <<= 1;
-#ifndef C25519_COOP_SKIP_LADDER                           // timing experiments only (tools/build_variants.sh): wrong results
-            v = coop::ladder_step<BASE9>(lds, L, v, (u32)0 - (u32)(bit == prev));
-#endif
-            prev = bit;
-        }
-    }
-    // P = the sum if the last bit was one, else the double (curve25519_dh.c:148-150): into both row pairs, x in the even
-    // rows, z in the odd; then the three clamped-away low bits -- three doublings of P
-    u32 lo, hi;
-    coop::half_exchange(lo, hi, v);
-    u32 p = hi ^ ((hi ^ lo) & ((u32)0 - prev));
-#pragma unroll 1
-    for (int i = 0; i < 3; i++) p = coop::mont_double(lds, L, p);
-    // x / z: the odd rows' inverse times the even rows' x, in every row; canonical bytes by every lane
-#ifndef C25519_COOP_SKIP_INVERT
-    const u32 zi = coop::invert(lds, L, p);
-#else
-    const u32 zi = p;
-#endif
-    u32 px, pz, ix, iz;
-    coop::pair_exchange(px, pz, p);
-    coop::pair_exchange(ix, iz, zi);
-    const u32 r = coop::mul2(lds, L, px, iz);
-    coop::put_a(lds, L, L.row, r);
-    coop::wave_fence();
-    fe R;
-    coop::get_fe(R, lds, 0);
-    u32 wds[8];
-    fe_to_words(wds, R);
-    if (threadIdx.x == 0) store32(out, e, wds);         // written last: `out` may alias `pk`
-    coop::wipe(lds, coop::ROWQ_OFF);
+    if (blockIdx.x >= n) return;
+    coop::x25519_one<BASE9>(lds, coop::make_lane(threadIdx.x), out, pk, sk, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,36 +502,14 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_finish(void* sig, 
 // The same three operations for a call of a few elements, ONE operation per wave (coop25519.cuh): hashing and scalar
 // arithmetic by every lane on the same values, the fixed-base walk, the inversion and the affine conversion cooperative.
 // (A blinding context: over the wide comb only -- with the LDS comb a blinded call runs the batch kernels.)
-C25519_DEV void coop_setup_one(u32* lds, const coop::Lane& L)
-{
-    fe one;
-    fe_set_u32(one, 1);
-    coop::put_y(lds, L, coop::SLOT_ONE, coop::my_limb(lds, L, one));
-}
-
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u32* __restrict__ g_tbl,
                        const u32* __restrict__ blind_ctx)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
-    const coop::Lane L = coop::make_lane(threadIdx.x);
-    const size_t e = blockIdx.x;
-    if (e >= n) return;
-    u32 seed[8], a[8], xw[8], yw[8], enc[8];
-    u64 b_words[4];
-    load32(seed, sk, e);
-    ed_expand_seed(a, b_words, seed);
-    coop_setup_one(lds, L);
-    const u32 v = WIDE ? coop::ge_base_mult_wide(lds, L, a, g_tbl, blind_ctx) : coop::ge_base_mult(lds, L, a, g_tbl);
-    coop::ge_affine_words(xw, yw, lds, L, v);
-    ge_pack(enc, xw, yw);
-    if (threadIdx.x == 0) {
-        store32(priv, 2 * e, seed);
-        store32(priv, 2 * e + 1, enc);
-        store32(pub, e, enc);
-    }
-    coop::wipe(lds, coop::LDS_WORDS);
+    if (blockIdx.x >= n) return;
+    coop::keypair_one<WIDE>(lds, coop::make_lane(threadIdx.x), pub, priv, sk, blockIdx.x, g_tbl, blind_ctx);
 }
 
 // curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189): S = clamp(sk) * B on the Edwards side, u = (Z + Y) / (Z - Y)
@@ -600,28 +518,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
-    const coop::Lane L = coop::make_lane(threadIdx.x);
-    const size_t e = blockIdx.x;
-    if (e >= n) return;
-    u32 k[8], wds[8];
-    load32(k, sk, e);
-    clamp_words(k);
-    if (threadIdx.x == 0) store32(sk, e, k);
-    coop_setup_one(lds, L);
-    const u32 v = WIDE ? coop::ge_base_mult_wide(lds, L, k, g_tbl) : coop::ge_base_mult(lds, L, k, g_tbl);
-    u32 ev, od, y, z, t;
-    coop::pair_exchange(ev, od, v);                       // lower pair: X, Y; upper pair: Z, T
-    coop::half_exchange(y, t, od);                        // y: Y in every row
-    coop::half_exchange(t, z, ev);                        // z: Z in every row
-    const u32 zi = coop::invert(lds, L, z + L.p2 - y);
-    const u32 r = coop::mul2(lds, L, z + y, zi);
-    coop::put_a(lds, L, L.row, r);
-    coop::wave_fence();
-    fe R;
-    coop::get_fe(R, lds, 0);
-    fe_to_words(wds, R);
-    if (threadIdx.x == 0) store32(pk, e, wds);
-    coop::wipe(lds, coop::LDS_WORDS);
+    if (blockIdx.x >= n) return;
+    coop::public_fast_one<WIDE>(lds, coop::make_lane(threadIdx.x), pk, sk, blockIdx.x, g_tbl);
 }
 
 template <bool WIDE>
@@ -630,23 +528,8 @@ k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32*
                     const u32* __restrict__ blind_ctx)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
-    const coop::Lane L = coop::make_lane(threadIdx.x);
-    const size_t e = blockIdx.x;
-    if (e >= n) return;
-    u32 seed[8], pkw[8], a[8], r[8], xw[8], yw[8], enc[8], s[8];
-    load32(seed, priv, 2 * e);
-    load32(pkw, priv, 2 * e + 1);
-    ed_sign_nonce(a, r, seed, msgs.ptr(e), msgs.len(e));
-    coop_setup_one(lds, L);
-    const u32 v = WIDE ? coop::ge_base_mult_wide(lds, L, r, g_tbl, blind_ctx) : coop::ge_base_mult(lds, L, r, g_tbl);
-    coop::ge_affine_words(xw, yw, lds, L, v);
-    ge_pack(enc, xw, yw);
-    ed_sign_s(s, enc, pkw, msgs.ptr(e), msgs.len(e), a, r);
-    if (threadIdx.x == 0) {
-        store32(sig, 2 * e, enc);
-        store32(sig, 2 * e + 1, s);
-    }
-    coop::wipe(lds, coop::LDS_WORDS);
+    if (blockIdx.x >= n) return;
+    coop::sign_one<WIDE>(lds, coop::make_lane(threadIdx.x), sig, priv, msgs, blockIdx.x, g_tbl, blind_ctx);
 }
 
 // ed25519_Blinding_Init (ed25519_sign.c:289-331) for one context: digest = SHA-512(domain || seed),
@@ -667,14 +550,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_blinding_init_coop(u32* ctx, const uint8_t* seed, size_t seed_len, const u32* __restrict__ wide)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
-    const coop::Lane L = coop::make_lane(threadIdx.x);
-    u32 t[8], bl[8], zr[8], xw[8], yw[8];
-    ed_blinding_scalars(t, bl, zr, seed, seed_len);
-    coop_setup_one(lds, L);
-    const u32 v = coop::ge_base_mult_wide(lds, L, t, wide);
-    coop::ge_affine_words(xw, yw, lds, L, v);
-    if (threadIdx.x == 0) ed_blinding_store(ctx, bl, zr, xw, yw);
-    coop::wipe(lds, coop::LDS_WORDS);
+    coop::blinding_init_one(lds, coop::make_lane(threadIdx.x), ctx, seed, seed_len, wide);
 }
 
 // ed25519_Verify_Init (ed25519_verify.c:179-232): decompress -A (inverted parity :192-195, no validation) and
@@ -734,19 +610,8 @@ __global__ void __launch_bounds__(ED_BLOCK, C25519_VC_WAVES) k_ed25519_verify_ch
 //   bit 0  R decodes canonically onto the curve      bit 1  the key is on the curve
 //   bit 2  the short vector fits the walk             bit 3  tau < 0
 //   bit 4  the element is on the slow list            bits 8..13  top nonzero digit of the element's scalars
-struct FastScratch {
-    u32 *tables;            // per lane: window table of +-Q, then of -R (2 x WTABLE_WORDS of packed 128-byte rows, 128-byte aligned)
-    u32 *sigma, *rho, *tau, *flags;
-    u32 *slow_list;         // indices of the elements the reference-order kernel has to decide ...
-    u32 *slow_count;        // ... and how many; [1], [2]: how many elements `order` holds from its front / from its back
-    u32 *order;             // the walk's lane j takes element order[j]: elements whose scalars start at digit 32 or below
-                            // from the front, the few longer ones from the back, so that a wave of 64 rarely holds one
-    u32 *slow_report;       // a word that outlives the call's scratch: the count again, for c25519_amd_verify_last_slow_elements
-    int lat_cap_bits;       // longest short vector the walk takes (LAT_CAP_BITS; lower only under the test knob VERIFY_LAT_CAP_BITS)
-};
-constexpr size_t FAST_TABLE_WORDS = 2 * WTABLE_WORDS;
+// (FastScratch, the scratch of the lattice path, and the FLAG_* bits: coop_ops.cuh)
 constexpr int FS_BLOCK = 256;
-constexpr u32 FLAG_R_OK = 1u, FLAG_KEY_OK = 2u, FLAG_FITS = 4u, FLAG_TAU_NEG = 8u, FLAG_SLOW = 16u;
 #ifndef C25519_VW_WAVES
 #define C25519_VW_WAVES 2            // waves per SIMD the register allocator aims at: the walk kernel (rows prefetched) ...
 #endif
@@ -857,92 +722,19 @@ __global__ void __launch_bounds__(WALK_BLOCK, C25519_VW_WAVES) k_ed25519_verify_
     verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
 }
 
-// The whole lattice path of ONE element in ONE launch, for a call of a few elements: a workgroup of THREE waves per element.
-//   phase 1   wave 0 hashes and reduces (step 1: every lane on the same values) WHILE wave 1 decodes the key in lane 0 and R in
-//             lane 1 (the two square roots of step 2, which do not need the scalars);
-//   phase 2   the equation sigma*B + tau*Q + rho*(-R) = O is three independent products, one wave each, every wave in an LDS
-//             region of its own: wave 0 builds the key's window table with the whole wave (coop::wtable_build_lds: straight into
-//             the forms the walk reads, no round trip through memory) and walks tau over it, wave 1 does the same for R and rho,
-//             wave 2 runs sigma*B over the comb by Horner's rule -- each needs the ~129 doublings the joint walk shared, but
-//             side by side on three SIMDs: 330 product levels in a row instead of 440;
-//   phase 3   waves 1 and 2 hand their points to wave 0 in precomputed form; two additions and the neutral-element test.
-// Three launches ran 40 + 83 + 91 us one after the other for one signature; this is ~60 + ~60.  Elements the path cannot
-// decide go on the slow list exactly as in the batch kernels (the host zeroes the list's counter in front of the launch).
+// The whole lattice path of ONE element in ONE launch, for a call of a few elements: a workgroup of THREE waves per element
+// (coop::verify_three_waves, coop_ops.cuh: wave 0 hashes and reduces while wave 1 takes the two square roots; then the three
+// products of sigma*B + tau*Q + rho*(-R) = O side by side, a wave each; wave 0 adds and tests).  Three launches ran
+// 40 + 83 + 91 us one after the other for one signature; this is ~60 + ~60.  The host zeroes the slow list's counter in front
+// of the launch.
 __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_ed25519_verify_one_per_group(FastScratch fs, int* verdict, const void* sig, const void* pk, Msgs msgs, size_t n,
                                const u32* __restrict__ g_tbl)
 {
-    // wave 0: operand slots, one window table, eight hand-over slots; wave 1: operand slots, one table; wave 2: operand slots, the
-    // comb's row queue: 45 KiB per workgroup, three workgroups per CU
-    constexpr int TABLE_SLOTS = WTABLE_ROWS * 4, HANDOVER = coop::VSLOT0 + TABLE_SLOTS;
-    constexpr int BASE1 = (HANDOVER + 8) * coop::SLOT_WORDS, BASE2 = BASE1 + (coop::VSLOT0 + TABLE_SLOTS) * coop::SLOT_WORDS;
-    constexpr int ROWQ2 = coop::NSLOTS * coop::SLOT_WORDS;
-    __shared__ __attribute__((aligned(16))) u32 lds_all[BASE2 + ROWQ2 + SC_ROUNDS * 4 * 64];
-    __shared__ u32 park[40];                                // limbs of the key's x, y (0 .. 19) and of R's (20 .. 39)
-    __shared__ u32 hand[4];                                 // tau < 0; wave 0's flag bits; key on the curve; R decodes canonically
-    const size_t e = blockIdx.x;
-    if (e >= n) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    u32* lds = lds_all + (wave == 0 ? 0 : wave == 1 ? BASE1 : BASE2);
-    if (wave == 0) {
-        u32 pkw[8], Rw[8], Sw[8], cols[SIGMA_WORDS], rho[5], tau[5], tau_neg;
-        load32(pkw, pk, e);
-        load32(Rw, sig, 2 * e);
-        load32(Sw, sig, 2 * e + 1);
-        const u32 lat_ok = ed_verify_fast_scalars(cols, rho, tau, tau_neg, pkw, Rw, Sw, msgs.ptr(e), msgs.len(e), fs.lat_cap_bits);
-        if (lane == 0) {
-#pragma unroll
-            for (int w = 0; w < SIGMA_WORDS; w++) fs.sigma[(size_t)w * n + e] = cols[w];
-#pragma unroll
-            for (int w = 0; w < 5; w++) { fs.rho[(size_t)w * n + e] = rho[w]; fs.tau[(size_t)w * n + e] = tau[w]; }
-            const int top = lat_ok ? walk_top_digit(tau, rho) : 0;
-            hand[0] = tau_neg;
-            hand[1] = (lat_ok & FLAG_FITS) | (tau_neg & FLAG_TAU_NEG) | ((u32)top << 8);
-        }
-    } else if (wave == 1 && lane < 2) {
-        u32 w[8];
-        fe X, Y;
-        if (lane) load32(w, sig, 2 * e); else load32(w, pk, e);
-        const u32 ok = ed_verify_fast_decode(X, Y, w, lane ? 0xffffffffu : 0u, 0u);   // (the key's sign of tau: wave 0, below)
-        hand[2 + lane] = ok ? 1u : 0u;
-#pragma unroll
-        for (int i = 0; i < 10; i++) { park[20 * lane + i] = X.v[i]; park[20 * lane + 10 + i] = Y.v[i]; }
-    }
-    __syncthreads();
-    const u32 f = hand[1] | (hand[2] ? FLAG_KEY_OK : 0u) | (hand[3] ? FLAG_R_OK : 0u);
-    if ((f & (FLAG_KEY_OK | FLAG_FITS)) != (FLAG_KEY_OK | FLAG_FITS)) {      // off-curve key / over-long vector: the slow list
-        if (threadIdx.x == 0) {
-            fs.flags[e] = f | FLAG_SLOW;
-            fs.slow_list[atomicAdd(fs.slow_count, 1u)] = (u32)e;
-        }
-        return;
-    }
-    if (threadIdx.x == 0) fs.flags[e] = f;
-    const coop::Lane L = coop::make_lane(lane);
-    const int top = (int)((f >> 8) & 63u);
-    const u32 c = L.c < 10 ? L.c : 0;
-    coop_setup_one(lds, L);
-    coop::put_y(lds, L, coop::SLOT_KDI, coop::my_limb(lds, L, fe_const(K_DI)));
-    u32 v;
-    if (wave == 0) {                                        // |tau| * (+-Q)
-        const u32 xl = hand[0] ? L.p2 - park[c] : park[c]; // tau < 0: the table of -Q (ed_verify_fast_decode)
-        coop::wtable_build_lds(lds, L, 0, xl, park[10 + c]);
-        v = coop::walk_point(lds, L, [&](int w) -> u32 { return fs.tau[(size_t)w * n + e]; }, coop::VSLOT0, top);
-    } else if (wave == 1) {                                 // rho * (-R)
-        coop::wtable_build_lds(lds, L, 0, park[20 + c], park[30 + c]);
-        v = coop::walk_point(lds, L, [&](int w) -> u32 { return fs.rho[(size_t)w * n + e]; }, coop::VSLOT0, top);
-        coop::store_pe(lds, lds_all, L, HANDOVER, v);
-    } else {                                                // sigma * B
-        coop::put_y(lds, L, coop::SLOT_K2D, coop::my_limb(lds, L, fe_const(K_2D)));
-        v = coop::walk_comb(lds, lds + ROWQ2, L, [&](int w) -> u32 { return fs.sigma[(size_t)w * n + e]; }, g_tbl + SC_TBL_OFFSET);
-        coop::store_pe(lds, lds_all, L, HANDOVER + 4, v);
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    v = coop::ge_add_pe(lds, L, v, HANDOVER, 0u);
-    v = coop::ge_add_pe(lds, L, v, HANDOVER + 4, 0u);
-    const u32 neutral = coop::is_neutral(lds, L, v);
-    if (lane == 0) verdict[e] = (neutral & f & FLAG_R_OK) ? 1 : 0;
+    __shared__ __attribute__((aligned(16))) u32 lds_all[coop::V3_LDS_WORDS];
+    __shared__ u32 park[40], hand[4];
+    if (blockIdx.x >= n) return;
+    coop::verify_three_waves(lds_all, park, hand, fs, verdict, sig, pk, msgs, n, blockIdx.x, g_tbl);
 }
 
 // step 5: the elements on the slow list (off-curve keys -- the reference does not reject them, so neither may we -- and
@@ -1024,16 +816,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_verify_init_coop(const void* pk, size_t n, u32* ctx_rows /* n contexts, stride_words apart, the 16 rows of each */, size_t stride_words)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::Q_LDS_WORDS];
-    const coop::Lane L = coop::make_lane(threadIdx.x);
-    const size_t e = blockIdx.x;
-    if (e >= n) return;
-    u32 pkw[8];
-    load32(pkw, pk, e);
-    ge_ext Q;
-    ed_decode_neg_key(Q, pkw);                              // -A, no validation (ed25519_verify.c:191-197)
-    coop_setup_one(lds, L);
-    const u32 xl = coop::my_limb(lds, L, Q.X), yl = coop::my_limb(lds, L, Q.Y);
-    coop::qtable_build_coop(lds, L, xl, yl, ctx_rows + e * stride_words);
+    if (blockIdx.x >= n) return;
+    coop::verify_init_one(lds, coop::make_lane(threadIdx.x), pk, blockIdx.x, ctx_rows + blockIdx.x * stride_words);
 }
 
 // ed25519_Verify_Check for a call of a few pairs (the reference's prototype is a call of ONE): one pair per wave, the
@@ -1043,29 +827,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_verify_check_coop(int* verdict, const void* sig, const u32* __restrict__ ctx, Msgs msgs, size_t n, const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::Q_LDS_WORDS];
-    const coop::Lane L = coop::make_lane(threadIdx.x);
-    const size_t e = blockIdx.x;
-    if (e >= n) return;
-    u32 pkw[8], Rw[8], Sw[8], h[8], xw[8], yw[8], enc[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) pkw[j] = ctx[j];
-    load32(Rw, sig, 2 * e);
-    ed_hram(h, Rw, pkw, msgs.ptr(e), msgs.len(e));
-    sc_mod(h);
-    load32(Sw, sig, 2 * e + 1);                            // raw 256 bits: no s < L check (ed25519_verify.c:308)
-    coop_setup_one(lds, L);
-    coop::put_y(lds, L, coop::SLOT_KDI, coop::my_limb(lds, L, fe_const(K_DI)));
-#pragma unroll 1
-    for (int r = 0; r < 16; r++)
-#pragma unroll
-        for (int f = 0; f < 4; f++) coop::put_y(lds, L, coop::QSLOT0 + r * 4 + f, coop::packed_limb(ctx + 8 + r * 32 + 8 * f, L));
-    const u32 v = coop::poly_mult(lds, L, Sw, h, g_tbl + REF_TBL_OFFSET);
-    coop::ge_affine_words(xw, yw, lds, L, v);
-    ge_pack(enc, xw, yw);
-    u32 diff = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
-    if (threadIdx.x == 0) verdict[e] = diff == 0 ? 1 : 0;
+    if (blockIdx.x >= n) return;
+    coop::verify_check_one(lds, coop::make_lane(threadIdx.x), verdict, sig, ctx, msgs, blockIdx.x, g_tbl + REF_TBL_OFFSET);
 }
 
 // ---- one key, a big batch: both scalars over wide combs ------------------------------------------------------------------

@@ -8,15 +8,15 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "curve25519_amd", "csrc")
 LIB = os.path.join(HERE, "libc25519_emul.so")
 HEADERS = ["valu_gfx950.cuh", "fe25519.cuh", "sc25519.cuh", "sha512.cuh", "ge25519.cuh", "x25519.cuh", "lanes.cuh",
-           "curve_constants.cuh", "verify_fast.cuh"]
+           "curve_constants.cuh", "verify_fast.cuh", "coop25519.cuh", "coop_ops.cuh"]
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(HERE, "emul.cpp"), os.path.join(HERE, "valu_model.h")] + [os.path.join(CSRC, h) for h in HEADERS]
+    srcs = [os.path.join(HERE, f) for f in ("emul.cpp", "valu_model.h", "coop_wave.h")] + [os.path.join(CSRC, h) for h in HEADERS]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(s) <= os.path.getmtime(LIB) for s in srcs):
         return LIB
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function",
-           "-include", os.path.join(HERE, "valu_model.h"), "-I", CSRC, os.path.join(HERE, "emul.cpp"),
+           "-include", os.path.join(HERE, "valu_model.h"), "-I", CSRC, "-I", HERE, os.path.join(HERE, "emul.cpp"),
            "-o", LIB + ".tmp", "-lpthread"]
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)

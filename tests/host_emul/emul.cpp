@@ -4,8 +4,11 @@
 // DEVICE SOURCE (field / scalar / group / hashing / lane logic) on a CPU-only machine; the GPU tests then only have
 // to establish that the kernels' indexing, LDS staging and scratch plumbing around these functions are right.
 // Not part of the product and not a fallback: libcurve25519_amd.so contains no host arithmetic.
+#define EMUL_COOP_WAVE_IMPL 1              // this translation unit holds the lock-step lane scheduler (coop_wave.h)
+#include "coop_wave.h"
 #include "lanes.cuh"
 #include "verify_fast.cuh"
+#include "coop_ops.cuh"
 
 #include <mutex>
 #include <thread>
@@ -15,6 +18,7 @@ using namespace c25519;
 
 namespace c25519 { unsigned long long emul_mad_overflows = 0, emul_mad_count = 0; LatCounters emul_lat_counters = { 0, 0, 0 }; }
 thread_local EmulWave* emul_wave = nullptr;
+thread_local emul_dim3 emul_tid = { 0, 0, 0 };
 
 namespace {
 
@@ -547,6 +551,119 @@ void emul_ed25519_verify_init(unsigned char* ctx, const unsigned char* pk, size_
         const QTableCanon t{ reinterpret_cast<u32*>(ctx + 2080 * i + 32) };
         qtable_build(t, Q);
     }
+}
+
+// ---- one operation per WAVE (csrc/coop_ops.cuh), every lane a fiber of this thread (coop_wave.h) ---------------------------
+// The kernels of engine.hip are: LDS array, `if (blockIdx.x >= n) return`, the call below with e = blockIdx.x.
+static std::mutex g_coop_mu;                 // one emulated workgroup at a time (the scheduler's stacks are shared)
+
+unsigned long long emul_coop_sync_points(void) { return emul_coop::sync_points(); }
+
+void emul_coop_x25519(unsigned char* out, const unsigned char* pk, unsigned char* sk, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    std::vector<u32> lds(coop::ROWQ_OFF);
+    for (size_t e = 0; e < n; e++)
+        emul_coop::run_block(64, [&] {
+            const coop::Lane L = coop::make_lane(threadIdx.x);
+            if (pk) coop::x25519_one<false>(lds.data(), L, out, pk, sk, e);
+            else coop::x25519_one<true>(lds.data(), L, out, pk, sk, e);
+        });
+}
+
+void emul_coop_public_fast(unsigned char* pk, unsigned char* sk, size_t n, int wide)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    std::vector<u32> lds(coop::LDS_WORDS);
+    const u32* tbl = wide ? wide_tables() : tables();
+    for (size_t e = 0; e < n; e++)
+        emul_coop::run_block(64, [&] {
+            const coop::Lane L = coop::make_lane(threadIdx.x);
+            if (wide) coop::public_fast_one<true>(lds.data(), L, pk, sk, e, tbl);
+            else coop::public_fast_one<false>(lds.data(), L, pk, sk, e, tbl);
+        });
+}
+
+void emul_coop_keypair(unsigned char* pub, unsigned char* priv, const unsigned char* blinding, const unsigned char* sk, size_t n, int wide)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    std::vector<u32> lds(coop::LDS_WORDS);
+    const u32* tbl = wide ? wide_tables() : tables();
+    for (size_t e = 0; e < n; e++)
+        emul_coop::run_block(64, [&] {
+            const coop::Lane L = coop::make_lane(threadIdx.x);
+            if (wide) coop::keypair_one<true>(lds.data(), L, pub, priv, sk, e, tbl, reinterpret_cast<const u32*>(blinding));
+            else coop::keypair_one<false>(lds.data(), L, pub, priv, sk, e, tbl, nullptr);
+        });
+}
+
+void emul_coop_sign(unsigned char* sig, const unsigned char* priv, const unsigned char* blinding, const unsigned char* msg, size_t len,
+                    size_t n, int wide)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    std::vector<u32> lds(coop::LDS_WORDS);
+    const u32* tbl = wide ? wide_tables() : tables();
+    const Msgs msgs{ msg, len, nullptr };
+    for (size_t e = 0; e < n; e++)
+        emul_coop::run_block(64, [&] {
+            const coop::Lane L = coop::make_lane(threadIdx.x);
+            if (wide) coop::sign_one<true>(lds.data(), L, sig, priv, msgs, e, tbl, reinterpret_cast<const u32*>(blinding));
+            else coop::sign_one<false>(lds.data(), L, sig, priv, msgs, e, tbl, nullptr);
+        });
+}
+
+void emul_coop_blinding_init(unsigned char* ctx /* 192 */, const unsigned char* seed, size_t len)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    std::vector<u32> lds(coop::LDS_WORDS);
+    emul_coop::run_block(64, [&] {
+        coop::blinding_init_one(lds.data(), coop::make_lane(threadIdx.x), reinterpret_cast<u32*>(ctx), seed, len, wide_tables());
+    });
+}
+
+// n contexts of 2080 bytes (pk || 16 rows), the rows by the wave
+void emul_coop_verify_init(unsigned char* ctx, const unsigned char* pk, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    std::vector<u32> lds(coop::Q_LDS_WORDS);
+    for (size_t e = 0; e < n; e++) {
+        memcpy(ctx + 2080 * e, pk + 32 * e, 32);
+        emul_coop::run_block(64, [&] {
+            coop::verify_init_one(lds.data(), coop::make_lane(threadIdx.x), pk, e, reinterpret_cast<u32*>(ctx + 2080 * e + 32));
+        });
+    }
+}
+
+// one context, n (signature, message) pairs
+void emul_coop_verify_check(int* verdict, const unsigned char* ctx, const unsigned char* sig, const unsigned char* msg, size_t len, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    std::vector<u32> lds(coop::Q_LDS_WORDS);
+    const Msgs msgs{ msg, len, nullptr };
+    for (size_t e = 0; e < n; e++)
+        emul_coop::run_block(64, [&] {
+            coop::verify_check_one(lds.data(), coop::make_lane(threadIdx.x), verdict, sig, reinterpret_cast<const u32*>(ctx), msgs, e,
+                                   tables() + (size_t)REF_TBL_OFFSET);
+        });
+}
+
+// the lattice path, three waves per element; need_slow[e] = 1 where the element went on the slow list (verdict untouched)
+void emul_coop_verify_three_waves(int* verdict, int* need_slow, const unsigned char* sig, const unsigned char* pk, const unsigned char* msg,
+                                  size_t len, size_t n, int lat_cap_bits)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    std::vector<u32> lds(coop::V3_LDS_WORDS), park(40), hand(4);
+    std::vector<u32> sigma((size_t)SIGMA_WORDS * n), rho(5 * n), tau(5 * n), flags(n), slow_list(n), counters(4, 0);
+    FastScratch fs{};
+    fs.sigma = sigma.data(); fs.rho = rho.data(); fs.tau = tau.data(); fs.flags = flags.data();
+    fs.slow_list = slow_list.data(); fs.slow_count = counters.data();
+    fs.lat_cap_bits = lat_cap_bits > 0 ? lat_cap_bits : LAT_CAP_BITS;
+    const Msgs msgs{ msg, len, nullptr };
+    for (size_t e = 0; e < n; e++)
+        emul_coop::run_block(192, [&] {
+            coop::verify_three_waves(lds.data(), park.data(), hand.data(), fs, verdict, sig, pk, msgs, n, e, tables());
+        });
+    for (size_t e = 0; e < n; e++) need_slow[e] = (flags[e] & FLAG_SLOW) ? 1 : 0;
 }
 
 }  // extern "C"

@@ -22,8 +22,19 @@
 struct uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{ x, y, z, w }; }
 struct emul_dim3 { unsigned x, y, z; };
-static const emul_dim3 threadIdx = { 0, 0, 0 }, blockIdx = { 0, 0, 0 }, blockDim = { 1, 1, 1 };
-static inline void __syncthreads() {}
+static const emul_dim3 blockIdx = { 0, 0, 0 }, blockDim = { 1, 1, 1 };
+// threadIdx: 0 for the one-lane-at-a-time tests; the lane number while coop_wave.h runs a workgroup of lock-step lanes
+extern thread_local emul_dim3 emul_tid;
+#define threadIdx emul_tid
+#include "coop_wave.h"
+static inline void __syncthreads() { emul_coop::block_sync(); }
+// the cross-lane instructions of coop25519.cuh, as rendezvous between the lanes coop_wave.h runs
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl) \
+    ((int)emul_coop::dpp((uint32_t)(old), (uint32_t)(src), (ctrl), (bound_ctrl)))
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) emul_coop::swap16((a), (b))
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) emul_coop::swap32((a), (b))
+#define __builtin_amdgcn_wave_barrier() emul_coop::wave_sync()
+static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { const uint32_t old = *p; *p = old + v; return old; }   // (lanes run one at a time)
 static inline int __syncthreads_or(int p) { return p; }
 // __any(): a "wave" of one lane by default.  emul_wave_run() (emul.cpp) runs G host threads as the lanes of one wave in
 // lock-step: each lane's code then meets every __any at the same point (the device source only branches on wave-uniform
