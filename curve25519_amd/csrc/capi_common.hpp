@@ -39,6 +39,24 @@ inline int fail(hipError_t err, const char* what, const char* file, int line)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Fill / upload device memory and KNOW it has happened before the next line runs.  hipMemset of device memory may return
+// before the fill has run, and the null stream it runs on does not order with this library's streams (all created
+// hipStreamNonBlocking): a fill that is still queued when a kernel of the call writes results into the same buffer wipes them
+// afterwards (seen on a busy device: tools/stress_host_api.py, zeros where a shard's signatures belonged).  Likewise for a
+// small upload the next kernels read.  Both helpers come back only when the null stream has drained.
+inline int zero_device_now(void* p, size_t bytes)
+{
+    C25519_TRY(hipMemsetAsync(p, 0, bytes, nullptr));
+    C25519_TRY(hipStreamSynchronize(nullptr));
+    return 0;
+}
+inline int upload_now(void* dst, const void* src, size_t bytes)
+{
+    C25519_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    C25519_TRY(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
 inline int bad_arg(const char* msg)
 {
     last_error() = msg;
@@ -240,7 +258,7 @@ struct ThreadState {
     {
         if (bytes <= dcap[lane][slot]) return 0;
         if (dbuf[lane][slot]) {                           // held staged secrets: zeroed before it goes back to the allocator
-            C25519_TRY(hipMemset(dbuf[lane][slot], 0, dcap[lane][slot]));
+            C25519_RC(zero_device_now(dbuf[lane][slot], dcap[lane][slot]));
             C25519_TRY(hipFree(dbuf[lane][slot]));
             dbuf[lane][slot] = nullptr; dcap[lane][slot] = 0;
         }
@@ -271,7 +289,7 @@ struct ThreadState {
         WorkSlab& w = *slab_for(s, dev);
         if (w.ptr && bytes > w.cap) {
             C25519_TRY(hipDeviceSynchronize());
-            C25519_TRY(hipMemset(w.ptr, 0, w.cap));
+            C25519_RC(zero_device_now(w.ptr, w.cap));
             C25519_TRY(hipFree(w.ptr));
             w.ptr = nullptr; w.cap = 0; w.used = false;
         }
@@ -303,7 +321,7 @@ struct ThreadState {
         }
         if (!w.ptr) {
             C25519_TRY(hipMalloc(&w.ptr, bytes));
-            C25519_TRY(hipMemset(w.ptr, 0, bytes));
+            C25519_RC(zero_device_now(w.ptr, bytes));
             w.cap = bytes;
             *fresh = true;
         }
@@ -329,7 +347,7 @@ struct ThreadState {
         WorkSlab& w = *slab_for(s, dev);
         if (!w.report) {
             C25519_TRY(hipMalloc(&w.report, 256));
-            C25519_TRY(hipMemset(w.report, 0, 256));
+            C25519_RC(zero_device_now(w.report, 256));
         }
         *out = w.report;
         return 0;

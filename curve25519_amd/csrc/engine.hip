@@ -1837,7 +1837,7 @@ static int upload_blinding(void** dctx, const void* blinding)
     if (!t.bctx) C25519_TRY(hipMalloc(&t.bctx, 4 * BLIND_WORDS));
     if (!t.bctx_valid || memcmp(t.bctx_host, blinding, 4 * BLIND_WORDS) != 0) {
         t.bctx_valid = false;
-        C25519_TRY(hipMemcpy(t.bctx, blinding, 4 * BLIND_WORDS, hipMemcpyHostToDevice));
+        C25519_RC(c25519_host::upload_now(t.bctx, blinding, 4 * BLIND_WORDS));
         memcpy(t.bctx_host, blinding, 4 * BLIND_WORDS);
         t.bctx_valid = true;
     }
@@ -2062,7 +2062,7 @@ int ed25519_Verify_Check_batch(int* verdict, const void* ctx, const unsigned cha
     void* dctx = t.vctx;
     if (!t.vctx_valid || memcmp(t.vctx_host, ctx, 2080) != 0) {
         t.vctx_valid = false;
-        C25519_TRY(hipMemcpy(dctx, ctx, 2080, hipMemcpyHostToDevice));
+        C25519_RC(c25519_host::upload_now(dctx, ctx, 2080));
         memcpy(t.vctx_host, ctx, 2080);
         t.vctx_valid = true;
     }

@@ -207,13 +207,14 @@ int reserve(void*& p, size_t& cap, size_t bytes)
 {
     if (bytes <= cap) return 0;
     if (p) {
-        C25519_TRY(hipMemset(p, 0, cap));
+        C25519_RC(c25519_host::zero_device_now(p, cap));
         C25519_TRY(hipFree(p));
         p = nullptr; cap = 0;
     }
     const size_t want = bytes < 4096 ? 4096 : bytes;
     C25519_TRY(hipMalloc(&p, want));
-    C25519_TRY(hipMemset(p, 0, want));               // pad rows of an uneven last shard travel through the gather: defined bytes
+    C25519_RC(c25519_host::zero_device_now(p, want));   // pad rows of an uneven last shard travel through the gather: defined bytes -- and
+                                                        // the fill must have RUN before the call's kernels write rows into the buffer
     cap = want;
     return 0;
 }
@@ -291,7 +292,7 @@ int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch lau
                             pa[a].dev = m->buf[a][d];
                             // a short shard's pad rows travel through the gather and the pinned slots: zero, not what an
                             // earlier call left there (nothing reads buf now: every call ends with the gather streams idle)
-                            if (cnt < rows) C25519_TRY(hipMemset((char*)m->buf[a][d] + cnt * arr[a].elem, 0, (rows - cnt) * arr[a].elem));
+                            if (cnt < rows) C25519_RC(c25519_host::zero_device_now((char*)m->buf[a][d] + cnt * arr[a].elem, (rows - cnt) * arr[a].elem));
                         } else if (arr[a].out && arr[a].gather) {
                             // no gather (one device, or switched off): the rows leave through the worker's pipeline like any
                             // output (piece by piece, under the next piece's kernels, over this device's own link)

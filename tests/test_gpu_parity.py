@@ -1014,6 +1014,19 @@ def test_multi_device_code_with_eight_virtual_devices(api, gather_mode):
             L.c25519_amd_multi_destroy(h)
 
 
+def test_host_api_soak_with_every_layer_in_the_mix():
+    """tools/stress_host_api.py: eight host threads at once, each hammering the *_batch calls (every shape of the pipeline:
+    zero-copy calls of a few rows, per-wave kernels, one piece, eight pieces, ragged tails, page-locked and pageable arguments),
+    blinded signatures, one-key two-phase verification (per-wave, reference-order and wide-comb kernels with the thread's
+    remembered key comb) and its own *_multi handle of three virtual devices in either gather mode -- every result compared
+    with the bytes of the plain calls.  This is the run that caught fills of freshly grown result buffers landing AFTER the
+    kernels' results on a busy device (hipMemset on the null stream against non-blocking streams: capi_common.hpp,
+    zero_device_now)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_host_api.py"), "--threads", "8", "--iters", "240"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "stress ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_two_multi_handles_in_two_threads_share_the_copy_threads(api):
     """Two *_multi handles (three and two virtual devices) driven from two host threads at the same time: five pipelines, two
     gathers and two hand-overs feed ONE process-wide pool of copy threads (host_pipeline.hpp: SharedCopyPool) -- every call

@@ -3,7 +3,10 @@
 streams / buffer sets / helper threads, hammer the three passes with batch sizes that exercise every shape of
 run_batch (single piece, exactly 8 pieces, more pieces than buffer sets via C25519_AMD_BATCH_PIECES, ragged tails),
 pageable and page-locked arguments mixed; every result is compared with the bytes the device-pointer path gave for the
-same inputs.   python tools/stress_host_api.py [--threads 4] [--iters 40]
+same inputs.  In the mix: blinded signatures with one context, two-phase verification under one key (per-wave kernels, the
+reference-order kernel and the two wide combs with the thread's remembered key comb), and a `*_multi` handle of three virtual
+devices per thread (workers, gather streams, the process-wide copy threads shared by every thread's handle).
+    python tools/stress_host_api.py [--threads 4] [--iters 40]
 """
 import argparse
 import ctypes as C
@@ -20,6 +23,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--threads", type=int, default=4)
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--n", type=int, default=(1 << 19) + 12345)
+ap.add_argument("--only", type=int, default=-1, help="every call is this operation (0 X25519, 1 sign, 2 verify, 3 blinded sign, 4 one-key verify, 5 *_multi)")
 args = ap.parse_args()
 L = _lib.load()
 N = args.n
@@ -32,17 +36,30 @@ bsig, bmsg, bad = synth.corrupt_for_verify(sig, msg)
 want_ok = (~bad).astype(np.int32)
 P = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
 errors = []
+# one key, many signatures (two-phase verification): the same private key over the first 2^17 + 77 messages
+ONE = (1 << 17) + 77
+one_sig = api.ed25519_SignMessage(np.ascontiguousarray(np.broadcast_to(priv[5], (ONE, 64))), msg[:ONE])
+one_bsig, one_bmsg, one_bad = synth.corrupt_for_verify(one_sig, msg[:ONE])
+one_ok = (~one_bad).astype(np.int32)
+one_ctx = api.ed25519_Verify_Init(pub[5:6])[0]
+bctx = np.zeros(192, np.uint8)
+L.ed25519_Blinding_Init.restype = C.c_void_p
+assert L.ed25519_Blinding_Init(P(bctx), b"stress", 6) == bctx.ctypes.data
 
 
 def worker(tid):
     rng = np.random.default_rng(1000 + tid)
     locked = []
+    handle = C.c_void_p()
     try:
+        dev = (C.c_int * 3)(0, 0, 0)
+        assert L.c25519_amd_multi_create(C.byref(handle), dev, 3) == 0
         for it in range(args.iters):
-            n = int(rng.choice([1, 255, 4097, 1 << 17, (1 << 17) + 1, 200003, 1 << 18, N]))
+            n = int(rng.choice([1, 2, 64, 65, 255, 1025, 4097, 1 << 16, 1 << 17, (1 << 17) + 1, 200003, 1 << 18, N]))
             lo = int(rng.integers(0, N - n + 1))
             sl = slice(lo, lo + n)
-            op = it % 3
+            op = it % 6 if args.only < 0 else args.only
+            detail = ""
             lock = bool(rng.integers(0, 2))
             if op == 0:
                 out, s2, p2 = np.zeros((n, 32), np.uint8), sk[sl].copy(), np.ascontiguousarray(pk[sl])
@@ -62,6 +79,36 @@ def worker(tid):
                     locked.append(pr)
                 assert L.ed25519_SignMessage_batch(P(out), P(pr), P(m), m.shape[1], n) == 0
                 good = np.array_equal(out, sig[sl])
+            elif op == 3:                                          # blinded signatures, one context for every thread
+                out = np.zeros((n, 64), np.uint8)
+                pr, m = np.ascontiguousarray(priv[sl]), np.ascontiguousarray(msg[sl])
+                assert L.ed25519_SignMessage_blinded_batch(P(out), P(pr), P(bctx), P(m), m.shape[1], n) == 0
+                good = np.array_equal(out, sig[sl])
+            elif op == 4:                                          # two-phase verification under one key
+                n = min(n, ONE)
+                lo = int(rng.integers(0, ONE - n + 1))
+                sl = slice(lo, lo + n)
+                out = np.full(n, -7, np.int32)
+                s2, m = np.ascontiguousarray(one_bsig[sl]), np.ascontiguousarray(one_bmsg[sl])
+                assert L.ed25519_Verify_Check_batch(P(out), P(one_ctx), P(s2), P(m), m.shape[1], n) == 0
+                good = np.array_equal(out, one_ok[sl])
+            elif op == 5:                                          # the multi-device layer: three virtual devices, either gather mode
+                mode = int(rng.integers(0, 2))
+                assert L.c25519_amd_multi_set_gather(handle, mode) == 0
+                out, s2, p2 = np.full((n, 32), 0xEE, np.uint8), sk[sl].copy(), np.ascontiguousarray(pk[sl])
+                assert L.curve25519_dh_CreateSharedKey_multi(handle, P(out), P(p2), P(s2), n) == 0
+                good = np.array_equal(out, shared[sl]) and np.array_equal(s2, sk_clamped[sl])
+                if not good:
+                    badrows = np.nonzero((out != shared[sl]).any(axis=1))[0]
+                    detail = f"x25519 gather={mode} bad rows {len(badrows)}: {badrows[:4]}..{badrows[-2:]} first bytes {out[badrows[0], :4] if len(badrows) else None} sk ok {np.array_equal(s2, sk_clamped[sl])}"
+                if good:
+                    o2 = np.full((n, 64), 0xEE, np.uint8)
+                    pr, m = np.ascontiguousarray(priv[sl]), np.ascontiguousarray(msg[sl])
+                    assert L.ed25519_SignMessage_multi(handle, P(o2), P(pr), P(m), m.shape[1], n) == 0
+                    good = np.array_equal(o2, sig[sl])
+                    if not good:
+                        badrows = np.nonzero((o2 != sig[sl]).any(axis=1))[0]
+                        detail = f"sign gather={mode} bad rows {len(badrows)}: {badrows[:4]}..{badrows[-2:]} first bytes {o2[badrows[0], :4]}"
             else:
                 out = np.full(n, -7, np.int32)
                 s2, p2, m = np.ascontiguousarray(bsig[sl]), np.ascontiguousarray(pub[sl]), np.ascontiguousarray(bmsg[sl])
@@ -74,11 +121,14 @@ def worker(tid):
             while locked:
                 assert L.c25519_amd_host_unregister(P(locked.pop())) == 0
             if not good:
-                errors.append((tid, it, op, n, lo, lock))
+                errors.append((tid, it, op, n, lo, lock, detail))
                 return
         L.c25519_amd_thread_release()
     except Exception as e:  # noqa: BLE001
         errors.append((tid, repr(e), L.c25519_amd_last_error()))
+    finally:
+        if handle:
+            L.c25519_amd_multi_destroy(handle)
 
 
 threads = [threading.Thread(target=worker, args=(t,)) for t in range(args.threads)]
