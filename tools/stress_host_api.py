@@ -3,7 +3,7 @@
 streams / buffer sets / helper threads, hammer the three passes with batch sizes that exercise every shape of
 run_batch (single piece, exactly 8 pieces, more pieces than buffer sets via C25519_AMD_BATCH_PIECES, ragged tails),
 pageable and page-locked arguments mixed; every result is compared with the bytes the device-pointer path gave for the
-same inputs.  In the mix: blinded signatures with one context, two-phase verification under one key (per-wave kernels, the
+same inputs.  In the mix: the device-pointer calls on a stream of the thread's own (three passes back to back), blinded signatures with one context, two-phase verification under one key (per-wave kernels, the
 reference-order kernel and the two wide combs with the thread's remembered key comb), and a `*_multi` handle of three virtual
 devices per thread (workers, gather streams, the process-wide copy threads shared by every thread's handle).
     python tools/stress_host_api.py [--threads 4] [--iters 40]
@@ -16,6 +16,7 @@ import threading
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from curve25519_amd import _lib, api, synth  # noqa: E402
 
@@ -23,8 +24,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--threads", type=int, default=4)
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--n", type=int, default=(1 << 19) + 12345)
-ap.add_argument("--only", type=int, default=-1, help="every call is this operation (0 X25519, 1 sign, 2 verify, 3 blinded sign, 4 one-key verify, 5 *_multi)")
+ap.add_argument("--only", type=int, default=-1, help="every call is this operation (0 X25519, 1 sign, 2 verify, 3 blinded sign, 4 one-key verify, 5 *_multi, 6 *_dev on the thread's own stream)")
 args = ap.parse_args()
+torch.cuda.init()                        # (in the main thread, before the workers: op 6 hands torch's streams and tensors to *_dev)
 L = _lib.load()
 N = args.n
 sk, pk = synth.x25519_inputs(N)
@@ -51,6 +53,7 @@ def worker(tid):
     rng = np.random.default_rng(1000 + tid)
     locked = []
     handle = C.c_void_p()
+    stream = None
     try:
         dev = (C.c_int * 3)(0, 0, 0)
         assert L.c25519_amd_multi_create(C.byref(handle), dev, 3) == 0
@@ -58,7 +61,7 @@ def worker(tid):
             n = int(rng.choice([1, 2, 64, 65, 255, 1025, 4097, 1 << 16, 1 << 17, (1 << 17) + 1, 200003, 1 << 18, N]))
             lo = int(rng.integers(0, N - n + 1))
             sl = slice(lo, lo + n)
-            op = it % 6 if args.only < 0 else args.only
+            op = it % 7 if args.only < 0 else args.only
             detail = ""
             lock = bool(rng.integers(0, 2))
             if op == 0:
@@ -109,6 +112,25 @@ def worker(tid):
                     if not good:
                         badrows = np.nonzero((o2 != sig[sl]).any(axis=1))[0]
                         detail = f"sign gather={mode} bad rows {len(badrows)}: {badrows[:4]}..{badrows[-2:]} first bytes {o2[badrows[0], :4]}"
+            elif op == 6:                                          # device pointers, this thread's own stream, three passes back to back
+                if stream is None:
+                    stream = torch.cuda.Stream()
+                with torch.cuda.stream(stream):
+                    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", non_blocking=False)  # noqa: E731
+                    d_pk, d_sk = up(pk[sl]), up(sk[sl])
+                    d_out = torch.full((n, 32), 0xEE, dtype=torch.uint8, device="cuda")
+                    api.curve25519_dh_CreateSharedKey_dev(d_out, d_pk, d_sk)
+                    d_priv, d_msg = up(priv[sl]), up(msg[sl])
+                    d_sig = torch.full((n, 64), 0xEE, dtype=torch.uint8, device="cuda")
+                    api.ed25519_SignMessage_dev(d_sig, d_priv, d_msg)
+                    d_bsig, d_pub, d_bmsg = up(bsig[sl]), up(pub[sl]), up(bmsg[sl])
+                    d_ok = torch.full((n, 1), -7, dtype=torch.int32, device="cuda")
+                    api.ed25519_VerifySignature_dev(d_ok, d_bsig, d_pub, d_bmsg)
+                    stream.synchronize()
+                    good = (np.array_equal(d_out.cpu().numpy(), shared[sl]) and np.array_equal(d_sk.cpu().numpy(), sk_clamped[sl])
+                            and np.array_equal(d_sig.cpu().numpy(), sig[sl]) and np.array_equal(d_ok.cpu().numpy()[:, 0], want_ok[sl]))
+                    if not good:
+                        detail = f"dev: x {np.array_equal(d_out.cpu().numpy(), shared[sl])} sign {np.array_equal(d_sig.cpu().numpy(), sig[sl])} verify {np.array_equal(d_ok.cpu().numpy()[:, 0], want_ok[sl])}"
             else:
                 out = np.full(n, -7, np.int32)
                 s2, p2, m = np.ascontiguousarray(bsig[sl]), np.ascontiguousarray(pub[sl]), np.ascontiguousarray(bmsg[sl])
