@@ -24,6 +24,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--threads", type=int, default=4)
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--n", type=int, default=(1 << 19) + 12345)
+ap.add_argument("--churn", type=int, default=1, help="generations of threads: every generation starts --threads fresh threads and joins them (no "
+                                                        "c25519_amd_thread_release in generations > 1: the thread-exit path frees)")
 ap.add_argument("--only", type=int, default=-1, help="every call is this operation (0 X25519, 1 sign, 2 verify, 3 blinded sign, 4 one-key verify, 5 *_multi, 6 *_dev on the thread's own stream)")
 args = ap.parse_args()
 torch.cuda.init()                        # (in the main thread, before the workers: op 6 hands torch's streams and tensors to *_dev)
@@ -145,7 +147,8 @@ def worker(tid):
             if not good:
                 errors.append((tid, it, op, n, lo, lock, detail))
                 return
-        L.c25519_amd_thread_release()
+        if args.churn == 1 or tid % 2:
+            L.c25519_amd_thread_release()
     except Exception as e:  # noqa: BLE001
         errors.append((tid, repr(e), L.c25519_amd_last_error()))
     finally:
@@ -153,11 +156,33 @@ def worker(tid):
             L.c25519_amd_multi_destroy(handle)
 
 
-threads = [threading.Thread(target=worker, args=(t,)) for t in range(args.threads)]
-for t in threads:
-    t.start()
-for t in threads:
-    t.join()
+def rss_mb():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2**20
+
+
+marks = []
+for gen in range(args.churn):
+    threads = [threading.Thread(target=worker, args=(gen * args.threads + t,)) for t in range(args.threads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                             # (torch caches freed blocks per stream: not this library's memory)
+    marks.append((torch.cuda.mem_get_info()[0] / 2**20, rss_mb()))
+    if errors:
+        break
+if args.churn > 1:
+    k = min(2, len(marks) - 1)                           # (the first generations warm the allocators' caches)
+    dev_growth, rss_growth = marks[k][0] - marks[-1][0], marks[-1][1] - marks[k][1]
+    print(f"churn: {len(marks)} generations of {args.threads} threads; device memory in use grew {dev_growth:.0f} MiB, host RSS {rss_growth:.0f} MiB "
+          f"between generation {k + 1} and the last")
+    print("  per generation (device MiB free, host RSS MiB):", " ".join(f"{a:.0f}/{b:.0f}" for a, b in marks))
+    # (host RSS is reported, not judged: Python / numpy / torch keep per-thread arenas; the library's own per-thread state is
+    # measured without them by tools/scratch/churn_threads.c -- flat over 480 threads)
+    if dev_growth > 256:
+        errors.append(("device memory leak", dev_growth))
 print("errors:", errors)
 print("stress ok" if not errors else "STRESS FAILED", f"({args.threads} threads x {args.iters} calls, pieces={os.environ.get('C25519_AMD_BATCH_PIECES', '8')})")
 sys.exit(1 if errors else 0)
