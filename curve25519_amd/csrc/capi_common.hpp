@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <pthread.h>
+#include <unistd.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -152,10 +154,58 @@ inline std::atomic<bool>& runtime_alive()
     static std::atomic<bool> alive{ true };
     return alive;
 }
+// ... and calls that are IN FLIGHT when exit() begins (another thread is in the middle of a batch while main returns) must be
+// allowed to finish before the HIP runtime's own teardown runs -- a kernel launch into a runtime that is being torn down is a
+// segmentation fault inside libamdhip64 (tools/scratch/exit_midcall.c) --, and calls that BEGIN after that point must not reach the
+// runtime at all.  Every C entry point that touches HIP holds an ApiCall for its duration (C25519_API_CALL()): the outermost one
+// of a thread counts itself in; the atexit handler below closes the gate and waits (up to 10 s) for the count to drain; a call
+// that arrives at a closed gate parks its thread for the rest of the process' life (which is being ended by exit()).
+struct ApiGate {
+    static std::atomic<long>& inflight() { static std::atomic<long> n{ 0 }; return n; }
+    static int& depth() { thread_local int d = 0; return d; }     // > 0: inside a call already (a *_batch call running its *_dev form)
+    static std::atomic<unsigned long>& exiting_thread() { static std::atomic<unsigned long> t{ 0 }; return t; }
+};
+class ApiCall {
+public:
+    ApiCall()
+    {
+        if (ApiGate::depth()++ > 0) return;
+        ApiGate::inflight().fetch_add(1);
+        if (!runtime_alive().load()) {
+            ApiGate::inflight().fetch_sub(1);
+            // the thread that RUNS exit() (a static destructor or an atexit handler of the caller's that reaches the library) must
+            // go on: its call is refused; any other thread has nothing left to do in this process
+            if (ApiGate::exiting_thread().load() == (unsigned long)pthread_self()) { refused_ = true; return; }
+            for (;;) pause();
+        }
+    }
+    ~ApiCall() { if (--ApiGate::depth() == 0 && !refused_) ApiGate::inflight().fetch_sub(1); }
+    bool refused() const { return refused_; }
+    ApiCall(const ApiCall&) = delete;
+    ApiCall& operator=(const ApiCall&) = delete;
+
+private:
+    bool refused_ = false;
+};
+inline int refused_call()
+{
+    last_error() = "the process is exiting: the HIP runtime is being torn down";
+    return (int)hipErrorDeinitialized;
+}
+#define C25519_API_CALL_OR(ret) c25519_host::ApiCall api_call_guard_; if (api_call_guard_.refused()) return ret
+#define C25519_API_CALL() C25519_API_CALL_OR(c25519_host::refused_call())
+// a thread that only ever works INSIDE somebody's call (a multi-GPU worker): its nested entry points pass the gate
+inline void mark_thread_inside_a_call() { ApiGate::depth() = 1; }
+
 inline void arm_exit_guard()
 {
     static std::atomic<bool> armed{ false };
-    if (!armed.exchange(true)) atexit([] { runtime_alive().store(false); });
+    if (!armed.exchange(true))
+        atexit([] {
+            ApiGate::exiting_thread().store((unsigned long)pthread_self());
+            runtime_alive().store(false);
+            for (int ms = 0; ms < 10000 && ApiGate::inflight().load() > 0; ms++) usleep(1000);
+        });
 }
 
 // Per-host-thread device resources.  The staging side (streams, pinned + device buffers of the *_batch pipeline)

@@ -1357,6 +1357,7 @@ const char* c25519_amd_last_error(void) { return c25519_host::last_error().c_str
 
 int c25519_amd_device_count(void)
 {
+    C25519_API_CALL_OR(0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
@@ -1364,6 +1365,7 @@ int c25519_amd_device_count(void)
 
 int c25519_amd_host_register(void* p, size_t bytes)
 {
+    C25519_API_CALL();
     if (!p || !bytes) return bad_arg("null pointer or empty range");
     // page locking works on whole pages: a buffer that shares a page with another allocation would get that neighbour
     // locked, and unlocked, with it (the runtime aborts on the second unregister) -- so only whole pages are accepted
@@ -1374,6 +1376,7 @@ int c25519_amd_host_register(void* p, size_t bytes)
 
 int c25519_amd_host_unregister(void* p)
 {
+    C25519_API_CALL();
     if (!p) return bad_arg("null pointer");
     C25519_TRY(hipHostUnregister(p));
     return 0;
@@ -1404,6 +1407,7 @@ int c25519_amd_usable_cpus(void) { return c25519_host::usable_cpus(); }
 
 int c25519_amd_set_device(int device)
 {
+    C25519_API_CALL();
     C25519_TRY(hipSetDevice(device));
     return 0;
 }
@@ -1421,6 +1425,8 @@ int c25519_amd_probe_words(void) { return PROBE_WORDS; }
 // frees the calling thread's streams, staging buffers (zeroed first) and work scratch
 void c25519_amd_thread_release(void)
 {
+    if (!c25519_host::runtime_alive().load()) return;                   // exit() has begun: the process' memory goes with it
+    C25519_API_CALL_OR((void)0);
     c25519_host::helper_pool_slot().reset();              // the pipeline's parked helper threads
     tls().release();
 }
@@ -1458,6 +1464,7 @@ static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t
 
 int curve25519_dh_CreateSharedKey_dev(void* shared, const void* pk, void* sk, size_t n, void* stream)
 {
+    C25519_API_CALL();
     if (!shared || !pk || !sk) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { shared, pk, sk })) return rc;
     if (n == 0) return 0;
@@ -1466,6 +1473,7 @@ int curve25519_dh_CreateSharedKey_dev(void* shared, const void* pk, void* sk, si
 
 int curve25519_dh_CalculatePublicKey_dev(void* pk, void* sk, size_t n, void* stream)
 {
+    C25519_API_CALL();
     if (!pk || !sk) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { pk, sk })) return rc;
     if (n == 0) return 0;
@@ -1474,6 +1482,7 @@ int curve25519_dh_CalculatePublicKey_dev(void* pk, void* sk, size_t n, void* str
 
 int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void* stream_)
 {
+    C25519_API_CALL();
     if (!pk || !sk) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { pk, sk })) return rc;
     if (n == 0) return 0;
@@ -1542,11 +1551,13 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
 
 int ed25519_CreateKeyPair_dev(void* pub, void* priv, const void* sk, size_t n, void* stream)
 {
+    C25519_API_CALL();
     return keypair_dev(pub, priv, sk, nullptr, n, (hipStream_t)stream);
 }
 
 int ed25519_CreateKeyPair_blinded_dev(void* pub, void* priv, const void* blinding, const void* sk, size_t n, void* stream)
 {
+    C25519_API_CALL();
     if (!blinding) return bad_arg("null blinding context");
     return keypair_dev(pub, priv, sk, blinding, n, (hipStream_t)stream);
 }
@@ -1595,6 +1606,7 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
 
 int ed25519_SignMessage_dev(void* sig, const void* priv, const void* msg, size_t msg_size, size_t n, void* stream)
 {
+    C25519_API_CALL();
     if (!sig || !priv || (!msg && msg_size)) return bad_arg("null pointer");
     return sign_dev(sig, priv, nullptr, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, (hipStream_t)stream);
 }
@@ -1602,6 +1614,7 @@ int ed25519_SignMessage_dev(void* sig, const void* priv, const void* msg, size_t
 int ed25519_SignMessage_blinded_dev(void* sig, const void* priv, const void* blinding, const void* msg, size_t msg_size,
                                     size_t n, void* stream)
 {
+    C25519_API_CALL();
     if (!sig || !priv || !blinding || (!msg && msg_size)) return bad_arg("null pointer");
     return sign_dev(sig, priv, blinding, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, (hipStream_t)stream);
 }
@@ -1609,6 +1622,7 @@ int ed25519_SignMessage_blinded_dev(void* sig, const void* priv, const void* bli
 int ed25519_SignMessage_ragged_dev(void* sig, const void* priv, const void* msgs, const uint64_t* offsets, size_t n,
                                    void* stream)
 {
+    C25519_API_CALL();
     if (!sig || !priv || !offsets) return bad_arg("null pointer");
     return sign_dev(sig, priv, nullptr, Msgs{ (const uint8_t*)msgs, 0, (const unsigned long long*)offsets }, n,
                     (hipStream_t)stream);
@@ -1617,6 +1631,7 @@ int ed25519_SignMessage_ragged_dev(void* sig, const void* priv, const void* msgs
 // one 192-byte blinding context from seed[0..seed_len) (device pointers)
 int ed25519_Blinding_Init_dev(void* ctx, const void* seed, size_t seed_len, void* stream)
 {
+    C25519_API_CALL();
     if (!ctx || (!seed && seed_len)) return bad_arg("null pointer");
     if (int rc = check_dev_args(1, { ctx })) return rc;
     const u32* tbl = nullptr;
@@ -1649,6 +1664,7 @@ static int verify_dev(void* verdict, const void* sig, const void* pk, Msgs msgs,
 int c25519_amd_verify_point_dev(void* out, const void* sig, const void* pk, const void* msg, size_t msg_size, size_t n,
                                 void* stream)
 {
+    C25519_API_CALL();
     if (!out || !sig || !pk || (!msg && msg_size)) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { out, sig, pk })) return rc;
     if (n == 0) return 0;
@@ -1660,6 +1676,7 @@ int c25519_amd_verify_point_dev(void* out, const void* sig, const void* pk, cons
 // reference-order kernel instead of the lattice path (-1: no fast-path verification to report).  Synchronises.
 long c25519_amd_verify_last_slow_elements(void)
 {
+    C25519_API_CALL_OR(-1);
     const LastVerify& lv = tl_last_verify;
     int dev = -1;
     if (!lv.count || hipGetDevice(&dev) != hipSuccess || dev != lv.device) return -1;
@@ -1673,6 +1690,7 @@ long c25519_amd_verify_last_slow_elements(void)
 int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, const void* msg, size_t msg_size,
                                 size_t n, void* stream)
 {
+    C25519_API_CALL();
     if (!verdict || !sig || !pk || (!msg && msg_size)) return bad_arg("null pointer");
     return verify_dev(verdict, sig, pk, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, (hipStream_t)stream);
 }
@@ -1680,6 +1698,7 @@ int ed25519_VerifySignature_dev(void* verdict, const void* sig, const void* pk, 
 int ed25519_VerifySignature_ragged_dev(void* verdict, const void* sig, const void* pk, const void* msgs,
                                        const uint64_t* offsets, size_t n, void* stream)
 {
+    C25519_API_CALL();
     if (!verdict || !sig || !pk || !offsets) return bad_arg("null pointer");
     return verify_dev(verdict, sig, pk, Msgs{ (const uint8_t*)msgs, 0, (const unsigned long long*)offsets }, n,
                       (hipStream_t)stream);
@@ -1689,6 +1708,7 @@ int ed25519_VerifySignature_ragged_dev(void* verdict, const void* sig, const voi
 // the reference's EDP_SIGV_CTX size and row order.
 int ed25519_Verify_Init_dev(void* ctx, const void* pk, size_t n, void* stream)
 {
+    C25519_API_CALL();
     if (!ctx || !pk) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { ctx, pk })) return rc;
     if (n == 0) return 0;
@@ -1705,6 +1725,7 @@ int ed25519_Verify_Init_dev(void* ctx, const void* pk, size_t n, void* stream)
 int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, const void* msg, size_t msg_size,
                              size_t n, void* stream_)
 {
+    C25519_API_CALL();
     if (!verdict || !ctx || !sig || (!msg && msg_size)) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { verdict, ctx, sig })) return rc;
     if (n == 0) return 0;
@@ -1794,6 +1815,7 @@ int c25519_amd_fold_selftest(unsigned char* out, const unsigned char* k, size_t 
 
 int c25519_amd_base_table(unsigned char* out)
 {
+    C25519_API_CALL();
     if (!out) return bad_arg("null pointer");
     const u32* bytes = nullptr;
     if (int rc = base_tables(nullptr, &bytes)) return rc;
@@ -1847,6 +1869,7 @@ static int upload_blinding(void** dctx, const void* blinding)
 
 static int keypair_batch(unsigned char* pub, unsigned char* priv, const void* blinding, const unsigned char* sk, size_t n)
 {
+    C25519_API_CALL();
     if (!pub || !priv || !sk) return bad_arg("null pointer");
     if (n == 0) return 0;
     void* dctx = nullptr;
@@ -1872,6 +1895,7 @@ int ed25519_CreateKeyPair_blinded_batch(unsigned char* pub, unsigned char* priv,
 static int sign_batch(unsigned char* sig, const unsigned char* priv, const void* blinding, const unsigned char* msg,
                       size_t msg_size, size_t n)
 {
+    C25519_API_CALL();
     if (!sig || !priv || (!msg && msg_size)) return bad_arg("null pointer");
     if (n == 0) return 0;
     void* dctx = nullptr;
@@ -1925,6 +1949,7 @@ static int ragged_upload(ThreadState& t, void** d_msgs, void** d_off, const unsi
 int ed25519_SignMessage_ragged_batch(unsigned char* sig, const unsigned char* priv, const unsigned char* msgs,
                                      const uint64_t* offsets, size_t n)
 {
+    C25519_API_CALL();
     if (!sig || !priv || !offsets) return bad_arg("null pointer");
     if (n == 0) return 0;
     ThreadState& t = tls();
@@ -1945,6 +1970,7 @@ int ed25519_SignMessage_ragged_batch(unsigned char* sig, const unsigned char* pr
 int ed25519_VerifySignature_ragged_batch(int* verdict, const unsigned char* sig, const unsigned char* pk,
                                          const unsigned char* msgs, const uint64_t* offsets, size_t n)
 {
+    C25519_API_CALL();
     if (!verdict || !sig || !pk || !offsets) return bad_arg("null pointer");
     if (n == 0) return 0;
     ThreadState& t = tls();
@@ -2007,6 +2033,7 @@ int ed25519_VerifySignature(const unsigned char* signature, const unsigned char*
 // (lanes.cuh), so the walk and its table lookups see a scalar that differs per context; outputs are unchanged.
 void* ed25519_Blinding_Init(void* context, const unsigned char* seed, size_t size)
 {
+    C25519_API_CALL_OR(nullptr);
     void* ctx = context ? context : malloc(4 * BLIND_WORDS);
     if (!ctx) return nullptr;                  // allocation failure is the only error the reference reports (:306)
     ThreadState& t = tls();
@@ -2051,6 +2078,7 @@ int ed25519_Verify_Init_batch(void* ctx, const unsigned char* pk, size_t n)
 int ed25519_Verify_Check_batch(int* verdict, const void* ctx, const unsigned char* sig, const unsigned char* msg,
                                size_t msg_size, size_t n)
 {
+    C25519_API_CALL();
     if (!verdict || !ctx || !sig || (!msg && msg_size)) return bad_arg("null pointer");
     if (n == 0) return 0;
     ThreadState& t = tls();

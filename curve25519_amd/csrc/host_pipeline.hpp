@@ -296,6 +296,7 @@ struct PieceHook {
 template <typename Launch>
 int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const PieceHook* hook = nullptr)
 {
+    C25519_API_CALL();
     ThreadState& t = tls();
     C25519_RC(t.ensure());
     const ShapeHint shape_hint(n);

@@ -110,6 +110,7 @@ struct Worker {
     {
         device = dev;
         th = std::thread([this] {
+            c25519_host::mark_thread_inside_a_call();     // a worker only ever runs jobs of a call that holds the gate (capi_common.hpp)
             (void)hipSetDevice(device);
             for (;;) {
                 std::function<int(bool)> j;
@@ -232,6 +233,7 @@ struct MArr {
 template <typename Launch>
 int run_multi(c25519_amd_multi* m, size_t n, const MArr* arr, int na, Launch launch)
 {
+    C25519_API_CALL();
     const int D = (int)m->dev.size();
     // C25519_AMD_MULTI_FORCE_GATHER=1: a one-device handle takes the gather path too (how the tests run the N > 1 code --
     // resident results, piece-wise grouped ncclGather, hand-over -- on a one-GPU box)
@@ -462,6 +464,7 @@ extern "C" {
 
 int c25519_amd_multi_create(c25519_amd_multi** out, const int* devices, int n_dev)
 {
+    C25519_API_CALL();
     if (!out || !devices || n_dev < 1 || n_dev > MAX_DEVICES) return bad_arg("c25519_amd_multi_create: bad arguments (1..64 devices)");
     int have = 0;
     C25519_TRY(hipGetDeviceCount(&have));
@@ -517,6 +520,8 @@ int c25519_amd_multi_create(c25519_amd_multi** out, const int* devices, int n_de
 
 void c25519_amd_multi_destroy(c25519_amd_multi* m)
 {
+    if (!c25519_host::runtime_alive().load()) return;         // exit() has begun: nothing to give back to a runtime that is going away
+    C25519_API_CALL_OR((void)0);
     if (!m) return;
     int prev = 0;
     (void)hipGetDevice(&prev);

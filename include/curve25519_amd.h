@@ -54,7 +54,11 @@ int  c25519_amd_usable_cpus(void);                     /* CPUs this process may 
  * Each host thread that calls into the library owns four streams, eight sets of pinned + device staging buffers and work
  * scratch slabs, all on the device that was current at its first call (they follow the thread to another device on
  * the next call, released on the old one first).  They are freed when the thread exits; a long-lived thread can
- * give them back earlier with this call.  Staging buffers are zeroed before they are freed. */
+ * give them back earlier with this call.  Staging buffers are zeroed before they are freed.
+ * Process exit: exit() may be called while other threads are inside library calls -- the library's atexit handler lets the
+ * calls in flight finish (it waits up to 10 s) before the HIP runtime is torn down, a thread that calls again afterwards is
+ * parked for the rest of the process' life, and a call made by the exiting thread itself (from a static destructor or an
+ * atexit handler of the caller's) returns hipErrorDeinitialized (release / destroy calls: return at once). */
 void c25519_amd_thread_release(void);
 
 /* Optional: page-lock a host array the caller is going to pass to *_batch functions again and again (hipHostRegister).

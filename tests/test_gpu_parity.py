@@ -648,6 +648,21 @@ def test_c_caller_links_and_passes(tmp_path):
     assert "0 failure(s)" in p.stdout
 
 
+def test_exit_with_a_call_in_flight(tmp_path):
+    """The process calls exit() while another thread is in the middle of *_batch (and *_multi) calls: with a CPU library that is
+    harmless; here a kernel launch into a HIP runtime that exit() is tearing down was a segmentation fault inside libamdhip64.
+    The entry points now hold a gate (capi_common.hpp: ApiCall): the library's atexit handler closes it and waits for the calls
+    in flight; a thread that calls again is parked.  tests/c/exit_midcall.c must exit 0 every time, at several points of the loop."""
+    exe = str(tmp_path / "exit_midcall")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "exit_midcall.c"),
+                           "-o", exe, "-L", os.path.join(ROOT, "curve25519_amd"), "-lcurve25519_amd", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "curve25519_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    for mode in (0, 1):
+        for us in (120000, 260000, 410000, 570000):
+            p = subprocess.run([exe, str(mode), str(us)], capture_output=True, text=True, timeout=60)
+            assert p.returncode == 0, (mode, us, p.returncode, p.stderr[-1500:])
+
+
 def test_reference_harness_runs_on_this_library():
     """The reference's own test/curve25519_test.c (dh_test, signature_test with the RFC 8032 vector and the
     blinded path, the donna cross-check and speed_test), built in the build container by
