@@ -170,6 +170,7 @@ public:
     ApiCall()
     {
         if (ApiGate::depth()++ > 0) return;
+        last_error().clear();                             // c25519_amd_last_error(): "" unless THIS call fails
         ApiGate::inflight().fetch_add(1);
         if (!runtime_alive().load()) {
             ApiGate::inflight().fetch_sub(1);

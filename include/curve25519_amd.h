@@ -31,7 +31,7 @@ extern "C" {
 
 /* library / device status ------------------------------------------------------------------- */
 const char *c25519_amd_version(void);
-const char *c25519_amd_last_error(void);               /* per-thread, "" when none */
+const char *c25519_amd_last_error(void);               /* per-thread: the text of the last call of this thread, "" if it succeeded */
 int  c25519_amd_device_count(void);                    /* usable HIP devices (0 when none) */
 int  c25519_amd_set_device(int device);                /* device used by this host thread */
 /* Tuning / A-B knobs.  Each knob is read ONCE from the environment variable C25519_AMD_<name> when the library is first

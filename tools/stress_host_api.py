@@ -68,6 +68,13 @@ def worker(tid):
             lock = bool(rng.integers(0, 2))
             if op == 0:
                 out, s2, p2 = np.zeros((n, 32), np.uint8), sk[sl].copy(), np.ascontiguousarray(pk[sl])
+                if not lock and rng.integers(0, 2):                # host arrays at odd byte addresses: nothing may assume alignment
+                    def odd(a):
+                        raw = np.empty(a.size + 3, np.uint8)
+                        v = raw[3:].reshape(a.shape)
+                        v[...] = a
+                        return v
+                    out, s2, p2 = odd(out), odd(s2), odd(p2)
                 if lock:
                     out, s2 = synth.page_aligned((n, 32)), synth.page_aligned((n, 32), like=s2)
                     for a in (out, s2):
