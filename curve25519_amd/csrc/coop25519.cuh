@@ -217,13 +217,13 @@ C25519_DEV u32 mul2(u32* lds, const Lane& L, u32 v, u32 w)
     return mul_level(lds, L, L.row, 4 + L.row);
 }
 
-// z^(p-2) limb-per-lane: the 254 S + 11 M chain of fe_invert (ecp_Inverse, curve25519_mehdi.c:340-409); 0 -> 0
-C25519_DEV u32 invert(u32* lds, const Lane& L, u32 z)
+// z^(2^250 - 1) and z^11 limb-per-lane: the shared head of the two exponentiations (fe_chain250, fe25519.cuh)
+C25519_DEV u32 chain250(u32* lds, const Lane& L, u32 z, u32& x11)
 {
     const u32 x2 = sqr_n(lds, L, z, 1);
     u32 t = sqr_n(lds, L, x2, 2);
     const u32 x9 = mul2(lds, L, t, z);
-    const u32 x11 = mul2(lds, L, x9, x2);
+    x11 = mul2(lds, L, x9, x2);
     t = sqr_n(lds, L, x11, 1);
     const u32 x5 = mul2(lds, L, t, x9);                   // z^(2^5 - 1)
     t = sqr_n(lds, L, x5, 5);
@@ -239,9 +239,80 @@ C25519_DEV u32 invert(u32* lds, const Lane& L, u32 z)
     t = sqr_n(lds, L, x100, 100);
     t = mul2(lds, L, t, x100);
     t = sqr_n(lds, L, t, 50);
-    t = mul2(lds, L, t, x50);                             // z^(2^250 - 1)
+    return mul2(lds, L, t, x50);                          // z^(2^250 - 1)
+}
+
+// z^(p-2) limb-per-lane: the 254 S + 11 M chain of fe_invert (ecp_Inverse, curve25519_mehdi.c:340-409); 0 -> 0
+C25519_DEV u32 invert(u32* lds, const Lane& L, u32 z)
+{
+    u32 x11;
+    u32 t = chain250(lds, L, z, x11);
     t = sqr_n(lds, L, t, 5);
     return mul2(lds, L, t, x11);
+}
+
+// z^((p-5)/8) = z^(2^252 - 3)   (fe_pow2523)
+C25519_DEV u32 pow2523(u32* lds, const Lane& L, u32 z)
+{
+    u32 x11;
+    u32 t = chain250(lds, L, z, x11);
+    t = sqr_n(lds, L, t, 2);
+    return mul2(lds, L, t, z);
+}
+
+// x from y with the requested parity, by the whole wave: ge_calc_x_checked (ge25519.cuh; ed25519_CalculateX) limb per lane, all four
+// rows on the same values -- 262 product levels in a row instead of one lane's 27 000 instructions.  yl: this lane's limb of y (the
+// same y in every row); xl: the limb of x; x_zero: all-ones iff x == 0 (the one x whose parity cannot be chosen).  Returns
+// all-ones iff v x^2 == u, i.e. the point is on the curve -- like the per-lane code there is no rejection: a non-square just
+// yields what the formula yields.  Uses SLOT_X1 and SLOT_K2D for the constants d and sqrt(-1) (the walks set theirs afterwards).
+C25519_DEV u32 calc_x_checked(u32* lds, const Lane& L, u32& xl, u32& x_zero, u32 yl, u32 parity)
+{
+    const u32 one = L.c == 0 ? 1u : 0u;
+    put_y(lds, L, SLOT_X1, my_limb(lds, L, fe_const(K_D)));
+    put_y(lds, L, SLOT_K2D, my_limb(lds, L, fe_const(K_SQRTM1)));
+    auto times = [&](u32 v, u32 slot) -> u32 { put_a(lds, L, L.row, v); return mul_level(lds, L, L.row, slot); };
+    const u32 y2 = sqr_n(lds, L, yl, 1);
+    const u32 v = times(y2, SLOT_X1) + one;               // d y^2 + 1
+    const u32 u = carry_small(L, (u64)(y2 + L.p2 - one)); // y^2 - 1, reduced
+    u32 b = sqr_n(lds, L, v, 1);
+    u32 a = mul2(lds, L, u, b);
+    a = mul2(lds, L, a, v);                               // u v^3
+    b = sqr_n(lds, L, b, 1);                              // v^4
+    b = mul2(lds, L, a, b);                               // u v^7
+    b = pow2523(lds, L, b);
+    u32 x = mul2(lds, L, b, a);
+    // is v x^2 == u (x is the root) or == -u (x sqrt(-1) is)?  Every lane reads both values whole and reduces them itself.
+    u32 c = sqr_n(lds, L, x, 1);
+    c = mul2(lds, L, c, v);
+    put_a(lds, L, L.row, c + u);
+    put_a(lds, L, 4 + L.row, c + L.p2 - u);
+    wave_fence();
+    fe S, D;
+    get_fe(S, lds, 0);
+    get_fe(D, lds, 4);
+    u32 sw[8], dw[8];
+    fe_to_words(sw, S);
+    fe_to_words(dw, D);
+    u32 nz = 0, nz2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { nz |= dw[i]; nz2 |= sw[i]; }
+    wave_fence();                                         // (every lane has read the two sums: the slots may be written again)
+    const u32 xi = times(x, SLOT_K2D);
+    x = nz ? xi : x;                                      // :92-93
+    put_a(lds, L, L.row, x);
+    wave_fence();
+    fe X;
+    get_fe(X, lds, 0);
+    u32 xw[8];
+    fe_to_words(xw, X);                                   // canonical, to read the parity (:95-99)
+    u32 any = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) any |= xw[i];
+    const u32 neg = carry_small(L, (u64)(L.p2 - x));
+    xl = ((xw[0] ^ parity) & 1u) ? neg : x;
+    x_zero = any ? 0u : 0xffffffffu;
+    wave_fence();
+    return (nz == 0 || nz2 == 0) ? 0xffffffffu : 0u;
 }
 
 // (X : Z) <- 2 (X : Z) for a point held x in the even rows, z in the odd rows (both row pairs may hold one): two product

@@ -190,16 +190,19 @@ C25519_DEV void blinding_init_one(u32* lds, const Lane& L, u32* ctx, const uint8
     wipe(lds, LDS_WORDS);
 }
 
-// ed25519_Verify_Init (ed25519_verify.c:179-232) for key e: the square root by every lane on the same value (one lane's code: a
-// cooperative one would be no faster), the 16-row table by the whole wave.  lds: Q_LDS_WORDS words; rows: the context's 16 rows.
+// ed25519_Verify_Init (ed25519_verify.c:179-232) for key e: the square root and the 16-row table by the whole wave.  lds: Q_LDS_WORDS words; rows: the context's 16 rows.
 C25519_DEV void verify_init_one(u32* lds, const Lane& L, const void* pk, size_t e, u32* rows)
 {
     u32 pkw[8];
     load32(pkw, pk, e);
-    ge_ext Q;
-    ed_decode_neg_key(Q, pkw);                              // -A, no validation (ed25519_verify.c:191-197)
+    const u32 parity = pkw[7] >> 31;                        // -A: y as given (bit 255 stripped), x with the INVERTED parity, no
+    pkw[7] &= 0x7fffffffu;                                  // validation (ed25519_verify.c:191-197; lanes.cuh: ed_decode_neg_key)
+    fe Y;
+    fe_from_words(Y, pkw);
     setup_one(lds, L);
-    const u32 xl = my_limb(lds, L, Q.X), yl = my_limb(lds, L, Q.Y);
+    const u32 yl = my_limb(lds, L, Y);
+    u32 xl, x_zero;
+    (void)calc_x_checked(lds, L, xl, x_zero, yl, ~parity);
     qtable_build_coop(lds, L, xl, yl, rows);
 }
 
@@ -231,8 +234,8 @@ C25519_DEV void verify_check_one(u32* lds, const Lane& L, int* verdict, const vo
 }
 
 // The whole lattice path of ONE element by a workgroup of THREE waves (k_ed25519_verify_one_per_group):
-//   phase 1   wave 0 hashes and reduces (every lane on the same values) WHILE wave 1 decodes the key in lane 0 and R in lane 1
-//             (the two square roots, which do not need the scalars);
+//   phase 1   wave 0 hashes and reduces (every lane on the same values) WHILE wave 1 decodes R and wave 2 the key, each square
+//             root by the whole wave (calc_x_checked; they do not need the scalars);
 //   phase 2   the equation sigma*B + tau*Q + rho*(-R) = O is three independent products, one wave each, every wave in an LDS
 //             region of its own: wave 0 builds the key's window table with the whole wave (wtable_build_lds: straight into
 //             the forms the walk reads, no round trip through memory) and walks tau over it, wave 1 does the same for R and rho,
@@ -269,14 +272,39 @@ C25519_DEV void verify_three_waves(u32* lds_all, u32* park, u32* hand, const Fas
             hand[0] = tau_neg;
             hand[1] = (lat_ok & FLAG_FITS) | (tau_neg & FLAG_TAU_NEG) | ((u32)top << 8);
         }
-    } else if (wave == 1 && lane < 2) {
-        u32 w[8];
-        fe X, Y;
-        if (lane) load32(w, sig, 2 * e); else load32(w, pk, e);
-        const u32 ok = ed_verify_fast_decode(X, Y, w, lane ? 0xffffffffu : 0u, 0u);   // (the key's sign of tau: wave 0, below)
-        hand[2 + lane] = ok ? 1u : 0u;
+    } else {
+        // ed_verify_fast_decode (verify_fast.cuh) by a whole wave each: wave 1 takes R -- which must be the canonical encoding of a
+        // curve point, and is negated: the walk adds rho * (-R) --, wave 2 the key, decoded as -A exactly as ed25519_Verify_Init
+        // does (the sign of tau turns it once more in phase 2)
+        const u32 is_r = wave == 1 ? 0xffffffffu : 0u;
+        const Lane L = make_lane(lane);
+        u32 w[8], yw[8], cw[8];
+        if (is_r) load32(w, sig, 2 * e); else load32(w, pk, e);
 #pragma unroll
-        for (int i = 0; i < 10; i++) { park[20 * lane + i] = X.v[i]; park[20 * lane + 10 + i] = Y.v[i]; }
+        for (int i = 0; i < 8; i++) yw[i] = w[i];
+        const u32 sign = yw[7] >> 31;
+        yw[7] &= 0x7fffffffu;
+        fe Y;
+        fe_from_words(Y, yw);
+        const u32 parity = sign ^ (~is_r & 1u);
+        setup_one(lds, L);
+        const u32 yl = my_limb(lds, L, Y);
+        u32 xl, x_zero;
+        u32 ok = calc_x_checked(lds, L, xl, x_zero, yl, parity);
+        fe_to_words(cw, Y);
+        u32 diff = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) diff |= cw[i] ^ yw[i];
+        // y < p, and the sign bit an encoder would have produced: x = 0 has parity 0 only
+        const u32 canonical = (diff == 0 && !(x_zero && (parity & 1u))) ? 0xffffffffu : 0u;
+        ok &= ~is_r | canonical;
+        const u32 neg = carry_small(L, (u64)(L.p2 - xl));
+        if (is_r) xl = neg;
+        if (lane == 0) hand[is_r ? 3 : 2] = ok ? 1u : 0u;
+        if (L.row == 0 && L.c < 10) {
+            park[(is_r ? 20 : 0) + L.c] = xl;
+            park[(is_r ? 30 : 10) + L.c] = yl;
+        }
     }
     __syncthreads();
     const u32 f = hand[1] | (hand[2] ? FLAG_KEY_OK : 0u) | (hand[3] ? FLAG_R_OK : 0u);
