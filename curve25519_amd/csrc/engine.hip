@@ -1327,10 +1327,10 @@ bool coop_for(size_t n, size_t dflt)
 }
 // crossovers measured on MI355X (tools/small_batch_sweep.py, profiles/r04_small_batch_sweep.txt): the ladder one per wave
 // wins up to 4096 elements (0.49 against 0.66 ms), the fixed-base operations up to 2048 (0.10-0.16 against 0.15-0.19 ms),
-// verification (three waves per element, profiles/r05_small_batch_sweep.txt) up to 1024
+// verification (three waves per element, profiles/r05_small_batch_sweep.txt) up to 2048
 bool x25519_coop_for(size_t n) { return coop_for(n, 4096); }
 bool fixed_base_coop_for(size_t n) { return coop_for(n, 2048); }
-bool verify_coop_for(size_t n) { return coop_for(n, 1024); }       // three waves per element: 0.15-0.34 against 0.60 ms (0.67 at 2048)
+bool verify_coop_for(size_t n) { return coop_for(n, 2048); }       // three waves per element: 0.13-0.55 against 0.60 ms (1.02 at 4096)
 
 // a batch that fills the chip runs the ladder and the shared inversion as two launches (k_x25519_ladder's comment);
 // tunable XF_SPLIT = 0 / 1 forces either shape (A/B knob)
