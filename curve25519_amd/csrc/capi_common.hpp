@@ -91,13 +91,14 @@ enum Tunable {
     T_HELPER_THREADS,           // cap on the staging helper threads of one process (unset: the CPUs this process may use)
     T_VERIFY_LAT_CAP_BITS,      // TEST knob: verification's lattice walk takes short vectors up to this many bits (100..158)
     T_ONE_KEY_WIDE,             // ed25519_Verify_Check: smallest batch that builds a wide comb for its key (0: never; default 2^16)
+    T_LADDER2_MAX,              // curve25519_dh_CreateSharedKey: largest call that runs the ladder on TWO waves per element (0: never)
     T_COUNT
 };
 constexpr long T_UNSET = -1;
 inline const char* const* tunable_names()
 {
     static const char* const names[T_COUNT] = { "COOP_MAX", "XF_SPLIT", "INV_K", "VERIFY_REFERENCE_ORDER", "MULTI_FORCE_GATHER",
-                                                "MULTI_VIRTUAL", "BASE_COMB", "HELPER_THREADS", "VERIFY_LAT_CAP_BITS", "ONE_KEY_WIDE" };
+                                                "MULTI_VIRTUAL", "BASE_COMB", "HELPER_THREADS", "VERIFY_LAT_CAP_BITS", "ONE_KEY_WIDE", "LADDER2_MAX" };
     return names;
 }
 inline std::atomic<long>* tunable_table()

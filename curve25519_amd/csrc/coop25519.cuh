@@ -369,6 +369,64 @@ C25519_DEV u32 ladder_step(u32* lds, const Lane& L, u32 v, u32 eq)
     return mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_X1, SLOT_ONE, SLOT_ONE));
 }
 
+// ---- the ladder on TWO waves: a step in two product levels instead of three --------------------------------------------------
+// The third level of ladder_step is ONE product, z3 = x1 (DA - CB)^2, with three rows idle: the multiplication by the base point's x
+// can only follow the squaring.  Carry the sum point TWICE -- S = (x : z) and x1 S = (x1 x : x1 z) -- and it disappears:
+//   level 1   DA = A Dp, CB = C B, x1 DA = (x1 A) Dp, x1 CB = C (x1 B)      |  AA = P^2, BB = M^2
+//   level 2   x3 = V^2, z3 = U (x1 U), x1 x3 = V (x1 V), x1 z3 = (x1 U)^2   |  x4 = AA BB, z4 = E F
+// with V = DA + CB, U = DA - CB and x1 V, x1 U the same sums of the scaled products: x1 U^2 = U (x1 U), x1 (x1 U^2) = (x1 U)^2.
+// Twelve products instead of nine -- the eight on the left are the differential addition, a full wave's two levels (state: x, z,
+// x1 x, x1 z in the four rows); the four on the right are the doubling, which a SECOND wave carries (x in its even rows, z in
+// the odd; its two row pairs square the double's and the sum's x + z, x - z side by side and the scalar's bit picks one).  Within a step neither wave needs the other; at the step's start wave 0 publishes B = x + z and A = x - z of the
+// sum (the doubling continues from them when the scalar's bit flips) and wave 1 publishes Dp and C of the double: ONE workgroup
+// barrier per step.  The published slots alternate between two sets by the step's parity, so a wave that is a step ahead writes
+// where nobody reads.  (Slot 10 stays the dump of the idle lanes.)
+constexpr int X2_PUB = 12;                                 // + 6 * parity: B, A, x1 B, x1 A (wave 0), Dp, C (wave 1)
+constexpr int X2_SHARED_SLOTS = 24;
+constexpr int X2_LDS_WORDS = (X2_SHARED_SLOTS + 2 * NSLOTS) * SLOT_WORDS;    // ... and a private region per wave
+
+// wave 0: the sum point and x1 times it (rows: x, z, x1 x, x1 z) through one step.  sh: the shared slots, lds: this wave's own.
+C25519_DEV u32 ladder2_step_sum(u32* sh, u32* lds, const Lane& L, u32 v, u32 parity)
+{
+    const u32 pub = X2_PUB + 6 * parity;
+    u32 ev, od;
+    pair_exchange(ev, od, v);
+    const u32 val = L.odd_row ? ev + L.p2 - od : ev + od;  // B, A, x1 B, x1 A
+    put(sh, L, pub + L.row, val);
+    __syncthreads();
+    // level 1: A * Dp, C * B, (x1 A) * Dp, C * (x1 B)
+    v = mul_level(sh, L, L.odd_row ? pub + 5 : pub + 1 + (L.upper ? 2 : 0), L.odd_row ? pub + (L.upper ? 2 : 0) : pub + 4);
+    pair_exchange(ev, od, v);
+    const u32 w = carry_small(L, (u64)(L.odd_row ? ev + L.p2 - od : ev + od));   // V, U, x1 V, x1 U
+    put(lds, L, L.row, w);
+    // level 2: V^2 = x3, U * (x1 U) = z3, V * (x1 V) = x1 x3, (x1 U)^2 = x1 z3
+    return mul_level(lds, L, by_row(L, 0, 1, 0, 3), by_row(L, 0, 3, 2, 3));
+}
+
+// wave 1: the double (even rows x, odd rows z; both row pairs alike) through the same step
+C25519_DEV u32 ladder2_step_double(u32* sh, u32* lds, const Lane& L, u32 v, u32 eq, u32 parity)
+{
+    const u32 pub = X2_PUB + 6 * parity;
+    u32 ev, od;
+    pair_exchange(ev, od, v);
+    const u32 val = L.odd_row ? ev + L.p2 - od : ev + od;  // Dp, C
+    put(sh, L, pub + 4 + (L.odd_row ? 1 : 0), val);
+    __syncthreads();
+    // the point to double is this one when the bit repeats, else the sum: the lower row pair squares Dp and C, the upper pair B and
+    // A as wave 0 published them (fixed slots: no secret-dependent address), and the bit chooses between the two pairs' squares
+    const u32 s = (L.upper ? pub : pub + 4) + (L.odd_row ? 1 : 0);
+    v = mul_level(sh, L, s, s);
+    u32 lo, hi;
+    half_exchange(lo, hi, v);
+    v = hi ^ ((hi ^ lo) & eq);                             // AA = P^2 (even rows), BB = M^2 (odd rows), in both row pairs
+    pair_exchange(ev, od, v);
+    const u32 E = ev + L.p2 - od;
+    const u32 F = carry_small(L, (u64)E * 121665u + ev);
+    put_a(lds, L, L.row, L.odd_row ? E : ev);
+    put_y(lds, L, L.row, L.odd_row ? F : od);
+    return mul_level(lds, L, L.row, L.row);                // x4 = AA * BB, z4 = E * F
+}
+
 // ---- the fixed-base Edwards walk, one operation per wave ------------------------------------------------------------
 // A point (X : Y : Z : T) lives in the four rows (row 0 X ... row 3 T), limb per lane; an addition of a precomputed affine
 // row (edp_AddAffinePoint, ed25519_sign.c:97-115) and a doubling (edp_DoublePoint, :122-143) are two product levels each:

@@ -102,6 +102,74 @@ C25519_DEV void x25519_one(u32* lds, const Lane& L, void* out, const void* pk, v
     wipe(lds, ROWQ_OFF);
 }
 
+// curve25519_dh_CreateSharedKey for element e by a workgroup of TWO waves (coop25519.cuh: the ladder step in two product levels,
+// wave 0 the differential addition with x1 times the sum carried along, wave 1 the doubling): 510 levels and 255 barriers instead
+// of 765 levels.  lds_all: X2_LDS_WORDS words.  The set-up
+// and the tail (three doublings, inversion, canonical bytes) are x25519_one's, in a slot region of the wave's own.
+C25519_DEV void x25519_two_waves(u32* lds_all, void* out, const void* pk, void* sk, size_t e)
+{
+    const int wave = threadIdx.x >> 6;
+    const Lane L = make_lane(threadIdx.x & 63);
+    u32* lds = lds_all + (X2_SHARED_SLOTS + wave * NSLOTS) * SLOT_WORDS;
+    u32 u[8], k[8];
+    load32(u, pk, e);
+    load32(k, sk, e);
+    clamp_words(k);
+    if (threadIdx.x == 0) store32(sk, e, k);            // the reference clamps in the caller's buffer
+    fe X1, one;
+    fe_from_words(X1, u);
+    fe_set_u32(one, 1);
+    const u32 x1 = my_limb(lds, L, X1), o1 = my_limb(lds, L, one);
+    u32 v;
+    if (wave == 0) {                                     // P = (X1 : 1) in rows 0, 1 and x1 P = (x1^2 : x1) in rows 2, 3
+        const u32 xx = sqr_n(lds, L, x1, 1);
+        v = L.upper ? (L.odd_row ? x1 : xx) : (L.odd_row ? o1 : x1);
+    } else {                                             // Q = 2P, in both row pairs
+        v = mont_double(lds, L, L.odd_row ? o1 : x1);
+    }
+    u32 prev = 1, par = 0;
+#pragma unroll 1
+    for (int w = 7; w >= 0; w--) {
+        u32 kw = k[7];                                   // the scalar's words as a queue (x25519.cuh)
+#pragma unroll
+        for (int t = 7; t > 0; t--) k[t] = k[t - 1];
+        const int top = (w == 7) ? 29 : 31, bottom = (w == 0) ? 3 : 0;
+        kw <<= (31 - top);
+#pragma unroll 1
+        for (int b = top; b >= bottom; b--) {
+            const u32 bit = kw >> 31;
+            kw <<= 1;
+            v = wave == 0 ? ladder2_step_sum(lds_all, lds, L, v, par) : ladder2_step_double(lds_all, lds, L, v, (u32)0 - (u32)(bit == prev), par);
+            par ^= 1u;
+            prev = bit;
+        }
+    }
+    // P = the sum if the last bit was one, else the double (curve25519_dh.c:148-150): wave 1 hands the double over and is done
+    const u32 slot = X2_PUB + 6 * par + 4 + (L.odd_row ? 1 : 0);
+    if (wave != 0) put_a(lds_all, L, slot, v);
+    __syncthreads();
+    if (wave != 0) return;                               // (no barrier behind this point)
+    u32 lo, hi;
+    half_exchange(lo, hi, v);                            // lo: x, z of the sum in both row pairs
+    const u32 dbl = lds_all[slot * SLOT_WORDS + A_OFF + (L.c < 10 ? L.c : 0)];
+    u32 p = dbl ^ ((dbl ^ lo) & ((u32)0 - prev));
+#pragma unroll 1
+    for (int i = 0; i < 3; i++) p = mont_double(lds, L, p);
+    const u32 zi = invert(lds, L, p);
+    u32 px, pz, ix, iz;
+    pair_exchange(px, pz, p);
+    pair_exchange(ix, iz, zi);
+    const u32 r = mul2(lds, L, px, iz);
+    put_a(lds, L, L.row, r);
+    wave_fence();
+    fe R;
+    get_fe(R, lds, 0);
+    u32 wds[8];
+    fe_to_words(wds, R);
+    if (threadIdx.x == 0) store32(out, e, wds);         // written last: `out` may alias `pk`
+    wipe(lds_all, X2_LDS_WORDS);
+}
+
 // the fixed-base walk of the three operations below: over the wide comb (rows from device memory; a blinding context if given)
 // or the eight LDS-comb tables read from device memory
 template <bool WIDE>

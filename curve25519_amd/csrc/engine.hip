@@ -272,6 +272,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
     coop::x25519_one<BASE9>(lds, coop::make_lane(threadIdx.x), out, pk, sk, blockIdx.x);
 }
 
+// ... and on TWO waves per element (coop::x25519_two_waves: a ladder step in two product levels -- the differential addition with
+// x1 times the sum carried along on one wave, the doubling on the other, one workgroup barrier per step): what ONE
+// curve25519_dh_CreateSharedKey call and calls of up to 512 run -- 183 -> 168 us per call
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop2(void* out, const void* pk, void* sk, size_t n)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds[coop::X2_LDS_WORDS];
+    if (blockIdx.x >= n) return;
+    coop::x25519_two_waves(lds, out, pk, sk, blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // 8-fold base table, generated on the device at first use
 // ------------------------------------------------------------------------------------------------
@@ -1329,6 +1339,14 @@ bool coop_for(size_t n, size_t dflt)
 // wins up to 4096 elements (0.49 against 0.66 ms), the fixed-base operations up to 2048 (0.10-0.16 against 0.15-0.19 ms),
 // verification (three waves per element, profiles/r05_small_batch_sweep.txt) up to 2048
 bool x25519_coop_for(size_t n) { return coop_for(n, 4096); }
+// ... two waves per element while every wave still finds a SIMD of its own: 167 against 179 us for one element, 193 against 201 for
+// 512, 213 against 216 for 1024 (profiles/r05_small_batch_sweep.txt; tunable LADDER2_MAX; a per-wave call in any case)
+bool x25519_two_waves_for(size_t n)
+{
+    const long v = c25519_host::tunable(c25519_host::T_LADDER2_MAX);
+    const size_t max = v == c25519_host::T_UNSET ? 512 : (size_t)std::min<long>(std::max<long>(v, 0), 1L << 20);
+    return n <= max && x25519_coop_for(n);
+}
 bool fixed_base_coop_for(size_t n) { return coop_for(n, 2048); }
 bool verify_coop_for(size_t n) { return coop_for(n, 2048); }       // three waves per element: 0.13-0.55 against 0.60 ms (1.02 at 4096)
 
@@ -1436,7 +1454,8 @@ void c25519_amd_thread_release(void)
 static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t stream)
 {
     if (x25519_coop_for(n)) {
-        if (pk) k_x25519_coop<false><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n);
+        if (pk && x25519_two_waves_for(n)) k_x25519_coop2<<<(unsigned)n, 128, 0, stream>>>(out, pk, sk, n);
+        else if (pk) k_x25519_coop<false><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n);
         else    k_x25519_coop<true><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n);
         C25519_TRY(hipGetLastError());
         return 0;

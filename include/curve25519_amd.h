@@ -43,7 +43,8 @@ int  c25519_amd_set_device(int device);                /* device used by this ho
  * 1 = the wide 13 x 20 comb read through L2, the default), HELPER_THREADS (cap on the staging helper threads; default: the CPUs this process may use),
  * VERIFY_LAT_CAP_BITS (test knob, 100..157: verification's lattice walk refuses longer short vectors, which then take the
  * reference-order kernel), ONE_KEY_WIDE (ed25519_Verify_Check_*: the smallest batch that builds a wide comb for its one key,
- * default 65536; 0 = never).
+ * default 65536; 0 = never), LADDER2_MAX (curve25519_dh_CreateSharedKey_*: the largest call that runs the ladder on two waves per
+ * element, default 512; 0 = never).
  * _get returns -1 for "built-in choice", -2 for an unknown name. */
 int  c25519_amd_tunable_set(const char *name, long value);
 long c25519_amd_tunable_get(const char *name);

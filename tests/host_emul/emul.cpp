@@ -571,6 +571,14 @@ void emul_coop_x25519(unsigned char* out, const unsigned char* pk, unsigned char
         });
 }
 
+void emul_coop_x25519_two_waves(unsigned char* out, const unsigned char* pk, unsigned char* sk, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    std::vector<u32> lds(coop::X2_LDS_WORDS);
+    for (size_t e = 0; e < n; e++)
+        emul_coop::run_block(128, [&] { coop::x25519_two_waves(lds.data(), out, pk, sk, e); });
+}
+
 void emul_coop_public_fast(unsigned char* pk, unsigned char* sk, size_t n, int wide)
 {
     std::lock_guard<std::mutex> lk(g_coop_mu);

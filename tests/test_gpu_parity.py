@@ -1232,6 +1232,36 @@ def test_small_calls_run_one_operation_per_wave_and_agree_with_the_batch_kernels
         assert np.array_equal(api.ed25519_SignMessage(priv, msg), oracle.ed25519_sign(priv, msg))
 
 
+def test_x25519_calls_of_a_few_elements_run_the_ladder_on_two_waves(api, oracle):
+    """curve25519_dh_CreateSharedKey for up to 512 elements per call runs k_x25519_coop2: two waves per element, a ladder step in
+    two product levels (one wave the differential addition with x1 times the sum carried along, the other the doubling), operands
+    exchanged through LDS behind one workgroup barrier per step.  KATs with every edge public key, fixture rows at 1 / 2 / 511 /
+    512 / 513 elements (the last one back on the one-wave kernel) and a random batch, against the reference's bytes and -- tunable
+    LADDER2_MAX = 0 / large -- against the one-wave kernel; the clamped secret is written back."""
+    from curve25519_amd import _lib
+    recs = KAT["x25519"]
+    pk, sk = np.concatenate([h2a(r["pk"]) for r in recs]), np.concatenate([h2a(r["sk"]) for r in recs])
+    shared, clamped = api.curve25519_dh_CreateSharedKey(pk, sk)
+    for i, r in enumerate(recs):
+        assert shared[i].tobytes().hex() == r["shared"] and clamped[i].tobytes().hex() == r["sk_clamped"], r["name"]
+    g = R1024
+    for n in (1, 2, 511, 512, 513, 1000):
+        got = {}
+        for knob in (0, 1 << 20):
+            with _lib.tunable("LADDER2_MAX", knob):
+                got[knob] = api.curve25519_dh_CreateSharedKey(g["x_pk"][:n], g["x_sk"][:n])
+        default = api.curve25519_dh_CreateSharedKey(g["x_pk"][:n], g["x_sk"][:n])
+        for shared, clamped in (got[0], got[1 << 20], default):
+            assert np.array_equal(shared, g["x_shared"][:n]) and np.array_equal(clamped, g["x_sk_clamped"][:n]), n
+    n = 700
+    sk, pk = synth.random_bytes((n, 32), 0x8801), synth.random_bytes((n, 32), 0x8802)
+    pk[3], pk[4] = 0, 255                                              # a low-order point; 2^256 - 1
+    with _lib.tunable("LADDER2_MAX", 1 << 20):
+        shared, clamped = api.curve25519_dh_CreateSharedKey(pk, sk)
+    e_shared, e_clamped = oracle.x25519_shared(pk, sk)
+    assert np.array_equal(shared, e_shared) and np.array_equal(clamped, e_clamped)
+
+
 def test_warm_device_calls_can_be_captured_into_a_hip_graph(api, oracle):
     """A *_dev call on a stream that has run it before allocates nothing and synchronises nothing: kernel launches and one
     event record, so a caller may capture it into a HIP graph and replay it.  (Replaying saves nothing -- back-to-back calls

@@ -49,6 +49,12 @@ class Wave:
         self.lib.emul_coop_x25519(ptr(out), ptr(rows(pk, 32)) if pk is not None else None, ptr(sk), sk.shape[0])
         return out, sk
 
+    def x25519_two_waves(self, pk, sk):
+        sk = rows(sk, 32).copy()
+        out = np.empty_like(sk)
+        self.lib.emul_coop_x25519_two_waves(ptr(out), ptr(rows(pk, 32)), ptr(sk), sk.shape[0])
+        return out, sk
+
     def public_fast(self, sk, wide=1):
         sk = rows(sk, 32).copy()
         out = np.empty_like(sk)
@@ -99,7 +105,8 @@ def lib():
     lib = C.CDLL(emul_build.build())
     lib.emul_mad_overflow_count.restype = C.c_ulonglong
     lib.emul_coop_sync_points.restype = C.c_ulonglong
-    for name, args in {"emul_coop_x25519": [vp, vp, vp, sz], "emul_coop_public_fast": [vp, vp, sz, C.c_int],
+    for name, args in {"emul_coop_x25519": [vp, vp, vp, sz], "emul_coop_x25519_two_waves": [vp, vp, vp, sz],
+                       "emul_coop_public_fast": [vp, vp, sz, C.c_int],
                        "emul_coop_keypair": [vp, vp, vp, vp, sz, C.c_int], "emul_coop_sign": [vp, vp, vp, vp, sz, sz, C.c_int],
                        "emul_coop_blinding_init": [vp, vp, sz], "emul_coop_verify_init": [vp, vp, sz],
                        "emul_coop_verify_check": [vp, vp, vp, vp, sz, sz],
@@ -136,6 +143,22 @@ def test_x25519_per_wave_gives_the_reference_bytes(wave, lib):
     shared, clamped = wave.x25519(g["x_pk"][:m], g["x_sk"][:m])
     assert np.array_equal(shared, g["x_shared"][:m]) and np.array_equal(clamped, g["x_sk_clamped"][:m])
     assert lib.emul_coop_sync_points() > before                       # the lanes did meet (the scheduler ran, not a one-lane stub)
+
+
+def test_x25519_on_two_waves_gives_the_reference_bytes(wave):
+    """The ladder step in two product levels (coop25519.cuh: one wave the differential addition with x1 times the sum point carried
+    along, the other the doubling; 128 lock-step lanes, a workgroup barrier per step): RFC 7748, every edge public key (0, 1, p - 1, p, p + 1, 2^255 - 1, 2^256 - 1: x1 = 0 makes
+    the scaled point vanish), rows of the reference's fixture -- and byte for byte the one-wave kernel's results."""
+    recs = KAT["x25519"]
+    pk, sk = np.concatenate([h2a(r["pk"]) for r in recs]), np.concatenate([h2a(r["sk"]) for r in recs])
+    shared, clamped = wave.x25519_two_waves(pk, sk)
+    for i, r in enumerate(recs):
+        assert shared[i].tobytes().hex() == r["shared"] and clamped[i].tobytes().hex() == r["sk_clamped"], r["name"]
+    g, m = R1024, 6
+    shared, clamped = wave.x25519_two_waves(g["x_pk"][10:10 + m], g["x_sk"][10:10 + m])
+    assert np.array_equal(shared, g["x_shared"][10:10 + m]) and np.array_equal(clamped, g["x_sk_clamped"][10:10 + m])
+    one, _ = wave.x25519(g["x_pk"][10:12], g["x_sk"][10:12])
+    assert np.array_equal(one, shared[:2])
 
 
 def test_ed25519_per_wave_gives_the_reference_bytes(wave):

@@ -39,6 +39,15 @@ def us(fn, n, reps=12):
     return sorted(ts)[len(ts) // 2]
 
 
+print(f"{'op':12s} {'n':>6s} {'two waves each [us]':>20s} {'one per wave [us]':>18s}     (curve25519_dh_CreateSharedKey: tunable LADDER2_MAX)")
+for n in (1, 16, 64, 128, 256, 512, 1024, 2048):
+    _lib.set_tunable("COOP_MAX", 1 << 20)
+    _lib.set_tunable("LADDER2_MAX", 1 << 20)
+    a = us(ops["x25519"], n)
+    _lib.set_tunable("LADDER2_MAX", 0)
+    b = us(ops["x25519"], n)
+    print(f"{'x25519':12s} {n:6d} {a:20.1f} {b:18.1f}", flush=True)
+_lib.set_tunable("LADDER2_MAX", -1)
 print(f"{'op':12s} {'n':>6s} {'one per wave [us]':>18s} {'one per lane [us]':>18s}")
 for name, fn in ops.items():
     for n in (1, 16, 64, 256, 1024, 2048, 4096, 8192, 16384):
