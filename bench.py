@@ -336,6 +336,39 @@ def cpu_baseline(quick=False):
             "cpu_model": model, "asm_backend": asm}
 
 
+def device_identity(torch, dev_index):
+    """What this rank's device IS, for the line's `ranks` attestation: UUID, PCI address, name, compute units -- so that "did
+    RCCL see N ranks on N distinct devices" is answerable from the record alone (rccl.h:745: one ncclGather, every peer on a
+    device of its own)."""
+    pr = torch.cuda.get_device_properties(dev_index)
+    uuid = getattr(pr, "uuid", None)
+    pci = None
+    if hasattr(pr, "pci_bus_id"):
+        pci = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+    return {"device_index": dev_index, "device_name": pr.name, "uuid": str(uuid) if uuid is not None else None,
+            "pci_bus_id": pci, "compute_units": pr.multi_processor_count, "gcn_arch": getattr(pr, "gcnArchName", None),
+            "hbm_bytes": pr.total_memory}
+
+
+def attest_ranks(identities, world, backend, share_gpu):
+    """The `rccl` object of the line from every rank's device_identity(): the ranks' devices must be pairwise distinct
+    (UUID and PCI address) unless the shared-GPU launcher self-test knob is set -- a run whose ranks sat on one device is
+    not a multi-GPU run whatever the launcher said."""
+    keys = [(a.get("uuid"), a.get("pci_bus_id"), a.get("device_index")) for a in identities]
+    hw = [(a.get("uuid"), a.get("pci_bus_id")) for a in identities]
+    distinct = len(set(keys)) == len(keys)
+    distinct_hw = len(set(hw)) == len(hw) and all(u is not None or p is not None for u, p in hw)
+    pcis = [a.get("pci_bus_id") for a in identities]
+    # CPX: the logical devices of ONE MI355X are distinct devices that share its PCI address
+    one_package = world > 1 and distinct and pcis[0] is not None and len(set(pcis)) == 1
+    return {"backend": backend, "world": world, "ranks_seen": len(identities),
+            "compute_partitions_of_one_device": bool(one_package or any(a.get("compute_partition") for a in identities)),
+            "devices_distinct": bool(distinct), "devices_distinct_by_uuid_or_pci": bool(distinct_hw),
+            "shared_gpu_selftest": bool(share_gpu),
+            "is_multi_gpu_measurement": bool(world > 1 and distinct and not share_gpu and backend == "nccl" and not one_package
+                                             and not any(a.get("compute_partition") for a in identities))}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -412,6 +445,22 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- who is here: every rank's device, the collective backend and its version, gathered to rank 0 for the line ----
+    ident = device_identity(torch, dev_index)
+    ident.update({"rank": rank, "local_rank": local_rank, "hostname": socket.gethostname(), "pid": os.getpid(),
+                  "backend": dist.get_backend() if use_dist else None,
+                  "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                  "compute_partition": os.environ.get("C25519_BENCH_PARTITION_NOTE")})
+    identities = [ident]
+    if use_dist:
+        identities = [None] * world
+        dist.all_gather_object(identities, ident)
+        identities.sort(key=lambda a: a["rank"])
+    rccl = attest_ranks(identities, world, dist.get_backend() if use_dist else None, share_gpu)
+    if world > 1 and not share_gpu and not rccl["devices_distinct"]:
+        raise SystemExit("bench.py: two ranks of this run sit on the same device (" + json.dumps(identities) + "): not a multi-GPU "
+                         "run.  (C25519_BENCH_SHARE_GPU=1 is the launcher self-test that allows it, over gloo.)")
 
     n = args.batch
     eng = HipEngine(dev)
@@ -729,9 +778,12 @@ def main():
             "time between the same points in `timing` / per_rank",
             "config": {"workload": WORKLOAD_NAME[wl], "batch_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"shard{world}" + (("+gloo_gather_SHARED_GPU_SELFTEST" if share_gpu else "+rccl_gather")
-                                                          if use_dist else "")},
+                                                          if use_dist else "") +
+                                      ("+COMPUTE_PARTITIONS_OF_ONE_GPU_not_a_scaling_figure" if rccl["compute_partitions_of_one_device"] else "")},
             "roofline": roof, "timing": primary.get("timing"),
         }
+        result["ranks"] = identities                 # every rank's device (UUID, PCI address), backend and RCCL version
+        result["rccl"] = rccl
         for k in ("rejected", "rejects_exactly_the_corrupted"):        # --workload verify: the primary pass's own check
             if k in primary:
                 result[k] = primary[k]

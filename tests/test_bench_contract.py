@@ -99,3 +99,25 @@ def test_expected_digests_cover_every_rank_of_the_scaling_run():
     for k, v in dig[str(n)].items():
         assert k == "n" or bench.expected_digests(0, 1, n)[k] == v
     assert bench.expected_digests(0, 1, 12345) is None and bench.expected_digests(9, 16, n) is None
+
+
+def test_rank_attestation_says_what_rccl_saw():
+    """The line's `ranks` / `rccl` objects (rccl.h:745): N ranks on N distinct devices over the "nccl" backend is
+    the only thing that counts as a multi-GPU measurement; a shared device, a gloo group or the logical devices of one
+    partitioned MI355X say so."""
+    bench = load(os.path.join(ROOT, "bench.py"), "c25519_bench_attest")
+    def ident(r, uuid, pci, idx, part=None):
+        return {"rank": r, "uuid": uuid, "pci_bus_id": pci, "device_index": idx, "compute_partition": part}
+    eight = [ident(r, f"GPU-{r:02x}", f"0000:{0x10 + r:02x}:00", r) for r in range(8)]
+    a = bench.attest_ranks(eight, 8, "nccl", False)
+    assert a["devices_distinct"] and a["devices_distinct_by_uuid_or_pci"] and a["is_multi_gpu_measurement"]
+    assert a["world"] == 8 and a["ranks_seen"] == 8 and not a["compute_partitions_of_one_device"]
+    same = [ident(r, "GPU-00", "0000:10:00", 0) for r in range(2)]
+    a = bench.attest_ranks(same, 2, "gloo", True)
+    assert not a["devices_distinct"] and not a["is_multi_gpu_measurement"] and a["shared_gpu_selftest"]
+    assert not bench.attest_ranks(same, 2, "nccl", False)["devices_distinct"]          # main() refuses to run this
+    cpx = [ident(r, f"GPU-{r:02x}", "0000:10:00", r) for r in range(8)]              # eight logical devices of ONE package
+    a = bench.attest_ranks(cpx, 8, "nccl", False)
+    assert a["devices_distinct"] and a["compute_partitions_of_one_device"] and not a["is_multi_gpu_measurement"]
+    one = bench.attest_ranks([ident(0, "GPU-00", "0000:10:00", 0)], 1, None, False)
+    assert one["devices_distinct"] and not one["is_multi_gpu_measurement"] and one["backend"] is None
