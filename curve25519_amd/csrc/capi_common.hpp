@@ -92,13 +92,16 @@ enum Tunable {
     T_VERIFY_LAT_CAP_BITS,      // TEST knob: verification's lattice walk takes short vectors up to this many bits (100..158)
     T_ONE_KEY_WIDE,             // ed25519_Verify_Check: smallest batch that builds a wide comb for its key (0: never; default 2^16)
     T_LADDER2_MAX,              // curve25519_dh_CreateSharedKey: largest call that runs the ladder on TWO waves per element (0: never)
+    T_QUAD_MIN,                 // calls of MORE than QUAD_MIN and at most QUAD_MAX elements run FOUR LANES per element (quad25519.cuh):
+    T_QUAD_MAX,                 //   QUAD_MAX = 0: never; unset: per operation (engine.hip)
     T_COUNT
 };
 constexpr long T_UNSET = -1;
 inline const char* const* tunable_names()
 {
     static const char* const names[T_COUNT] = { "COOP_MAX", "XF_SPLIT", "INV_K", "VERIFY_REFERENCE_ORDER", "MULTI_FORCE_GATHER",
-                                                "MULTI_VIRTUAL", "BASE_COMB", "HELPER_THREADS", "VERIFY_LAT_CAP_BITS", "ONE_KEY_WIDE", "LADDER2_MAX" };
+                                                "MULTI_VIRTUAL", "BASE_COMB", "HELPER_THREADS", "VERIFY_LAT_CAP_BITS", "ONE_KEY_WIDE", "LADDER2_MAX",
+                                                "QUAD_MIN", "QUAD_MAX" };
     return names;
 }
 inline std::atomic<long>* tunable_table()

@@ -19,6 +19,7 @@
 #include "verify_fast.cuh"
 #include "coop25519.cuh"
 #include "coop_ops.cuh"
+#include "quad25519.cuh"
 
 #include "../../include/curve25519_amd.h"
 #include "../../include/curve25519_dh.h"
@@ -280,6 +281,18 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 4))
     __shared__ __attribute__((aligned(16))) u32 lds[coop::X2_LDS_WORDS];
     if (blockIdx.x >= n) return;
     coop::x25519_two_waves(lds, out, pk, sk, blockIdx.x);
+}
+
+// FOUR LANES per element (quad25519.cuh): what a call of 2^12 .. 2^14 elements runs -- too many for a wave each, too few to
+// give every SIMD a wave of one-lane elements (2^14 elements are 256 such waves on 1024 SIMDs).  A quad runs one product of a
+// ladder step per lane and level, operands exchanged with v_mov_b32_dpp quad_perm; 16 elements per wave, one wave per
+// workgroup, inversion and encoding in the same launch: no LDS, no scratch, no barrier.
+template <bool BASE9>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_x25519_quad(void* out, const void* pk, void* sk, size_t n)
+{
+    const size_t e = (size_t)blockIdx.x * quad::ELEMS_PER_WAVE + (threadIdx.x >> 2);
+    if (e >= n) return;                                       // (whole quads leave: the exchanges stay inside a quad)
+    quad::x25519_element<BASE9>(out, pk, sk, e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1347,6 +1360,19 @@ bool x25519_two_waves_for(size_t n)
     const size_t max = v == c25519_host::T_UNSET ? 512 : (size_t)std::min<long>(std::max<long>(v, 0), 1L << 20);
     return n <= max && x25519_coop_for(n);
 }
+// four lanes per element (k_x25519_quad): between the per-wave kernels and the batches that give every SIMD a wave of one-lane
+// elements.  X25519: the quad's step is 721 instructions against the lane's 1246 and a lone wave issues one every ~5.1 cycles, so
+// up to 2^14 elements (1024 quad-waves, one per SIMD) a call takes ~0.47 ms instead of 0.71; from 2^14 + 1 the second wave on a
+// SIMD doubles that.  Tunables QUAD_MIN / QUAD_MAX (tools/mid_batch_sweep.py, profiles/r06_mid_batch_sweep.txt).
+bool quad_for(size_t n, size_t dflt_min, size_t dflt_max)
+{
+    const long lo = c25519_host::tunable(c25519_host::T_QUAD_MIN), hi = c25519_host::tunable(c25519_host::T_QUAD_MAX);
+    const size_t mn = lo == c25519_host::T_UNSET ? dflt_min : (size_t)std::max<long>(lo, 0);
+    const size_t mx = hi == c25519_host::T_UNSET ? dflt_max : (size_t)std::min<long>(std::max<long>(hi, 0), 1L << 24);
+    const size_t m = std::max(n, c25519_host::batch_shape_hint());     // a piece of a pipelined *_batch call: the whole call counts
+    return m > mn && m <= mx;
+}
+bool x25519_quad_for(size_t n) { return quad_for(n, 4608, (size_t)1 << 14); }
 bool fixed_base_coop_for(size_t n) { return coop_for(n, 2048); }
 bool verify_coop_for(size_t n) { return coop_for(n, 2048); }       // three waves per element: 0.13-0.55 against 0.60 ms (1.02 at 4096)
 
@@ -1453,6 +1479,13 @@ void c25519_amd_thread_release(void)
 
 static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t stream)
 {
+    if (x25519_quad_for(n)) {                                 // four lanes per element
+        const unsigned grid = grid_for(n, quad::ELEMS_PER_WAVE);
+        if (pk) k_x25519_quad<false><<<grid, 64, 0, stream>>>(out, pk, sk, n);
+        else    k_x25519_quad<true><<<grid, 64, 0, stream>>>(out, pk, sk, n);
+        C25519_TRY(hipGetLastError());
+        return 0;
+    }
     if (x25519_coop_for(n)) {
         if (pk && x25519_two_waves_for(n)) k_x25519_coop2<<<(unsigned)n, 128, 0, stream>>>(out, pk, sk, n);
         else if (pk) k_x25519_coop<false><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n);

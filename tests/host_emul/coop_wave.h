@@ -5,7 +5,8 @@
 // reaches one publishes its value and yields until all lanes of its wave (workgroup) have arrived.  Between two rendezvous a
 // lane runs alone, so an exchange through LDS that the device source does NOT bracket with wave_fence() shows up here as a
 // wrong result (on the device the lanes of a wave execute in lock-step, but the fence is also what keeps the compiler from
-// moving the accesses).  The model of the instructions is the ISA's: row_shr:n / row_ror:n within 16-lane rows with
+// moving the accesses).  The model of the instructions is the ISA's: quad_perm within groups of four lanes (quad25519.cuh),
+// row_shr:n / row_ror:n within 16-lane rows with
 // bound_ctrl (zero where nothing arrives), permlane16_swap = odd rows of the first operand <-> even rows of the second,
 // permlane32_swap = upper half of the first <-> lower half of the second.  The GPU suite establishes that the hardware
 // agrees; this establishes the arithmetic and data movement of the cooperative formulas on a CPU-only machine.
@@ -111,7 +112,8 @@ uint32_t dpp(uint32_t old, uint32_t src, int ctrl, bool bound_ctrl)
     b->xchg[me] = src;
     wave_sync();
     int from = -1;
-    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if (c >= n) from = row + c - n; }              // row_shr:n
+    if (ctrl >= 0 && ctrl <= 0xff) from = (me & ~3) + ((ctrl >> (2 * (me & 3))) & 3);                                  // quad_perm:[a,b,c,d]
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if (c >= n) from = row + c - n; }              // row_shr:n
     else if (ctrl >= 0x101 && ctrl <= 0x10f) { const int n = ctrl - 0x100; if (c + n < 16) from = row + c + n; }      // row_shl:n
     else if (ctrl >= 0x121 && ctrl <= 0x12f) { const int n = ctrl - 0x120; from = row + ((c - n) & 15); }             // row_ror:n
     else throw std::logic_error("emul_coop: DPP control not modelled");

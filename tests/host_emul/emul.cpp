@@ -9,6 +9,7 @@
 #include "lanes.cuh"
 #include "verify_fast.cuh"
 #include "coop_ops.cuh"
+#include "quad25519.cuh"
 
 #include <mutex>
 #include <thread>
@@ -577,6 +578,20 @@ void emul_coop_x25519_two_waves(unsigned char* out, const unsigned char* pk, uns
     std::vector<u32> lds(coop::X2_LDS_WORDS);
     for (size_t e = 0; e < n; e++)
         emul_coop::run_block(128, [&] { coop::x25519_two_waves(lds.data(), out, pk, sk, e); });
+}
+
+// ---- four lanes per element (csrc/quad25519.cuh): a wave of 64 lock-step lanes carries 16 elements; the kernel is
+// `e = blockIdx.x * 16 + lane / 4; if (e >= n) return;` around the call below
+void emul_quad_x25519(unsigned char* out, const unsigned char* pk, unsigned char* sk, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    for (size_t base = 0; base < n; base += quad::ELEMS_PER_WAVE)
+        emul_coop::run_block(64, [&] {
+            const size_t e = base + (threadIdx.x >> 2);
+            if (e >= n) return;
+            if (pk) quad::x25519_element<false>(out, pk, sk, e);
+            else quad::x25519_element<true>(out, pk, sk, e);
+        });
 }
 
 void emul_coop_public_fast(unsigned char* pk, unsigned char* sk, size_t n, int wide)

@@ -1501,3 +1501,45 @@ def test_page_locked_caller_arrays_are_used_in_place(api, oracle):
     t_sig.copy_(torch.from_numpy(bsig))
     assert L.ed25519_VerifySignature_batch(D(t_ok), D(t_sig), D(pin["pub"]), P(bmsg), bmsg.shape[1], n) == 0
     assert np.array_equal(t_ok.numpy() == 0, bad)
+
+
+def test_x25519_on_four_lanes_per_element(api, oracle):
+    """k_x25519_quad (quad25519.cuh): a quad of lanes per element, one product of the ladder step per lane and level, operands
+    exchanged with v_mov_b32_dpp quad_perm -- what calls of 2^12 .. 2^14 elements run.  Forced (QUAD_MIN = 0) for the KATs with
+    every edge public key (zero Z -> zero bytes), the base-point ladder of curve25519_dh_CalculatePublicKey (level 3 is a
+    multiplication by 9), fixture rows at 1 / 15 / 16 / 17 / 1000 elements (a lone quad, a wave short of one quad, exactly one
+    wave, one quad into the next workgroup), output aliasing the public keys, and at its own sizes by default -- 4609, 5000 and
+    2^14 elements -- against the oracle and against the one-lane kernels (QUAD_MAX = 0); the clamped secret is written back."""
+    import torch
+    import vectors
+    from curve25519_amd import _lib
+    recs = KAT["x25519"]
+    pk, sk = np.concatenate([h2a(r["pk"]) for r in recs]), np.concatenate([h2a(r["sk"]) for r in recs])
+    with _lib.tunable("QUAD_MIN", 0), _lib.tunable("QUAD_MAX", 1 << 20):
+        shared, clamped = api.curve25519_dh_CreateSharedKey(pk, sk)
+        for i, r in enumerate(recs):
+            assert shared[i].tobytes().hex() == r["shared"] and clamped[i].tobytes().hex() == r["sk_clamped"], r["name"]
+        recs = KAT["x25519_public"]
+        pub, clamped = api.curve25519_dh_CalculatePublicKey(np.concatenate([h2a(r["sk"]) for r in recs]))
+        for i, r in enumerate(recs):
+            assert pub[i].tobytes().hex() == r["pk"] and clamped[i].tobytes().hex() == r["sk_clamped"], r["name"]
+        g = R1024
+        for n in (1, 15, 16, 17, 1000):
+            shared, clamped = api.curve25519_dh_CreateSharedKey(g["x_pk"][:n], g["x_sk"][:n])
+            assert np.array_equal(shared, g["x_shared"][:n]) and np.array_equal(clamped, g["x_sk_clamped"][:n]), n
+        dev = torch.device("cuda", 0)                                  # `shared` aliasing `pk` (curve25519_dh.c:104,150)
+        buf, dsk = torch.from_numpy(g["x_pk"][:333].copy()).to(dev), torch.from_numpy(g["x_sk"][:333].copy()).to(dev)
+        api.curve25519_dh_CreateSharedKey_dev(buf, buf, dsk)
+        assert np.array_equal(buf.cpu().numpy(), g["x_shared"][:333]) and np.array_equal(dsk.cpu().numpy(), g["x_sk_clamped"][:333])
+    for n in (4609, 5000, 1 << 14):                                    # the sizes the dispatch gives to the quads by itself
+        sk, pk = synth.random_bytes((n, 32), 0x9901 + n), synth.random_bytes((n, 32), 0x9902 + n)
+        pk[3], pk[4], pk[n - 1] = 0, 255, 1                            # a low-order point; 2^256 - 1; another low-order point
+        shared, clamped = api.curve25519_dh_CreateSharedKey(pk, sk)
+        with _lib.tunable("QUAD_MAX", 0):
+            lane_shared, lane_clamped = api.curve25519_dh_CreateSharedKey(pk, sk)
+        assert np.array_equal(shared, lane_shared) and np.array_equal(clamped, lane_clamped), n
+        if n <= 5000:
+            e_shared, e_clamped = oracle.x25519_shared(pk, sk)
+            assert np.array_equal(shared, e_shared) and np.array_equal(clamped, e_clamped), n
+            pub, _ = api.curve25519_dh_CalculatePublicKey(sk)
+            assert np.array_equal(pub, oracle.x25519_shared(np.tile(vectors.le(9, 32), (n, 1)), sk)[0]), n

@@ -1,0 +1,77 @@
+"""CPU tests of the FOUR-LANES-PER-ELEMENT device source (curve25519_amd/csrc/quad25519.cuh: what batches of 2^12 .. 2^14 elements
+run on the device).  The same source is compiled by g++ and run as 64 lock-step lanes on the host -- 16 elements per wave, the
+v_mov_b32_dpp quad_perm exchanges between a quad's lanes as rendezvous (tests/host_emul/coop_wave.h) -- against the committed
+fixtures (the real reference's outputs).  What the GPU suite adds is that the hardware's quad_perm does what the model says."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "host_emul"))
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+KAT = json.load(open(os.path.join(GOLD, "kat.json")))
+R1024 = np.load(os.path.join(GOLD, "random_1024.npz"))
+vp, sz = C.c_void_p, C.c_size_t
+
+
+def h2a(s):
+    return np.frombuffer(bytes.fromhex(s), np.uint8).reshape(1, -1).copy()
+
+
+def ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import build as emul_build
+    lib = C.CDLL(emul_build.build())
+    lib.emul_mad_overflow_count.restype = C.c_ulonglong
+    lib.emul_coop_sync_points.restype = C.c_ulonglong
+    for name, args in {"emul_quad_x25519": [vp, vp, vp, sz]}.items():
+        getattr(lib, name).argtypes = args
+        getattr(lib, name).restype = None
+    yield lib
+    assert lib.emul_mad_overflow_count() == 0, "a v_mad_u64_u32 column wrapped 2^64: the bound contract is broken"
+
+
+def quad_x25519(lib, pk, sk):
+    sk = np.ascontiguousarray(sk, dtype=np.uint8).reshape(-1, 32).copy()
+    out = np.empty_like(sk)
+    pk = None if pk is None else np.ascontiguousarray(pk, dtype=np.uint8).reshape(-1, 32)
+    lib.emul_quad_x25519(ptr(out), ptr(pk), ptr(sk), sk.shape[0])
+    return out, sk
+
+
+def test_x25519_on_quads_gives_the_reference_bytes(lib):
+    """RFC 7748, the reference's test inputs and the edge public keys of SURVEY 3.5 (0, 1, p - 1, p, p + 1, 2^255 - 1, 2^256 - 1,
+    ...: a zero Z must come out as zero bytes) -- more records than one wave's 16 elements, so a partly filled wave runs too;
+    the base-point ladder (curve25519_dh_CalculatePublicKey: level 3 is a multiplication by 9); rows of the reference's
+    1024-row fixture; the clamped keys written back."""
+    before = lib.emul_coop_sync_points()
+    recs = KAT["x25519"]
+    shared, clamped = quad_x25519(lib, np.concatenate([h2a(r["pk"]) for r in recs]), np.concatenate([h2a(r["sk"]) for r in recs]))
+    for i, r in enumerate(recs):
+        assert shared[i].tobytes().hex() == r["shared"] and clamped[i].tobytes().hex() == r["sk_clamped"], r["name"]
+    recs = KAT["x25519_public"]
+    pk, clamped = quad_x25519(lib, None, np.concatenate([h2a(r["sk"]) for r in recs]))
+    for i, r in enumerate(recs):
+        assert pk[i].tobytes().hex() == r["pk"] and clamped[i].tobytes().hex() == r["sk_clamped"], r["name"]
+    g, m = R1024, 21                                                   # one full wave and five elements of the next
+    shared, clamped = quad_x25519(lib, g["x_pk"][100:100 + m], g["x_sk"][100:100 + m])
+    assert np.array_equal(shared, g["x_shared"][100:100 + m]) and np.array_equal(clamped, g["x_sk_clamped"][100:100 + m])
+    assert lib.emul_coop_sync_points() > before                       # the lanes did meet (the scheduler ran, not a one-lane stub)
+
+
+def test_x25519_on_quads_in_place(lib):
+    """`shared` may alias `pk` (curve25519_dh.c:104,150: the base point is copied first, the output written last)."""
+    g = R1024
+    buf = g["x_pk"][:5].copy()
+    sk = g["x_sk"][:5].copy()
+    lib.emul_quad_x25519(ptr(buf), ptr(buf), ptr(sk), 5)
+    assert np.array_equal(buf, g["x_shared"][:5]) and np.array_equal(sk, g["x_sk_clamped"][:5])
