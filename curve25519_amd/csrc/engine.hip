@@ -745,6 +745,39 @@ __global__ void __launch_bounds__(WALK_BLOCK, C25519_VW_WAVES) k_ed25519_verify_
     verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
 }
 
+// step 3 on QUADS (quad25519.cuh: quad::walk_is_neutral): what batches of 2^11 .. 2^15 signatures run -- the walk is two thirds of
+// a verification's chain, and four lanes per element walk it in two product levels per addition and a level of squarings and
+// one of products per doubling (~2.3 x shorter).  64 elements (four waves) per workgroup share one staged comb table; slot j of
+// the grid takes element order[j] like the one-lane walk's lane j.
+constexpr int QW_BLOCK = 256;
+__global__ void __launch_bounds__(QW_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_ed25519_verify_quad_walk(FastScratch fs, int* verdict, size_t n, const u32* __restrict__ g_tbl)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds_tbl[SC_TBL_WORDS];
+    lds_stage_words(lds_tbl, g_tbl + SC_TBL_OFFSET, SC_TBL_WORDS);
+    const size_t slot = (size_t)blockIdx.x * (QW_BLOCK / 4) + (threadIdx.x >> 2);
+#if C25519_WALK_SORTED
+    const size_t i = slot < n ? fs.order[slot] : n;
+#else
+    const size_t i = slot;
+#endif
+    const u32 f = i < n ? fs.flags[i] : FLAG_SLOW;
+    const bool walks = !(f & FLAG_SLOW);
+    int top = walks ? (int)((f >> 8) & 63u) : 0;           // the wave walks from its longest element's first digit
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int other = __shfl_xor(top, o);
+        top = other > top ? other : top;
+    }
+    top = __builtin_amdgcn_readfirstlane(top);
+    if (!walks) return;                                   // (whole quads leave)
+    const quad::Roles R = quad::roles();
+    const u32* tq = fs.tables + i * FAST_TABLE_WORDS;
+    const WalkScalars sc{ fs.sigma, fs.tau, fs.rho, n, i };
+    const u32 neutral = quad::walk_is_neutral(sc, tq, tq + WTABLE_WORDS, lds_tbl, top < 8 ? 8 : top, R);
+    if (R.is0) verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
+}
+
 // The whole lattice path of ONE element in ONE launch, for a call of a few elements: a workgroup of THREE waves per element
 // (coop::verify_three_waves, coop_ops.cuh: wave 0 hashes and reduces while wave 1 takes the two square roots; then the three
 // products of sigma*B + tau*Q + rho*(-R) = O side by side, a wave each; wave 0 adds and tests).  Three launches ran
@@ -1270,6 +1303,7 @@ struct LastVerify { const u32* count = nullptr; hipStream_t stream = nullptr; in
 thread_local LastVerify tl_last_verify;
 
 bool verify_coop_for(size_t n);
+bool verify_quad_for(size_t n);
 
 template <typename MakeFin>
 int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t stream, int* verdict, bool fast, MakeFin make_fin)
@@ -1299,7 +1333,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
             const long cap = c25519_host::tunable_or(c25519_host::T_VERIFY_LAT_CAP_BITS, LAT_CAP_BITS);
             fs.lat_cap_bits = cap >= 100 && cap < LAT_CAP_BITS ? (int)cap : LAT_CAP_BITS;
         }
-        if (verify_coop_for(n)) {                          // a few elements: one launch, three waves per element
+        if (!verify_quad_for(n) && verify_coop_for(n)) {   // a few elements: one launch, three waves per element
             C25519_TRY(hipMemsetAsync(fs.slow_count, 0, 3 * sizeof(u32), stream));
             k_ed25519_verify_one_per_group<<<(unsigned)n, 192, 0, stream>>>(fs, verdict, sig, pk, msgs, n, tbl);
             C25519_TRY(hipGetLastError());
@@ -1308,7 +1342,8 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
             C25519_TRY(hipGetLastError());
             k_ed25519_verify_fast_points<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
             C25519_TRY(hipGetLastError());
-            k_ed25519_verify_fast_walk<<<grid_for(n, WALK_BLOCK), WALK_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
+            if (verify_quad_for(n)) k_ed25519_verify_quad_walk<<<grid_for(n, QW_BLOCK / 4), QW_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
+            else k_ed25519_verify_fast_walk<<<grid_for(n, WALK_BLOCK), WALK_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
             C25519_TRY(hipGetLastError());
         }
         k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
@@ -1361,9 +1396,10 @@ bool x25519_two_waves_for(size_t n)
     return n <= max && x25519_coop_for(n);
 }
 // four lanes per element (k_x25519_quad): between the per-wave kernels and the batches that give every SIMD a wave of one-lane
-// elements.  X25519: the quad's step is 721 instructions against the lane's 1246 and a lone wave issues one every ~5.1 cycles, so
-// up to 2^14 elements (1024 quad-waves, one per SIMD) a call takes ~0.47 ms instead of 0.71; from 2^14 + 1 the second wave on a
-// SIMD doubles that.  Tunables QUAD_MIN / QUAD_MAX (tools/mid_batch_sweep.py, profiles/r06_mid_batch_sweep.txt).
+// elements.  X25519: the quad's step is 679 instructions against the lane's 1246, so up to 2^14 elements (1024 quad-waves, one per
+// SIMD) a call takes 0.39 ms instead of 0.71 (21 / 42 M/s at 2^13 / 2^14 against 11.6 / 23.1); two quad-waves per SIMD (2^15
+// elements) still beat the 512 one-lane waves, 0.63 against 0.71 ms; below ~3600 elements a wave per element is faster.
+// Tunables QUAD_MIN / QUAD_MAX (tools/mid_batch_sweep.py, profiles/r06_mid_batch_sweep.txt).
 bool quad_for(size_t n, size_t dflt_min, size_t dflt_max)
 {
     const long lo = c25519_host::tunable(c25519_host::T_QUAD_MIN), hi = c25519_host::tunable(c25519_host::T_QUAD_MAX);
@@ -1372,7 +1408,8 @@ bool quad_for(size_t n, size_t dflt_min, size_t dflt_max)
     const size_t m = std::max(n, c25519_host::batch_shape_hint());     // a piece of a pipelined *_batch call: the whole call counts
     return m > mn && m <= mx;
 }
-bool x25519_quad_for(size_t n) { return quad_for(n, 4608, (size_t)1 << 14); }
+bool x25519_quad_for(size_t n) { return quad_for(n, 3584, (size_t)1 << 15); }
+bool verify_quad_for(size_t n) { return quad_for(n, 1024, (size_t)1 << 15); }      // the walk kernel only
 bool fixed_base_coop_for(size_t n) { return coop_for(n, 2048); }
 bool verify_coop_for(size_t n) { return coop_for(n, 2048); }       // three waves per element: 0.13-0.55 against 0.60 ms (1.02 at 4096)
 

@@ -19,6 +19,7 @@
 // differs per lane is which registers a per-lane mask selects as the product's operands.
 #pragma once
 #include "lanes.cuh"
+#include "verify_fast.cuh"
 
 namespace c25519 {
 namespace quad {
@@ -34,6 +35,29 @@ C25519_DEV void fe_qperm(fe& r, const fe& a)
 {
 #pragma unroll
     for (int i = 0; i < 10; i++) r.v[i] = qperm<P0, P1, P2, P3>(a.v[i]);
+}
+
+// additions, subtractions and selects without the wave-priority dips of fe25519.cuh's (a quad-wave has its SIMD to itself:
+// there is no other wave's VOP2 run to pair up with)
+C25519_DEV void q_add(fe& r, const fe& a, const fe& b)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + b.v[i];
+}
+C25519_DEV void q_sub(fe& r, const fe& a, const fe& b)            // a - b + 2p, b reduced
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + fe_2p(i) - b.v[i];
+}
+C25519_DEV void q_neg(fe& r, const fe& a)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = fe_2p(i) - a.v[i];
+}
+C25519_DEV void q_sel(fe& r, u32 mask, const fe& a, const fe& b)  // mask ? a : b
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = (a.v[i] & mask) | (b.v[i] & ~mask);
 }
 
 // all-ones on the lane that has the role, zero elsewhere
@@ -54,33 +78,33 @@ C25519_DEV Roles roles()
 template <bool BASE9>
 C25519_DEV void ladder_step(fe& own, const fe& x1, u32 eq, const Roles& R)
 {
-    fe other, sum, diff, osum, odiff, X, Y, a, b, p;
+    fe other, sum, diff, give, keep, got, a, b, p;
     // ---- level 1
     fe_qperm<1, 0, 3, 2>(other, own);                  // the other coordinate of the lane's point
-    fe_add(sum, own, other);                           // q0, q1: Sx+Sz          q2, q3: Dx+Dz                      beta 2
-    fe_sub(diff, own, other);                          // q0: Sx-Sz  q1: -(Sx-Sz)  q2: Dx-Dz  q3: -(Dx-Dz)          beta 3
-    fe_qperm<2, 3, 0, 1>(osum, sum);                   // the other point's x+z
-    fe_qperm<2, 2, 0, 0>(odiff, diff);                 // the other point's x-z (from the lane that has it with sign +)
-    fe_select(X, R.is1 | (R.is2 & eq), sum, osum);     // q0: Dx+Dz   q1: Sx+Sz   q2: P
-    fe_select(Y, R.is0 | (R.is3 & eq), diff, odiff);   // q0: Sx-Sz   q1: Dx-Dz   q3: +-M
-    fe_select(a, R.is2, X, Y);
-    fe_select(b, R.is3, Y, X);
+    q_add(sum, own, other);                            // q0, q1: Sx+Sz          q2, q3: Dx+Dz                      beta 2
+    q_sub(diff, own, other);                           // q0: Sx-Sz  q1: -(Sx-Sz)  q2: Dx-Dz  q3: -(Dx-Dz)          beta 3
+    q_sel(give, R.is1 | R.is2, diff, sum);             // what the other pair wants of this lane: q0: Sx+Sz  q1: -(Sx-Sz)  q2: Dx-Dz  q3: Dx+Dz
+    q_sel(keep, R.is1 | R.is2, sum, diff);             // ... and the lane's own factor:        q0: Sx-Sz  q1: Sx+Sz     q2: Dx+Dz  q3: -(Dx-Dz)
+    fe_qperm<3, 2, 0, 1>(got, give);                   // q0: Dx+Dz   q1: Dx-Dz   q2: Sx+Sz   q3: -(Sx-Sz)
+    const u32 twice = (R.is2 | R.is3) & eq;            // the doubling lanes square their own point's P, M when it is doubled again
+    q_sel(a, R.is0 | twice, keep, got);                // q0: Sx-Sz   q1: Dx-Dz   q2: P   q3: +-M
+    q_sel(b, R.is1 | twice, keep, got);                // q0: Dx+Dz   q1: Sx+Sz   q2: P   q3: +-M
     fe_mul(p, a, b);
     // ---- level 2
     fe_qperm<1, 0, 3, 2>(other, p);
-    fe_add(sum, p, other);                             // q0, q1: DA+CB                                              beta 2
-    fe_sub(diff, p, other);                            // q0: DA-CB  q1: -(DA-CB)  q2: E = AA-BB  q3: -E            beta 3
-    fe_neg(X, other);                                  // q3: -AA                                                   beta 2
-    fe_mul121665_add(Y, X, diff);                      // q3: -(AA + 121665 E), reduced
-    fe_select(X, R.is0, sum, diff);
-    fe_select(a, R.is2, p, X);                         // q0: sum    q1: diff   q2: AA   q3: -E
-    fe_select(b, R.is3, Y, X);
-    fe_select(b, R.is2, other, b);                     // q0: sum    q1: diff   q2: BB   q3: -(AA + 121665 E)
+    q_add(sum, p, other);                              // q0, q1: DA+CB                                              beta 2
+    q_sub(diff, p, other);                             // q0: DA-CB  q1: -(DA-CB)  q2: E = AA-BB  q3: -E            beta 3
+    q_neg(keep, other);                                // q3: -AA                                                   beta 2
+    fe_mul121665_add(got, keep, diff);                 // q3: -(AA + 121665 E), reduced
+    q_sel(give, R.is0, sum, diff);
+    q_sel(a, R.is2, p, give);                          // q0: sum    q1: diff   q2: AA   q3: -E
+    q_sel(b, R.is3, got, give);
+    q_sel(b, R.is2, other, b);                         // q0: sum    q1: diff   q2: BB   q3: -(AA + 121665 E)
     fe_mul(p, a, b);
     // ---- level 3: z3 = x_base * (DA-CB)^2 on q1; the other lanes keep their level-2 product
     if (BASE9) fe_mul_small(a, p, 9);
     else fe_mul(a, p, x1);
-    fe_select(own, R.is1, a, p);
+    q_sel(own, R.is1, a, p);
 }
 
 // curve25519_dh_CreateSharedKey / _CalculatePublicKey (BASE9) for element e, by the quad this lane belongs to: the
@@ -152,6 +176,178 @@ C25519_DEV void x25519_element(void* out, const void* pk, void* sk, size_t e)
 }
 
 constexpr int ELEMS_PER_WAVE = 16;
+
+// =====================================================================================================================
+// Edwards points on a quad.  Lane roles between operations:   q0: X   q1: Y   q2: T   q3: Z   (extended coordinates, all reduced)
+// The reference's formulas (edp_AddPoint source/ed25519_verify.c:142-161, edp_AddAffinePoint / edp_DoublePoint
+// source/ed25519_sign.c:97-143; ge25519.cuh has them one point per lane) are two levels of four independent products each:
+//   addition   level 1: B = (Y+X) ypx   A = (Y-X) ymx   C = T t2d   D = Z z2        -- one field of the table row per lane
+//              level 2: X3 = e f   Y3 = h g   T3 = e h   Z3 = f g     (e = B-A, h = B+A, f = D-C, g = D+C)
+//   doubling   level 1: A = X^2   B = Y^2   (X+Y)^2   C = Z^2                       -- four squarings: fe_sqr, 55 MADs
+//              level 2: X3 = E Fn   Y3 = G Hn   T3 = E Hn   Z3 = G Fn  (Hn = A+B, G = B-A, E = (X+Y)^2 - Hn, Fn = 2C - G)
+// so a quad runs an addition in two product levels instead of eight products in a row, a doubling in a squaring and a product
+// instead of four and four.  Sums and differences are formed inside a pair of lanes (X with Y, T with Z: one quad_perm swap),
+// the cross terms fetched from the other pair; where a lane holds the negated difference it is not used (each product has a
+// lane that holds both its factors with the right sign, or fetches them).
+// =====================================================================================================================
+
+// own <- own + P, `mult` = the lane's field of P's precomputed row: q0: Y+X (of -P: Y-X)   q1: Y-X (Y+X)   q2: 2dT (-2dT)
+// q3: 2Z (an affine row: the constant 2).  mult: beta <= 2.
+C25519_DEV void ge_add_fields(fe& own, const fe& mult, const Roles& R)
+{
+    fe other, sum, diff, a, b, p, f1, f2;
+    fe_qperm<1, 0, 3, 2>(other, own);
+    q_add(sum, own, other);                            // q0, q1: Y+X                                                beta 2
+    q_sub(diff, own, other);                           // q1: Y-X                                                    beta 3
+    q_sel(a, R.is0, sum, own);
+    q_sel(a, R.is1, diff, a);                          // q0: Y+X   q1: Y-X   q2: T   q3: Z
+    fe_mul(p, a, mult);                                // q0: B     q1: A     q2: C   q3: D
+    fe_qperm<1, 0, 3, 2>(other, p);
+    q_add(sum, p, other);                              // q0, q1: h = B+A     q2, q3: g = D+C                        beta 2
+    q_sub(diff, p, other);                             // q0: e = B-A   q1: -e   q2: -f   q3: f = D-C                beta 3
+    fe_qperm<3, 1, 0, 3>(f1, diff);                    // q0: f     q2: e
+    fe_qperm<0, 2, 0, 3>(f2, sum);                     // q1: g     q2: h
+    q_sel(a, R.is2, f1, diff);
+    q_sel(a, R.is1, sum, a);                           // q0: e   q1: h   q2: e   q3: f
+    q_sel(b, R.is3, sum, f2);
+    q_sel(b, R.is0, f1, b);                            // q0: f   q1: g   q2: h   q3: g
+    fe_mul(own, a, b);                                 // q0: X3 = e f   q1: Y3 = h g   q2: T3 = e h   q3: Z3 = f g
+}
+
+// own <- 2 own   (T is not read)
+C25519_DEV void ge_double(fe& own, const Roles& R)
+{
+    fe other, sum, diff, a, b, p, F, u, U2, U3;
+    fe_qperm<1, 0, 3, 2>(other, own);
+    q_add(sum, own, other);                            // q0: X+Y                                                    beta 2
+    fe_qperm<0, 1, 0, 3>(F, sum);
+    q_sel(a, R.is2, F, own);                           // q0: X   q1: Y   q2: X+Y   q3: Z
+    fe_sqr(p, a);                                      // q0: A   q1: B   q2: (X+Y)^2   q3: C
+    fe_qperm<1, 0, 3, 2>(other, p);
+    q_add(sum, p, other);                              // q0, q1: Hn = A+B                                           beta 2
+    q_sub(diff, p, other);                             // q0: -G   q1: G = B-A                                       beta 3
+    q_sel(a, R.is1, diff, sum);
+    fe_qperm<0, 1, 0, 1>(F, a);                        // q2: Hn   q3: G
+    // q2: E = (X+Y)^2 - Hn   q3: Fn = 2C - G   (bias 4p: the subtrahends have beta 2 and 3), carried back to reduced -- E Fn
+    // needs one of them reduced, and both are second factors below
+#pragma unroll
+    for (int i = 0; i < 10; i++) u.v[i] = p.v[i] + (p.v[i] & R.is3) + 2u * fe_2p(i) - F.v[i];
+    fe_carry32(u, u);
+    fe_qperm<2, 1, 2, 3>(U2, u);                       // q0: E
+    fe_qperm<3, 1, 2, 3>(U3, u);                       // q0: Fn
+    q_sel(a, R.is1, diff, F);
+    q_sel(a, R.is0, U2, a);                            // q0: E    q1: G    q2: Hn   q3: G
+    q_sel(b, R.is1, sum, u);
+    q_sel(b, R.is0, U3, b);                            // q0: Fn   q1: Hn   q2: E    q3: Fn
+    fe_mul(own, a, b);                                 // q0: X3 = E Fn   q1: Y3 = G Hn   q2: T3 = Hn E   q3: Z3 = G Fn
+}
+
+// the neutral element (0 : 1 : 0 : 1)
+C25519_DEV void ge_neutral(fe& own, const Roles& R)
+{
+    fe_set_u32(own, 0);
+    own.v[0] = (R.is1 | R.is3) & 1u;
+}
+
+// ---- the lane's field of a packed table row (verify_fast.cuh: (Y+X | Y-X | 2dT | 2Z), 8 words each), fetched early, unpacked late
+struct field_raw { uint4 lo, hi; u32 neg; };
+C25519_DEV void row_field_fetch(field_raw& r, const u32* row, u32 neg)
+{
+    const u32 q = threadIdx.x & 3u;
+    const u32 fld = q < 2u ? (q ^ (neg & 1u)) : q;      // -P: Y+X and Y-X trade places
+    const uint4* p = reinterpret_cast<const uint4*>(row + 8 * fld);
+    r.lo = p[0];
+    r.hi = p[1];
+    r.neg = neg;
+}
+C25519_DEV void row_field_unpack(fe& mult, const field_raw& r, const Roles& R)
+{
+    const u32 w[8] = { r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y, r.hi.z, r.hi.w };
+    fe f, n;
+    fe_from_words(f, w);
+    q_neg(n, f);                                        // -P: 2p - 2dT, beta 2
+    q_sel(mult, R.is2 & r.neg, n, f);
+}
+
+// the lane's field of column c of the walk's signed comb (limb-major LDS table [30][SC_ROWS], ge_add_pa_comb's recoding): an
+// affine row, so q3's factor is the constant 2
+C25519_DEV void comb_field(fe& mult, const u32* tbl, u32 c, const Roles& R)
+{
+    const u32 neg = ((c >> (SC_TEETH - 1)) & 1u) - 1u;   // all-ones: negative column
+    const u32 r = (c ^ neg) & (u32)(SC_ROWS - 1);
+    const u32 q = threadIdx.x & 3u;
+    const u32 fld = q < 2u ? (q ^ (neg & 1u)) : 2u;
+    const u32* p = tbl + 10 * fld * SC_ROWS + r;
+    fe f, n, two;
+#pragma unroll
+    for (int i = 0; i < 10; i++) f.v[i] = p[i * SC_ROWS];
+    q_neg(n, f);
+    q_sel(f, R.is2 & neg, n, f);
+    fe_set_u32(two, 2);
+    q_sel(mult, R.is3, two, f);
+}
+
+// ge_walk_is_neutral (verify_fast.cuh) by a quad: W = sigma*B + tau*Q + rho*Rn from the element's two window tables, its biased
+// scalars and the LDS comb; all-ones iff W is the neutral element.  Same digits, same rows, same order of operations; the walk
+// starts from the neutral element (one more addition than the one-lane walk's "first row as the starting point").
+C25519_DEV u32 walk_is_neutral(const WalkScalars& sc, const u32* tq, const u32* tr, const u32* lds_tbl, int top, const Roles& R)
+{
+    fe own, mult;
+    ge_neutral(own, R);
+    {
+        u32 neg;
+        field_raw rq, rr;
+        const u32 mq = signed16_of(neg, sc.tau_word(top >> 3), top & 7);
+        row_field_fetch(rq, tq + mq * ROW_WORDS, neg);
+        const u32 mr = signed16_of(neg, sc.rho_word(top >> 3), top & 7);
+        row_field_fetch(rr, tr + mr * ROW_WORDS, neg);
+        row_field_unpack(mult, rq, R);
+        ge_add_fields(own, mult, R);
+        row_field_unpack(mult, rr, R);
+        ge_add_fields(own, mult, R);
+    }
+#pragma unroll 1
+    for (int i = top - 1; i >= 0; i--) {
+        const u32 tw = sc.tau_word(i >> 3), rw = sc.rho_word(i >> 3);
+        u32 neg;
+        field_raw rq, rr;                               // the round's two rows: in flight under the doublings
+        const u32 mq = signed16_of(neg, tw, i & 7);
+        row_field_fetch(rq, tq + mq * ROW_WORDS, neg);
+        const u32 mr = signed16_of(neg, rw, i & 7);
+        row_field_fetch(rr, tr + mr * ROW_WORDS, neg);
+        if (i >= SC_ROUNDS) {
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) ge_double(own, R);
+        } else {
+            u64 cols = (u64)sc.sigma_word(2 * i) | ((u64)sc.sigma_word(2 * i + 1) << 32);
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                ge_double(own, R);
+                if (4 * i + 3 - j < SC_COLS) {          // wave-uniform: the first round may carry fewer than four
+                    comb_field(mult, lds_tbl, (u32)cols & 0xffffu, R);
+                    ge_add_fields(own, mult, R);
+                }
+                cols >>= 16;
+            }
+        }
+        row_field_unpack(mult, rq, R);
+        ge_add_fields(own, mult, R);
+        row_field_unpack(mult, rr, R);
+        ge_add_fields(own, mult, R);
+    }
+    // neutral element: X == 0 and Y == Z (Z != 0 for on-curve inputs under the complete law)
+    fe X, Y, Z, d;
+    fe_qperm<0, 0, 0, 0>(X, own);
+    fe_qperm<1, 1, 1, 1>(Y, own);
+    fe_qperm<3, 3, 3, 3>(Z, own);
+    u32 xw[8], dw[8], acc = 0;
+    q_sub(d, Y, Z);
+    fe_to_words(xw, X);
+    fe_to_words(dw, d);
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc |= xw[i] | dw[i];
+    return acc == 0 ? 0xffffffffu : 0u;
+}
 
 }  // namespace quad
 }  // namespace c25519

@@ -594,6 +594,53 @@ void emul_quad_x25519(unsigned char* out, const unsigned char* pk, unsigned char
         });
 }
 
+// the lattice path with the WALK on quads (quad::walk_is_neutral): scalars, decoding and window tables by the one-lane code, as
+// k_ed25519_verify_fast_scalars / _points run them; then 16 elements per wave walk together from the wave's top digit
+// (k_ed25519_verify_quad_walk).  need_slow: the elements the walk does not decide (their verdict stays 0).
+void emul_quad_verify(int* verdict, int* need_slow, const unsigned char* sig, const unsigned char* pk, const unsigned char* msg,
+                      size_t len, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    const u32* tbl = tables() + (size_t)SC_TBL_OFFSET;
+    constexpr int G = quad::ELEMS_PER_WAVE;
+    std::vector<u32> tabs((size_t)G * 2 * WTABLE_WORDS), cols((size_t)SIGMA_WORDS * G), rho(5 * G), tau(5 * G);
+    for (size_t base = 0; base < n; base += G) {
+        const int m = (int)std::min<size_t>(G, n - base);
+        int wave_top = 0;
+        u32 r_ok[G] = {}, walks[G] = {};
+        for (int j = 0; j < m; j++) {
+            const size_t i = base + j;
+            u32 pkw[8], Rw[8], Sw[8], c[SIGMA_WORDS], rh[5], ta[5], tau_neg;
+            rd32(pkw, pk, i);
+            rd32(Rw, sig, 2 * i);
+            rd32(Sw, sig, 2 * i + 1);
+            const u32 lat_ok = ed_verify_fast_scalars(c, rh, ta, tau_neg, pkw, Rw, Sw, msg + len * i, len);
+            fe QX, QY, RX, RY;
+            const u32 q_ok = ed_verify_fast_decode(QX, QY, pkw, 0u, tau_neg);
+            r_ok[j] = ed_verify_fast_decode(RX, RY, Rw, 0xffffffffu, tau_neg);
+            need_slow[i] = (lat_ok && q_ok) ? 0 : 1;
+            verdict[i] = 0;
+            walks[j] = !need_slow[i];
+            if (!walks[j]) continue;
+            wtable_build(tabs.data() + (size_t)j * 2 * WTABLE_WORDS, QX, QY);
+            wtable_build(tabs.data() + (size_t)j * 2 * WTABLE_WORDS + WTABLE_WORDS, RX, RY);
+            for (int w = 0; w < SIGMA_WORDS; w++) cols[(size_t)w * G + j] = c[w];
+            for (int w = 0; w < 5; w++) { rho[(size_t)w * G + j] = rh[w]; tau[(size_t)w * G + j] = ta[w]; }
+            wave_top = std::max(wave_top, walk_top_digit(ta, rh));
+        }
+        if (wave_top < 8) wave_top = 8;
+        emul_coop::run_block(64, [&] {
+            const int j = (int)(threadIdx.x >> 2);
+            if (j >= m || !walks[j]) return;
+            const quad::Roles R = quad::roles();
+            const WalkScalars sc{ cols.data(), tau.data(), rho.data(), (size_t)G, (size_t)j };
+            const u32* tq = tabs.data() + (size_t)j * 2 * WTABLE_WORDS;
+            const u32 neutral = quad::walk_is_neutral(sc, tq, tq + WTABLE_WORDS, tbl, wave_top, R);
+            if (R.is0) verdict[base + j] = (r_ok[j] && neutral) ? 1 : 0;
+        });
+    }
+}
+
 void emul_coop_public_fast(unsigned char* pk, unsigned char* sk, size_t n, int wide)
 {
     std::lock_guard<std::mutex> lk(g_coop_mu);

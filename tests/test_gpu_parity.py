@@ -1543,3 +1543,38 @@ def test_x25519_on_four_lanes_per_element(api, oracle):
             assert np.array_equal(shared, e_shared) and np.array_equal(clamped, e_clamped), n
             pub, _ = api.curve25519_dh_CalculatePublicKey(sk)
             assert np.array_equal(pub, oracle.x25519_shared(np.tile(vectors.le(9, 32), (n, 1)), sk)[0]), n
+
+
+def test_verification_walk_on_four_lanes_per_element(api, oracle):
+    """k_ed25519_verify_quad_walk (quad25519.cuh): the lattice path's walk with a quad of lanes per element -- an addition in two
+    product levels (one field of the table row per lane), a doubling as a level of squarings and one of products -- what
+    batches of 2^11 .. 2^15 signatures run.  Forced (QUAD_MIN = 0) on the fixture at 1 / 15 / 16 / 17 / 63 / 64 / 65 / 1000
+    signatures (a lone quad, wave and workgroup edges) with its rejected entries, on the degenerate vectors (small-order keys and
+    R, S >= L, off-curve keys on the slow list: the reference's verdicts), with garbage keys; at its own sizes by default (5000,
+    2^14 with corrupted entries) against the oracle and against the one-lane walk (QUAD_MAX = 0)."""
+    from curve25519_amd import _lib
+    L = _lib.load()
+    g = R1024
+    with _lib.tunable("QUAD_MIN", 0), _lib.tunable("QUAD_MAX", 1 << 20):
+        for n in (1, 15, 16, 17, 63, 64, 65, 1000):
+            assert np.array_equal(api.ed25519_VerifySignature(g["v_sig"][:n], g["ed_pub"][:n], g["v_msg"][:n]), g["v_ok"][:n]), n
+        d = np.load(os.path.join(GOLD, "degenerate_verify.npz"))
+        sig, pk, msg, exp = (np.ascontiguousarray(d[k]) for k in ("sig", "pk", "msg", "verdict"))
+        assert np.array_equal(api.ed25519_VerifySignature(sig, pk, msg), exp)
+        assert L.c25519_amd_verify_last_slow_elements() >= 0               # the lattice path ran
+        n = 700
+        mixed = g["ed_pub"][:n].copy()
+        mixed[::5] = synth.random_bytes((n, 32), 0x5109)[::5]              # garbage keys: half of them off the curve
+        assert np.array_equal(api.ed25519_VerifySignature(g["v_sig"][:n], mixed, g["v_msg"][:n]),
+                              oracle.ed25519_verify(g["v_sig"][:n], mixed, g["v_msg"][:n]))
+        assert L.c25519_amd_verify_last_slow_elements() > 20               # off-curve keys went to the reference-order kernel
+    for n in (5000, 1 << 14):
+        sk, msg = synth.random_bytes((n, 32), 0x6b1 + n), synth.random_bytes((n, 33), 0x6b2 + n)
+        pub, priv = api.ed25519_CreateKeyPair(sk)
+        bsig, bmsg, bad = synth.corrupt_for_verify(api.ed25519_SignMessage(priv, msg), msg)
+        ok = api.ed25519_VerifySignature(bsig, pub, bmsg)
+        with _lib.tunable("QUAD_MAX", 0):
+            lane = api.ed25519_VerifySignature(bsig, pub, bmsg)
+        assert np.array_equal(ok, lane) and np.array_equal(ok == 0, bad), n
+        if n == 5000:
+            assert np.array_equal(ok, oracle.ed25519_verify(bsig, pub, bmsg))

@@ -33,7 +33,8 @@ def lib():
     lib = C.CDLL(emul_build.build())
     lib.emul_mad_overflow_count.restype = C.c_ulonglong
     lib.emul_coop_sync_points.restype = C.c_ulonglong
-    for name, args in {"emul_quad_x25519": [vp, vp, vp, sz]}.items():
+    for name, args in {"emul_quad_x25519": [vp, vp, vp, sz], "emul_quad_verify": [vp, vp, vp, vp, vp, sz, sz],
+                       "emul_ed25519_verify_fast": [vp, vp, vp, vp, vp, sz, sz]}.items():
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = None
     yield lib
@@ -75,3 +76,47 @@ def test_x25519_on_quads_in_place(lib):
     sk = g["x_sk"][:5].copy()
     lib.emul_quad_x25519(ptr(buf), ptr(buf), ptr(sk), 5)
     assert np.array_equal(buf, g["x_shared"][:5]) and np.array_equal(sk, g["x_sk_clamped"][:5])
+
+
+def quad_verify(lib, sig, pk, msg):
+    sig, pk = np.ascontiguousarray(sig, dtype=np.uint8).reshape(-1, 64), np.ascontiguousarray(pk, dtype=np.uint8).reshape(-1, 32)
+    n = sig.shape[0]
+    msg = np.ascontiguousarray(msg, dtype=np.uint8).reshape(n, -1)
+    ok, slow = np.full(n, -1, np.int32), np.zeros(n, np.int32)
+    lib.emul_quad_verify(ptr(ok), ptr(slow), ptr(sig), ptr(pk), ptr(msg) if msg.shape[1] else None, msg.shape[1], n)
+    return ok, slow
+
+
+def test_verification_walk_on_quads_gives_the_reference_verdicts(lib):
+    """The lattice path's walk by quads (quad::walk_is_neutral: additions in two product levels with one field of the table row
+    per lane, doublings as a level of squarings and a level of products): RFC 8032 and the reference's own vectors, a window of
+    the 1024-row fixture with rejected entries in it (16 elements per wave walk together from the wave's top digit), and the
+    one-lane walk's verdicts and slow-list decisions element for element."""
+    for r in KAT["ed25519"]:
+        msg = np.frombuffer(bytes.fromhex(r["msg"]), np.uint8).reshape(1, -1)
+        ok, slow = quad_verify(lib, h2a(r["sig"]), h2a(r["pk"]), msg)
+        assert ok[0] == 1 and slow[0] == 0, r["name"]
+        if msg.shape[1]:
+            bad = msg.copy(); bad[0, 0] ^= 1
+            assert quad_verify(lib, h2a(r["sig"]), h2a(r["pk"]), bad)[0][0] == 0, r["name"]
+    g, m = R1024, 37
+    lo = int(np.nonzero(g["v_ok"] == 0)[0][0]) - 5                     # a window with rejected entries in it
+    ok, slow = quad_verify(lib, g["v_sig"][lo:lo + m], g["ed_pub"][lo:lo + m], g["v_msg"][lo:lo + m])
+    assert np.array_equal(ok, g["v_ok"][lo:lo + m]) and not slow.any() and (ok == 0).any()
+
+
+def test_degenerate_vectors_through_the_quad_walk(lib):
+    """tests/golden/degenerate_verify.npz (small-order and mixed-order keys, small-order R in every encoding, S in {0, L, 2L, 15L},
+    off-curve keys; verdicts = the real reference's): a sample of every label.  The quad walk starts from the neutral element and
+    adds neutral rows for zero digits -- exactly the inputs where a formula that is not complete would show."""
+    d = np.load(os.path.join(GOLD, "degenerate_verify.npz"))
+    pick = np.arange(0, 1024, 13)
+    sig, pk, msg, exp = (np.ascontiguousarray(d[k][pick]) for k in ("sig", "pk", "msg", "verdict"))
+    n = len(pick)
+    ok, slow = quad_verify(lib, sig, pk, msg)
+    lane_ok, lane_slow = np.full(n, -1, np.int32), np.zeros(n, np.int32)
+    lib.emul_ed25519_verify_fast(ptr(lane_ok), ptr(lane_slow), ptr(sig), ptr(pk), ptr(msg), msg.shape[1], n)
+    assert np.array_equal(slow, lane_slow)
+    decided = slow == 0
+    assert decided.sum() >= n // 2 and np.array_equal(ok[decided], exp[decided]) and np.array_equal(ok[decided], lane_ok[decided])
+    assert exp[decided].sum() > 10 and (exp[decided] == 0).sum() > 0
