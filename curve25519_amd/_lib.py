@@ -28,6 +28,7 @@ SIGNATURES = {
     "ed25519_VerifySignature_dev": [_vp, _vp, _vp, _vp, _sz, _sz, _vp],
     "ed25519_VerifySignature_scratch_bytes": [_sz],
     "c25519_amd_verify_last_slow_elements": [],
+    "c25519_amd_verify_check_last_wide": [],
     "c25519_amd_host_register": [_vp, _sz],
     "c25519_amd_host_unregister": [_vp],
     "ed25519_Verify_Init_batch": [_vp, _vp, _sz],
@@ -76,6 +77,7 @@ SIGNATURES = {
 _RESTYPE = {
     "ed25519_VerifySignature_scratch_bytes": _sz,
     "c25519_amd_verify_last_slow_elements": C.c_long,
+    "c25519_amd_verify_check_last_wide": C.c_long,
     "c25519_amd_tunable_get": C.c_long,
     "c25519_amd_version": C.c_char_p,
     "c25519_amd_last_error": C.c_char_p,

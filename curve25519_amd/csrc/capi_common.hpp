@@ -89,7 +89,7 @@ enum Tunable {
     T_MULTI_VIRTUAL,            // c25519_amd_multi_create: a one-device list becomes this many virtual devices on it
     T_BASE_COMB,                // fixed-base walks: 0 = the 8-table signed comb in LDS, 1 = the wide comb read from L2 (default)
     T_HELPER_THREADS,           // cap on the staging helper threads of one process (unset: the CPUs this process may use)
-    T_VERIFY_LAT_CAP_BITS,      // TEST knob: verification's lattice walk takes short vectors up to this many bits (100..158)
+    T_VERIFY_LAT_CAP_BITS,      // TEST knob: verification's lattice walk takes short vectors up to this many bits (100..157; anything else: the production cap, 158)
     T_ONE_KEY_WIDE,             // ed25519_Verify_Check: smallest batch that builds a wide comb for its key (0: never; default 2^16)
     T_LADDER2_MAX,              // curve25519_dh_CreateSharedKey: largest call that runs the ladder on TWO waves per element (0: never)
     T_QUAD_MIN,                 // calls of MORE than QUAD_MIN and at most QUAD_MAX elements run FOUR LANES per element (quad25519.cuh):
@@ -160,7 +160,7 @@ inline std::atomic<bool>& runtime_alive()
 }
 // ... and calls that are IN FLIGHT when exit() begins (another thread is in the middle of a batch while main returns) must be
 // allowed to finish before the HIP runtime's own teardown runs -- a kernel launch into a runtime that is being torn down is a
-// segmentation fault inside libamdhip64 (tools/scratch/exit_midcall.c) --, and calls that BEGIN after that point must not reach the
+// segmentation fault inside libamdhip64 (tests/c/exit_midcall.c) --, and calls that BEGIN after that point must not reach the
 // runtime at all.  Every C entry point that touches HIP holds an ApiCall for its duration (C25519_API_CALL()): the outermost one
 // of a thread counts itself in; the atexit handler below closes the gate and waits (up to 10 s) for the count to drain; a call
 // that arrives at a closed gate parks its thread for the rest of the process' life (which is being ended by exit()).
@@ -393,6 +393,13 @@ struct ThreadState {
         C25519_TRY(hipEventRecord(keep[dev].done, s));
         return 0;
     }
+    // has a call of this thread on the current device left a kept buffer behind (a key's comb and the context it belongs to)?
+    bool has_keep() const
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
+        return keep[dev].ptr != nullptr;
+    }
     // the report word of the slab acquire_work(…, s) handed out (call between acquire_work and release_work)
     int report_word_for(unsigned** out, hipStream_t s)
     {
@@ -499,6 +506,33 @@ public:
     {
         live_ = false;
         return tls().release_work(stream_);
+    }
+
+private:
+    hipStream_t stream_ = nullptr;
+    bool live_ = false;
+};
+
+// ... and of the kept buffer (ThreadState::acquire_keep): whatever way the call leaves, the buffer's `done` event is recorded
+// behind what was enqueued on it, so that a later call on another stream waits for this call's kernels before it rewrites the
+// key's comb
+class KeepLease {
+public:
+    KeepLease() = default;
+    KeepLease(const KeepLease&) = delete;
+    KeepLease& operator=(const KeepLease&) = delete;
+    ~KeepLease() { if (live_) { (void)tls().release_keep(stream_); (void)hipGetLastError(); } }
+    int acquire(void** out, size_t bytes, hipStream_t s, bool* fresh)
+    {
+        C25519_RC(tls().acquire_keep(out, bytes, s, fresh));
+        stream_ = s; live_ = true;
+        return 0;
+    }
+    int release()
+    {
+        if (!live_) return 0;
+        live_ = false;
+        return tls().release_keep(stream_);
     }
 
 private:

@@ -903,15 +903,21 @@ k_ed25519_verify_check_coop(int* verdict, const void* sig, const u32* __restrict
 // all of the preparation (every block finds that out for itself: 2080 bytes out of L2); k_ed25519_verify_ctx_remember, behind
 // this kernel on the stream, writes the bytes down.
 constexpr int KEEP_CTX_WORDS = 2080 / 4;
+// build_if_new = 0 (one block): only ask whether the context is the remembered one -- what calls below the ONE_KEY_WIDE size do:
+// a remembered comb costs them nothing, a new one would cost more than they take.
 __global__ void __launch_bounds__(128) k_ed25519_verify_ctx_prepare(u32* wide_key /*[WB_NT][WB_ROWS][WB_ROW_WORDS]*/, u32* check_rows /*[16][32]*/,
                                                                      u32* wide_ok, const u32* __restrict__ ctx,
-                                                                     const u32* __restrict__ remembered)
+                                                                     const u32* __restrict__ remembered, int build_if_new)
 {
     {
         int same = remembered[KEEP_CTX_WORDS] != 0;
         for (int w = threadIdx.x; w < KEEP_CTX_WORDS; w += 128) same = same && remembered[w] == ctx[w];
         if (__syncthreads_and(same)) {
             if (blockIdx.x == 0 && threadIdx.x == 0) *wide_ok = remembered[KEEP_CTX_WORDS] == 2 ? 1u : 0u;
+            return;
+        }
+        if (!build_if_new) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) *wide_ok = 0u;
             return;
         }
     }
@@ -1305,6 +1311,11 @@ thread_local LastVerify tl_last_verify;
 bool verify_coop_for(size_t n);
 bool verify_quad_for(size_t n);
 
+// what the calling thread's last ed25519_Verify_Check_* call on this device left behind for c25519_amd_verify_check_last_wide:
+// where its "the two wide combs decide this batch" word lives (null: the call never asked)
+struct LastCheck { const u32* wide_ok = nullptr; hipStream_t stream = nullptr; int device = -1; unsigned long generation = 0; bool ran = false; };
+thread_local LastCheck tl_last_check;
+
 template <typename MakeFin>
 int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t stream, int* verdict, bool fast, MakeFin make_fin)
 {
@@ -1578,8 +1589,9 @@ int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void
     hipStream_t stream = (hipStream_t)stream_;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
+    const bool wide_comb = base_comb_wide();                  // every knob is read ONCE per call (another thread may turn it meanwhile)
     if (fixed_base_coop_for(n)) {                             // a few elements: one operation per wave
-        if (base_comb_wide()) {
+        if (wide_comb) {
             const u32* wide = nullptr;
             C25519_RC(wide_tables(&wide));
             k_x25519_public_fast_coop<true><<<(unsigned)n, 64, 0, stream>>>(pk, sk, n, wide);
@@ -1591,7 +1603,7 @@ int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void
     c25519_host::WorkLease lease;
     C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
-    if (base_comb_wide()) {
+    if (wide_comb) {
         const u32* wide = nullptr;
         C25519_RC(wide_tables(&wide));
         k_x25519_public_fast_mult<true><<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(scr, sk, n, wide);
@@ -1610,8 +1622,9 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
     if (n == 0) return 0;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
-    if ((!blinding || base_comb_wide()) && fixed_base_coop_for(n)) {   // a few elements: one operation per wave
-        if (base_comb_wide()) {
+    const bool wide_comb = base_comb_wide();                  // every knob is read ONCE per call (another thread may turn it meanwhile)
+    if ((!blinding || wide_comb) && fixed_base_coop_for(n)) {   // a few elements: one operation per wave
+        if (wide_comb) {
             const u32* wide = nullptr;
             C25519_RC(wide_tables(&wide));
             k_ed25519_keypair_coop<true><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, wide, (const u32*)blinding);
@@ -1623,7 +1636,7 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
     c25519_host::WorkLease lease;
     C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
-    if (base_comb_wide()) {
+    if (wide_comb) {
         const u32* wide = nullptr;
         C25519_RC(wide_tables(&wide));
         if (blinding) k_ed25519_keypair_mult<true, true><<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(scr, priv, sk, n, wide, (const u32*)blinding);
@@ -1657,8 +1670,9 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
     if (n == 0) return 0;
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
-    if ((!blinding || base_comb_wide()) && fixed_base_coop_for(n)) {   // a few elements: one operation per wave
-        if (base_comb_wide()) {
+    const bool wide_comb = base_comb_wide();                  // every knob is read ONCE per call (another thread may turn it meanwhile)
+    if ((!blinding || wide_comb) && fixed_base_coop_for(n)) {   // a few elements: one operation per wave
+        if (wide_comb) {
             const u32* wide = nullptr;
             C25519_RC(wide_tables(&wide));
             k_ed25519_sign_coop<true><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, wide, (const u32*)blinding);
@@ -1673,7 +1687,7 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
     const ProjScratch scr = carve_proj((u32*)w, n);
     u32* a_buf = (u32*)w + proj_words(n);
     u32* r_buf = a_buf + sc_words;
-    if (base_comb_wide()) {
+    if (wide_comb) {
         const u32* wide = nullptr;
         C25519_RC(wide_tables(&wide));
         if (blinding) k_ed25519_sign_mult<true, true><<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(scr, a_buf, r_buf, priv, msgs, n, wide, (const u32*)blinding);
@@ -1822,10 +1836,18 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     // a big batch under one key: both scalars over wide combs, if the context is Verify_Init's own and the key is on the
-    // curve (k_ed25519_verify_check_wide); decided on the device, the reference-order kernel behind it takes the batch otherwise
-    const bool try_wide = n >= (size_t)c25519_host::tunable_or(c25519_host::T_ONE_KEY_WIDE, 1 << 16) &&
-                          c25519_host::tunable_or(c25519_host::T_ONE_KEY_WIDE, 1) != 0;
-    if (!try_wide && coop_for(n, 1024)) {                   // a few pairs: one per wave, the reference's order
+    // curve (k_ed25519_verify_check_wide); decided on the device, the reference-order kernel behind it takes the batch otherwise.
+    // Building the key's comb (0.6 ms) pays from ONE_KEY_WIDE signatures per call (2^16); a comb that is REMEMBERED -- one
+    // Verify_Init, many Verify_Check calls, ed25519_verify.c:282-286 -- costs nothing, so every call above the per-wave kernels'
+    // range asks the device whether its context is the remembered one (one block, 2080 bytes out of L2) and walks the combs if so.
+    const long wide_from = c25519_host::tunable_or(c25519_host::T_ONE_KEY_WIDE, 1 << 16);      // (read once per call)
+    const bool small = coop_for(n, 1024);
+    const bool build = wide_from != 0 && n >= (size_t)wide_from;
+    const bool reuse = !build && wide_from != 0 && !small && tls().has_keep();
+    const bool try_wide = build || reuse;
+    tl_last_check = LastCheck();
+    tl_last_check.ran = true;
+    if (!try_wide && small) {                               // a few pairs: one per wave, the reference's order
         k_ed25519_verify_check_coop<<<(unsigned)n, 64, 0, stream>>>((int*)verdict, sig, (const u32*)ctx,
                                                                     Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl);
         C25519_TRY(hipGetLastError());
@@ -1833,26 +1855,32 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
     }
     void* w = nullptr;
     c25519_host::WorkLease lease;
-    C25519_RC(lease.acquire(&w, proj_words(n) * sizeof(u32), stream));
+    C25519_RC(lease.acquire(&w, (proj_words(n) + 4) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     u32* wide_ok = nullptr;
+    c25519_host::KeepLease keep_lease;                      // records the kept buffer's event however this call leaves
     if (try_wide) {
         const u32* wide_base = nullptr;
         C25519_RC(wide_tables(&wide_base));
-        // the key's comb, the context it was built for and the verdict on that context live in a buffer of the calling thread
-        // that outlives the call (ThreadState::keep): the next call with the same context bytes finds them there
+        // the key's comb and the context it was built for live in a buffer of the calling thread that outlives the call
+        // (ThreadState::keep): the next call with the same context bytes finds them there.  The verdict on THIS call's context
+        // (wide_ok) is the call's own: a word of its work scratch.
         void* keep = nullptr;
         bool fresh = false;
-        constexpr size_t KEEP_WORDS = WB_TBL_WORDS + 16 * 32 + KEEP_CTX_WORDS + 1 + 3 + 4;
-        C25519_RC(tls().acquire_keep(&keep, KEEP_WORDS * sizeof(u32), stream, &fresh));
+        constexpr size_t KEEP_WORDS = WB_TBL_WORDS + 16 * 32 + KEEP_CTX_WORDS + 1 + 3;
+        C25519_RC(keep_lease.acquire(&keep, KEEP_WORDS * sizeof(u32), stream, &fresh));
         u32* wide_key = (u32*)keep;
         u32* check_rows = wide_key + WB_TBL_WORDS;
         u32* remembered = check_rows + 16 * 32;
-        wide_ok = remembered + KEEP_CTX_WORDS + 1 + 3;         // (its own 16 bytes)
-        k_ed25519_verify_ctx_prepare<<<1 + WB_NT * WB_ROWS / 128, 128, 0, stream>>>(wide_key, check_rows, wide_ok, (const u32*)ctx, remembered);
+        wide_ok = (u32*)w + proj_words(n);                  // (16-byte aligned: proj_words is a multiple of 4)
+        tl_last_check.wide_ok = wide_ok; tl_last_check.stream = stream; tl_last_check.generation = tls().generation;
+        (void)hipGetDevice(&tl_last_check.device);
+        k_ed25519_verify_ctx_prepare<<<build ? 1 + WB_NT * WB_ROWS / 128 : 1, 128, 0, stream>>>(wide_key, check_rows, wide_ok, (const u32*)ctx, remembered, build ? 1 : 0);
         C25519_TRY(hipGetLastError());
-        k_ed25519_verify_ctx_remember<<<1, 128, 0, stream>>>(remembered, (const u32*)ctx, wide_ok);
-        C25519_TRY(hipGetLastError());
+        if (build) {
+            k_ed25519_verify_ctx_remember<<<1, 128, 0, stream>>>(remembered, (const u32*)ctx, wide_ok);
+            C25519_TRY(hipGetLastError());
+        }
         k_ed25519_verify_check_wide<<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(
             scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, wide_base, wide_key, wide_ok);
         C25519_TRY(hipGetLastError());
@@ -1861,8 +1889,26 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
         scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl, wide_ok);
     C25519_TRY(hipGetLastError());
     C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
-    if (try_wide) C25519_RC(tls().release_keep(stream));     // (the shared kernel reads wide_ok out of the kept buffer too)
+    C25519_RC(keep_lease.release());
     return lease.release();
+}
+
+// test / accounting hook: did the calling thread's last ed25519_Verify_Check_* call on this device walk the two wide combs (1), or
+// did the reference-order kernel decide it (0: the call did not ask -- too small, no remembered comb, ONE_KEY_WIDE = 0 -- or the
+// device said no: another context than the remembered one, a context that is not Verify_Init's, an off-curve key)?  -1: no such
+// call to report.  Synchronises with that call's stream.  (A *_batch call of several pieces reports its last piece.)
+long c25519_amd_verify_check_last_wide(void)
+{
+    C25519_API_CALL_OR(-1);
+    const LastCheck& lc = tl_last_check;
+    if (!lc.ran) return -1;
+    if (!lc.wide_ok) return 0;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != lc.device || lc.generation != tls().generation) return -1;
+    if (hipStreamSynchronize(lc.stream) != hipSuccess) return -1;
+    u32 v = 0;
+    if (hipMemcpy(&v, lc.wide_ok, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v ? 1 : 0;
 }
 
 // ---- unit-test hooks (host pointers) ---------------------------------------------------------------

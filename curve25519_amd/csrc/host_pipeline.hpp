@@ -99,10 +99,13 @@ private:
 class SharedCopyPool {
 public:
     struct Range { void* dst; const void* src; size_t bytes; };
+    // never destroyed: exit() runs static destructors while *_multi calls of other threads may still be copying through the pool
+    // (the API gate's exit handler waits for them AFTER this object's destructor would have run); the threads are detached
+    // and end with the process
     static SharedCopyPool& instance()
     {
-        static SharedCopyPool pool;
-        return pool;
+        static SharedCopyPool* const pool = new SharedCopyPool();
+        return *pool;
     }
     int size() const { return (int)th_.size(); }
     void copy(const Range* r, int count)
@@ -137,16 +140,11 @@ private:
         long n = tunable_or(T_HELPER_THREADS, usable_cpus()) - 4;
         n = n < 2 ? 2 : n > 12 ? 12 : n;
         try {
-            for (long i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
+            for (long i = 0; i < n; i++) { th_.emplace_back([this] { loop(); }); th_.back().detach(); }
         } catch (const std::system_error&) {              // fewer threads than asked for: still a pool; none: copy() copies inline
         }
     }
-    ~SharedCopyPool()
-    {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
-        cv_.notify_all();
-        for (auto& t : th_) if (t.joinable()) t.join();
-    }
+    ~SharedCopyPool() = delete;
     void loop()
     {
         for (;;) {
@@ -218,7 +216,7 @@ inline HelperPlan pipeline_helpers(int concurrent, int reserved = 0)
     if (concurrent > 1) return HelperPlan{ 0, 0, true };   // one orchestrating helper per pipeline; the copies go to SharedCopyPool
     const long budget = tunable_or(T_HELPER_THREADS, usable_cpus());
     const long share = (budget - reserved) / (concurrent < 1 ? 1 : concurrent);
-    HelperPlan p = share >= (concurrent > 1 ? 6 : 16) ? HelperPlan{ 4, 2, false }
+    HelperPlan p = share >= 16 ? HelperPlan{ 4, 2, false }
                  : share >= 3 ? HelperPlan{ 2, 1, false } : share >= 2 ? HelperPlan{ 1, 1, false } : HelperPlan{ 0, 0, true };
     if (!p.combined) {
         p.stagers = env_count("C25519_AMD_STAGERS", p.stagers, MAX_STAGERS);
@@ -283,6 +281,8 @@ inline size_t piece_rows(size_t n, size_t row)
 // more than the few hundred bytes cost over PCIe.  The *_dev entry points, which refuse host pointers from callers, accept them
 // while this flag is up (engine.hip: check_dev_args).
 constexpr size_t ZERO_COPY_MAX_ROWS = 64;
+constexpr size_t ZERO_COPY_MAX_BYTES = 16384;             // ... of all arrays together: a message of KiB .. MiB is hashed byte by byte
+                                                          // (sha512.cuh), twice when signing -- over PCIe that is a DMA upload's job
 inline bool& zero_copy_call() { thread_local bool on = false; return on; }
 
 // What the multi-GPU layer hangs on a device's pipeline: the piece size (so that every device cuts its shard at the same
@@ -322,7 +322,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
             any_dev = true;
         }
     static const bool zero_copy_on = [] { const char* e = getenv("C25519_AMD_ZERO_COPY"); return !(e && atoi(e) == 0); }();
-    const bool zero_copy = zero_copy_on && n <= ZERO_COPY_MAX_ROWS && nchunks == 1 && !any_dev;
+    const bool zero_copy = zero_copy_on && n <= ZERO_COPY_MAX_ROWS && row * n <= ZERO_COPY_MAX_BYTES && nchunks == 1 && !any_dev;
     for (int l = 0; l < sets; l++)
         for (int a = 0; a < na; a++) {
             if (!arr[a].dev && !zero_copy) C25519_RC(t.reserve_dev(l, a, arr[a].elem * chunk));

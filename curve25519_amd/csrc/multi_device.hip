@@ -475,9 +475,12 @@ int c25519_amd_multi_create(c25519_amd_multi** out, const int* devices, int n_de
     const long v = c25519_host::tunable_or(c25519_host::T_MULTI_VIRTUAL, 0);
     if (n_dev == 1 && v > 1) list.assign((size_t)(v > MAX_DEVICES ? MAX_DEVICES : v), devices[0]);
     n_dev = (int)list.size();
-    bool dup = false;
+    bool dup = false, distinct = false;
     for (int d = 0; d < n_dev; d++)
-        for (int e = 0; e < d; e++) dup = dup || list[d] == list[e];
+        for (int e = 0; e < d; e++) { dup = dup || list[d] == list[e]; distinct = distinct || list[d] != list[e]; }
+    // ONE device named D times is D virtual devices on it (device-to-device copies in RCCL's place); a list that repeats some
+    // devices and not others ([0, 0, 1]) is neither that nor a set of real devices RCCL would accept
+    if (dup && distinct) return bad_arg("c25519_amd_multi_create: a device list either names distinct devices or ONE device several times");
     c25519_amd_multi* m = new c25519_amd_multi();
     int prev = 0;
     (void)hipGetDevice(&prev);

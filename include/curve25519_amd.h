@@ -42,9 +42,12 @@ int  c25519_amd_set_device(int device);                /* device used by this ho
  * one-device list given to c25519_amd_multi_create becomes V virtual devices on it), BASE_COMB (fixed-base walks: 0 = the 8 x 32 comb staged in LDS,
  * 1 = the wide 13 x 20 comb read through L2, the default), HELPER_THREADS (cap on the staging helper threads; default: the CPUs this process may use),
  * VERIFY_LAT_CAP_BITS (test knob, 100..157: verification's lattice walk refuses longer short vectors, which then take the
- * reference-order kernel), ONE_KEY_WIDE (ed25519_Verify_Check_*: the smallest batch that builds a wide comb for its one key,
- * default 65536; 0 = never), LADDER2_MAX (curve25519_dh_CreateSharedKey_*: the largest call that runs the ladder on two waves per
- * element, default 512; 0 = never).
+ * reference-order kernel), ONE_KEY_WIDE (ed25519_Verify_Check_*: the smallest batch that BUILDS a wide comb for its one key,
+ * default 65536; a call of more than 1024 pairs whose context is the one the calling thread's last such batch built a comb for
+ * walks that comb whatever its size; 0 = never), LADDER2_MAX (curve25519_dh_CreateSharedKey_*: the largest call that runs the
+ * ladder on two waves per element, default 512; 0 = never), QUAD_MIN / QUAD_MAX (calls of more than QUAD_MIN and at most QUAD_MAX
+ * elements run FOUR LANES per element -- X25519: the whole operation, defaults 3584 / 32768; ed25519_VerifySignature_*: the walk,
+ * defaults 1024 / 32768; QUAD_MAX = 0: never).
  * _get returns -1 for "built-in choice", -2 for an unknown name. */
 int  c25519_amd_tunable_set(const char *name, long value);
 long c25519_amd_tunable_get(const char *name);
@@ -144,6 +147,9 @@ int ed25519_VerifySignature_ragged_dev(void *verdict, const void *sig, const voi
  * there is nothing to report (a *_batch call that was cut into pieces reports one of its pieces).  Synchronises with
  * that call's stream. */
 long c25519_amd_verify_last_slow_elements(void);
+/* did the calling thread's last ed25519_Verify_Check_* call on this device walk the two wide combs (1) or did the reference-order
+ * kernel decide it (0)?  -1: no such call.  Synchronises with that call's stream. */
+long c25519_amd_verify_check_last_wide(void);
 
 /* bytes of device scratch ed25519_VerifySignature_dev needs for n elements (per-lane 4-fold tables);
  * the library allocates and caches it per host thread (about 2.8 KB per element). */

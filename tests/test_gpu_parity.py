@@ -1578,3 +1578,69 @@ def test_verification_walk_on_four_lanes_per_element(api, oracle):
         assert np.array_equal(ok, lane) and np.array_equal(ok == 0, bad), n
         if n == 5000:
             assert np.array_equal(ok, oracle.ed25519_verify(bsig, pub, bmsg))
+
+
+def test_a_remembered_key_comb_serves_batches_of_any_size(api, oracle):
+    """One ed25519_Verify_Init, many ed25519_Verify_Check calls (ed25519_verify.c:282-286): the comb a batch of >= 2^16 pairs builds
+    for its key stays with the calling thread, and every later call of more than 1024 pairs whose context is that one walks the
+    two wide combs again -- at 2^12 and 2^14 pairs, where building a comb (0.6 ms) would not pay -- while another key's context,
+    a tampered copy and a call before any comb exists keep the reference-order kernel.  c25519_amd_verify_check_last_wide says
+    which path decided; the verdicts are the oracle's either way."""
+    from curve25519_amd import _lib
+    L = _lib.load()
+    big = 1 << 16
+    sk = synth.random_bytes((2, 32), 0x7b03)
+    pub, priv = oracle.ed25519_keypair(sk)
+    ctx = api.ed25519_Verify_Init(pub)
+    msg = synth.random_bytes((big, 19), 0x7b04)
+    sig = [oracle.ed25519_sign(np.repeat(priv[k:k + 1], big, axis=0), msg, threads=THREADS) for k in range(2)]
+    for s in sig:
+        s[5::11, 40] ^= 4                                              # rejected entries in every batch
+    want = [oracle.ed25519_verify(sig[k], np.repeat(pub[k:k + 1], big, axis=0), msg, threads=THREADS) for k in range(2)]
+    assert 0 < want[0].sum() < big
+
+    def check(k, n, expect_wide, cx=None):
+        got = api.ed25519_Verify_Check(ctx[k] if cx is None else cx, sig[k][:n], msg[:n])
+        path = L.c25519_amd_verify_check_last_wide()
+        assert path == expect_wide, (k, n, path)
+        return got
+
+    L.c25519_amd_thread_release()                                      # this thread remembers nothing
+    assert np.array_equal(check(0, 1 << 12, 0), want[0][:1 << 12])      # no comb yet: reference order
+    assert np.array_equal(check(0, big, 1), want[0])                    # builds and remembers key 0's comb
+    for n in (1 << 12, 1 << 14, 5000, 1025):
+        assert np.array_equal(check(0, n, 1), want[0][:n]), n           # the remembered comb, at any size
+        assert np.array_equal(check(1, n, 0), want[1][:n]), n           # another key: not worth a comb at this size
+        assert np.array_equal(check(0, n, 1), want[0][:n]), n           # ... and key 0's comb is still the remembered one
+    tampered = ctx[0].copy()
+    tampered[32 + 128 * 3 + 9] ^= 0x10
+    bent = check(0, 1 << 12, 0, cx=tampered)                            # not the remembered bytes: the rows are read as they are
+    with _lib.tunable("ONE_KEY_WIDE", 0):
+        assert np.array_equal(bent, api.ed25519_Verify_Check(tampered, sig[0][:1 << 12], msg[:1 << 12]))
+        assert np.array_equal(check(0, 1 << 14, 0), want[0][:1 << 14])  # the knob turns the comb path off altogether
+    assert np.array_equal(check(0, 1000, 0), want[0][:1000])            # per-wave kernels' range
+    assert np.array_equal(check(1, big, 1), want[1])                    # key 1 takes the buffer over ...
+    assert np.array_equal(check(0, 1 << 12, 0), want[0][:1 << 12])      # ... and key 0 is no longer remembered
+    assert np.array_equal(check(1, 1 << 12, 1), want[1][:1 << 12])
+
+
+def test_single_calls_with_large_messages_are_uploaded_not_read_over_pcie(api, oracle):
+    """A call of a few elements reads its operands straight out of pinned host memory (no copy commands) -- but only while they
+    are small: a message of KiB .. MiB is hashed byte by byte (twice when signing), which over PCIe would be millions of uncached
+    reads; such a call is staged like any batch.  Bytes and verdicts for both sides of the 16 KiB gate, and the big
+    call must not be absurdly slower than the small one."""
+    import time
+    sk = synth.random_bytes((1, 32), 0x7c01)
+    pub, priv = api.ed25519_CreateKeyPair(sk)
+    took = {}
+    for mlen in (100, 16000, 17000, 1 << 20):
+        msg = synth.random_bytes((1, mlen), 0x7c02 + mlen)
+        api.ed25519_SignMessage(priv, msg)
+        t0 = time.perf_counter()
+        sig = api.ed25519_SignMessage(priv, msg)
+        took[mlen] = time.perf_counter() - t0
+        assert np.array_equal(sig, oracle.ed25519_sign(priv, msg)), mlen
+        assert api.ed25519_VerifySignature(sig, pub, msg)[0] == 1
+        msg[0, mlen // 2] ^= 1
+        assert api.ed25519_VerifySignature(sig, pub, msg)[0] == 0
+    assert took[1 << 20] < 2.0, took                                    # a lone lane hashes 1 MiB twice: tens of ms, not minutes

@@ -7,6 +7,7 @@
 // The long-trip accumulating-MAD figure is the denominator of bench.py's roofline.valu (JSON: argv[1]).
 // Build: hipcc --offload-arch=gfx950 -O3 mad_peak.hip -o mad_peak
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <cstdio>
 #include <cstdlib>
 
@@ -310,6 +311,38 @@ int main(int argc, char** argv)
     g_cyc_host = (unsigned long long*)malloc(sizeof(unsigned long long) * MAX_WAVES);
     hipStream_t s; CHECK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    if (argc > 1 && !strcmp(argv[1], "--quick")) {
+        // bench.py's same-box, same-run roof: ONE configuration -- the accumulating v_mad_u64_u32 stream, 128 per trip, 8 waves per
+        // SIMD launched: roofline.valu's peak row -- behind ~60 ms of the same launches (the chip's clock ramp); one JSON line on stdout
+        const Row* r = nullptr;
+        for (const Row& q : rows) if (!strcmp(q.key, "v_mad_u64_u32")) r = &q;
+        if (!r) { fprintf(stderr, "mad_peak --quick: no such row\n"); return 1; }
+        const int trips = 65536 / r->per_trip, blocks = cus * 8;
+        float best = 1e30f, total = 0;
+        for (int rep = 0; rep < 400 && (rep < 8 || total < 60.0f); rep++) {          // the ramp: untimed in effect (best-of below)
+            CHECK(hipEventRecord(e0, s));
+            dispatch(r->id, blocks, d, trips, s);
+            CHECK(hipEventRecord(e1, s));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            total += ms;
+        }
+        float sum = 0;
+        const int reps = 10;
+        for (int rep = 0; rep < reps; rep++) {
+            CHECK(hipEventRecord(e0, s));
+            dispatch(r->id, blocks, d, trips, s);
+            CHECK(hipEventRecord(e1, s));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            sum += ms;
+            if (ms < best) best = ms;
+        }
+        const double per = r->scale * (double)blocks * 4 * (double)trips * r->per_trip * 64;
+        printf("{\"v_mad_u64_u32\": %.4e, \"v_mad_u64_u32_mean_of_%d\": %.4e, \"ms_best\": %.4f, \"device_cus\": %d, \"waves_per_simd\": 8, "
+               "\"unit\": \"lane-op/s\", \"row\": \"%s\"}\n", per / (best * 1e-3), reps, per / (sum / reps * 1e-3), best, cus, r->name);
+        return 0;
+    }
     FILE* jf = argc > 1 ? fopen(argv[1], "w") : nullptr;
     if (jf) fprintf(jf, "{\"device_cus\": %d, \"waves_per_simd\": 8, \"unit\": \"lane-op/s\", \"rates\": {\n", cus);
     // argv[2]: SIMD cycles per wave-instruction of every row (s_memtime inside the kernels), the issue model's class costs
