@@ -362,7 +362,8 @@ __global__ void __launch_bounds__(128) k_gen_wide_table(u32* wide /*[WB_NT][WB_R
         out[2 * f] = make_uint4(rows[f][0], rows[f][1], rows[f][2], rows[f][3]);
         out[2 * f + 1] = make_uint4(rows[f][4], rows[f][5], rows[f][6], rows[f][7]);
     }
-    out[6] = out[7] = make_uint4(0, 0, 0, 0);
+    out[6] = make_uint4(2, 0, 0, 0);                          // the row's fourth field: 2Z of an affine point (quad25519.cuh reads a row
+    out[7] = make_uint4(0, 0, 0, 0);                          // as the four factors of an addition, one per lane)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -553,6 +554,37 @@ k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32*
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
     if (blockIdx.x >= n) return;
     coop::sign_one<WIDE>(lds, coop::make_lane(threadIdx.x), sig, priv, msgs, blockIdx.x, g_tbl, blind_ctx);
+}
+
+// The same three operations on FOUR lanes per element (quad25519.cuh), for calls between the per-wave kernels and the batches
+// that fill the chip: 16 elements per one-wave workgroup, the walk over the wide comb in two product levels per addition,
+// inversion, encoding and the last hash in the same launch (the one-lane path's three launches are 80 + 56 + 15 us for 2^12 ..
+// 2^14 signatures whatever their number; this is one chain of ~110 us).  LDS: the lanes' parked column numbers.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_ed25519_keypair_quad(void* pub, void* priv, const void* sk, size_t n, const u32* __restrict__ g_wide)
+{
+    __shared__ unsigned short cols[WB_COLS * 64];
+    const size_t e = (size_t)blockIdx.x * quad::ELEMS_PER_WAVE + (threadIdx.x >> 2);
+    if (e >= n) return;                                       // (whole quads leave)
+    quad::keypair_element(pub, priv, sk, e, g_wide, cols + threadIdx.x, 64);
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_x25519_public_fast_quad(void* pk, void* sk, size_t n, const u32* __restrict__ g_wide)
+{
+    __shared__ unsigned short cols[WB_COLS * 64];
+    const size_t e = (size_t)blockIdx.x * quad::ELEMS_PER_WAVE + (threadIdx.x >> 2);
+    if (e >= n) return;
+    quad::public_fast_element(pk, sk, e, g_wide, cols + threadIdx.x, 64);
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_ed25519_sign_quad(void* sig, const void* priv, Msgs msgs, size_t n, const u32* __restrict__ g_wide)
+{
+    __shared__ unsigned short cols[WB_COLS * 64];
+    const size_t e = (size_t)blockIdx.x * quad::ELEMS_PER_WAVE + (threadIdx.x >> 2);
+    if (e >= n) return;
+    quad::sign_element(sig, priv, msgs.ptr(e), msgs.len(e), e, g_wide, cols + threadIdx.x, 64);
 }
 
 // ed25519_Blinding_Init (ed25519_sign.c:289-331) for one context: digest = SHA-512(domain || seed),
@@ -964,7 +996,8 @@ __global__ void __launch_bounds__(128) k_ed25519_verify_ctx_prepare(u32* wide_ke
         out[2 * f] = make_uint4(rows[f][0], rows[f][1], rows[f][2], rows[f][3]);
         out[2 * f + 1] = make_uint4(rows[f][4], rows[f][5], rows[f][6], rows[f][7]);
     }
-    out[6] = out[7] = make_uint4(0, 0, 0, 0);
+    out[6] = make_uint4(2, 0, 0, 0);                          // 2Z, as in k_gen_wide_table
+    out[7] = make_uint4(0, 0, 0, 0);
 }
 
 __global__ void __launch_bounds__(128) k_ed25519_verify_ctx_remember(u32* remembered, const u32* __restrict__ ctx, const u32* __restrict__ wide_ok)
@@ -1421,6 +1454,10 @@ bool quad_for(size_t n, size_t dflt_min, size_t dflt_max)
 }
 bool x25519_quad_for(size_t n) { return quad_for(n, 3584, (size_t)1 << 15); }
 bool verify_quad_for(size_t n) { return quad_for(n, 1024, (size_t)1 << 15); }      // the walk kernel only
+// the fixed-base operations on quads (k_ed25519_*_quad; over the wide comb, without a blinding context): one chain of ~110 us up to
+// 2^14 elements (one quad-wave per SIMD) against 115 us for 1024 per-wave operations and the one-lane path's 127-156 us of three
+// launches (profiles/r06_mid_batch_sweep.txt)
+bool fixed_base_quad_for(size_t n) { return quad_for(n, 1024, (size_t)1 << 14); }
 bool fixed_base_coop_for(size_t n) { return coop_for(n, 2048); }
 bool verify_coop_for(size_t n) { return coop_for(n, 2048); }       // three waves per element: 0.13-0.55 against 0.60 ms (1.02 at 4096)
 
@@ -1590,6 +1627,13 @@ int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     const bool wide_comb = base_comb_wide();                  // every knob is read ONCE per call (another thread may turn it meanwhile)
+    if (wide_comb && fixed_base_quad_for(n)) {                // four lanes per element
+        const u32* wide = nullptr;
+        C25519_RC(wide_tables(&wide));
+        k_x25519_public_fast_quad<<<grid_for(n, quad::ELEMS_PER_WAVE), 64, 0, stream>>>(pk, sk, n, wide);
+        C25519_TRY(hipGetLastError());
+        return 0;
+    }
     if (fixed_base_coop_for(n)) {                             // a few elements: one operation per wave
         if (wide_comb) {
             const u32* wide = nullptr;
@@ -1623,6 +1667,13 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     const bool wide_comb = base_comb_wide();                  // every knob is read ONCE per call (another thread may turn it meanwhile)
+    if (!blinding && wide_comb && fixed_base_quad_for(n)) {   // four lanes per element
+        const u32* wide = nullptr;
+        C25519_RC(wide_tables(&wide));
+        k_ed25519_keypair_quad<<<grid_for(n, quad::ELEMS_PER_WAVE), 64, 0, stream>>>(pub, priv, sk, n, wide);
+        C25519_TRY(hipGetLastError());
+        return 0;
+    }
     if ((!blinding || wide_comb) && fixed_base_coop_for(n)) {   // a few elements: one operation per wave
         if (wide_comb) {
             const u32* wide = nullptr;
@@ -1671,6 +1722,13 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
     const u32* tbl = nullptr;
     C25519_RC(base_tables(&tbl, nullptr));
     const bool wide_comb = base_comb_wide();                  // every knob is read ONCE per call (another thread may turn it meanwhile)
+    if (!blinding && wide_comb && fixed_base_quad_for(n)) {   // four lanes per element
+        const u32* wide = nullptr;
+        C25519_RC(wide_tables(&wide));
+        k_ed25519_sign_quad<<<grid_for(n, quad::ELEMS_PER_WAVE), 64, 0, stream>>>(sig, priv, msgs, n, wide);
+        C25519_TRY(hipGetLastError());
+        return 0;
+    }
     if ((!blinding || wide_comb) && fixed_base_coop_for(n)) {   // a few elements: one operation per wave
         if (wide_comb) {
             const u32* wide = nullptr;

@@ -349,5 +349,128 @@ C25519_DEV u32 walk_is_neutral(const WalkScalars& sc, const u32* tq, const u32* 
     return acc == 0 ? 0xffffffffu : 0u;
 }
 
+
+// =====================================================================================================================
+// Fixed-base multiples k * B over the WIDE comb (ge25519.cuh: ge_base_mult_wide -- 13 signed teeth, four tables of 4096 packed
+// 128-byte rows read through L2) by a quad: what ed25519_CreateKeyPair / ed25519_SignMessage / curve25519_dh_CalculatePublicKey_fast
+// calls of 2^11 .. 2^14 elements run (engine.hip: k_ed25519_*_quad).  One lane per element walks 19 additions of seven products and
+// four doublings of eight, one after the other (~22 000 instructions), then waits for two more launches (the shared inversion,
+// the last hash); a quad walks 20 additions of TWO product levels and the doublings as a level of squarings and one of products
+// (~8 500), and carries on in the same launch: inversion, encoding, h and S = h a + r by all four lanes on the same values
+// (hashing has no four-way structure; the chip has the SIMDs to spare at these sizes).  A row of the comb is the precomputed
+// form of an affine point: (Y+X | Y-X | 2dT | 2) -- the fourth field, the constant 2 = 2Z, is the row's padding, so lane q's
+// factor is word group q of the line whatever the point (row_field_fetch).  The walk starts from the neutral element (one
+// addition more than ge_base_mult_wide's "first row as the starting point": the formulas are complete).
+// =====================================================================================================================
+
+// the lane's field of the row column c (13 bits: tooth 12 is the sign) selects in `tbl`
+C25519_DEV void wide_field_fetch(field_raw& r, const u32* __restrict__ tbl, u32 c)
+{
+    const u32 neg = ((c >> (WB_TEETH - 1)) & 1u) - 1u;          // all-ones: negative column
+    const u32 row = (c ^ neg) & (u32)(WB_ROWS - 1);
+    row_field_fetch(r, tbl + (size_t)row * WB_ROW_WORDS, neg);
+}
+
+// own <- k * B.  cols: this lane's parked columns of k (wb_columns; every lane of the quad parks the same twenty), `stride`
+// elements apart, in the order the walk consumes them: s = m * WB_NT + t selects a row of table t; a doubling in front of every
+// m > 0.  The next row is fetched under the current addition (~1 600 cycles against ~700 of L2 latency).
+C25519_DEV void base_mult_wide(fe& own, const u32* __restrict__ g_wide, const unsigned short* cols, int stride, const Roles& R)
+{
+    static_assert(ROW_WORDS == WB_ROW_WORDS, "one row shape for the window tables and the wide comb");
+    fe mult;
+    field_raw cur, nxt;
+    ge_neutral(own, R);
+    wide_field_fetch(cur, g_wide, cols[0]);
+    nxt = cur;
+#pragma unroll 1
+    for (int s = 0; s < WB_COLS; s++) {
+        const int t = s & (WB_NT - 1);
+        if (s + 1 < WB_COLS)
+            wide_field_fetch(nxt, g_wide + (size_t)((s + 1) & (WB_NT - 1)) * WB_ROWS * WB_ROW_WORDS, cols[(s + 1) * stride]);
+        if (t == 0 && s) ge_double(own, R);
+        row_field_unpack(mult, cur, R);
+        ge_add_fields(own, mult, R);
+        cur = nxt;
+    }
+}
+
+// enc(P) (ed25519_PackPoint, curve25519_utils.c:77-98: y with the parity of x in bit 255) of own = (X, Y, T, Z), in every lane.
+// One inversion (ed25519_sign.c:265) by all four lanes; then x on q0 and y on q1 are one product.
+C25519_DEV void encode_point(u32 (&enc)[8], const fe& own)
+{
+    fe Z, zi, a;
+    fe_qperm<3, 3, 3, 3>(Z, own);
+    fe_invert(zi, Z);
+    fe_mul(a, own, zi);                                    // q0: x   q1: y
+    u32 w[8];
+    fe_to_words(w, a);
+    const u32 x_odd = qperm<0, 0, 0, 0>(w[0]) << 31;
+#pragma unroll
+    for (int i = 0; i < 8; i++) enc[i] = qperm<1, 1, 1, 1>(w[i]);
+    enc[7] = (enc[7] & 0x7fffffffu) | x_odd;
+}
+
+// ed25519_CreateKeyPair (ed25519_sign.c:344-367) for element e: priv = sk || enc(A), pub = enc(A), A = clamp(H(sk)[0..31]) * B
+C25519_DEV void keypair_element(void* pub, void* priv, const void* sk, size_t e, const u32* __restrict__ g_wide,
+                                unsigned short* cols, int stride)
+{
+    const Roles R = roles();
+    u32 seed[8], a[8], enc[8];
+    u64 b_words[4];
+    load32(seed, sk, e);
+    ed_expand_seed(a, b_words, seed);
+    wb_columns(cols, stride, a);
+    fe own;
+    base_mult_wide(own, g_wide, cols, stride, R);
+    encode_point(enc, own);
+    if (R.is0) {
+        store32(priv, 2 * e, seed);
+        store32(priv, 2 * e + 1, enc);
+        store32(pub, e, enc);
+    }
+}
+
+// ed25519_SignMessage (ed25519_sign.c:372-419) for element e: r = H(H(sk)[32..63] || m) mod L, R = r * B, S = H(enc(R) || pk || m) a + r
+C25519_DEV void sign_element(void* sig, const void* priv, const uint8_t* msg, size_t len, size_t e, const u32* __restrict__ g_wide,
+                             unsigned short* cols, int stride)
+{
+    const Roles R = roles();
+    u32 seed[8], a[8], r[8], encR[8], pkw[8], s[8];
+    load32(seed, priv, 2 * e);
+    ed_sign_nonce(a, r, seed, msg, len);
+    wb_columns(cols, stride, r);
+    fe own;
+    base_mult_wide(own, g_wide, cols, stride, R);
+    encode_point(encR, own);
+    load32(pkw, priv, 2 * e + 1);
+    ed_sign_s(s, encR, pkw, msg, len, a, r);
+    if (R.is0) {
+        store32(sig, 2 * e, encR);
+        store32(sig, 2 * e + 1, s);
+    }
+}
+
+// curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189) for element e: S = clamp(sk) * B on the Edwards side,
+// u = (Z + Y) / (Z - Y); the clamped key written back
+C25519_DEV void public_fast_element(void* pk, void* sk, size_t e, const u32* __restrict__ g_wide, unsigned short* cols, int stride)
+{
+    const Roles R = roles();
+    u32 k[8], w[8];
+    load32(k, sk, e);
+    clamp_words(k);
+    if (R.is0) store32(sk, e, k);
+    wb_columns(cols, stride, k);
+    fe own, Y, Z, t, num, den, zi;
+    base_mult_wide(own, g_wide, cols, stride, R);
+    fe_qperm<1, 1, 1, 1>(Y, own);
+    fe_qperm<3, 3, 3, 3>(Z, own);
+    fe_add(t, Z, Y);  fe_carry32(num, t);
+    fe_sub(t, Z, Y);  fe_carry32(den, t);
+    fe_invert(zi, den);                                    // Z = Y (the neutral element) gives 0, like the reference's inversion
+    fe_mul(num, num, zi);
+    fe_to_words(w, num);
+    if (R.is0) store32(pk, e, w);
+}
+
 }  // namespace quad
 }  // namespace c25519

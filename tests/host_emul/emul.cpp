@@ -146,6 +146,7 @@ void build_wide_of(std::vector<u32>& g_wide, const ge_pa& b)
             fe_mul(row[2], t, fe_const(K_2D));
             u32* out = g_wide.data() + ((size_t)table * WB_ROWS + i) * WB_ROW_WORDS;
             for (int f = 0; f < 3; f++) { u32 w[8]; fe_to_words(w, row[f]); memcpy(out + 8 * f, w, 32); }
+            out[24] = 2;                                             // the fourth field: 2Z of an affine point (k_gen_wide_table)
         }
     }
 }
@@ -591,6 +592,47 @@ void emul_quad_x25519(unsigned char* out, const unsigned char* pk, unsigned char
             if (e >= n) return;
             if (pk) quad::x25519_element<false>(out, pk, sk, e);
             else quad::x25519_element<true>(out, pk, sk, e);
+        });
+}
+
+// the fixed-base operations on quads (k_ed25519_keypair_quad / k_ed25519_sign_quad / k_x25519_public_fast_quad): the kernels are the
+// element index, `if (e >= n) return`, the lanes' parked columns in LDS, and the call below
+void emul_quad_keypair(unsigned char* pub, unsigned char* priv, const unsigned char* sk, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    const u32* wide = wide_tables();
+    std::vector<unsigned short> cols(WB_COLS * 64);
+    for (size_t base = 0; base < n; base += quad::ELEMS_PER_WAVE)
+        emul_coop::run_block(64, [&] {
+            const size_t e = base + (threadIdx.x >> 2);
+            if (e >= n) return;
+            quad::keypair_element(pub, priv, sk, e, wide, cols.data() + threadIdx.x, 64);
+        });
+}
+
+void emul_quad_sign(unsigned char* sig, const unsigned char* priv, const unsigned char* msg, size_t len, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    const u32* wide = wide_tables();
+    std::vector<unsigned short> cols(WB_COLS * 64);
+    for (size_t base = 0; base < n; base += quad::ELEMS_PER_WAVE)
+        emul_coop::run_block(64, [&] {
+            const size_t e = base + (threadIdx.x >> 2);
+            if (e >= n) return;
+            quad::sign_element(sig, priv, msg + len * e, len, e, wide, cols.data() + threadIdx.x, 64);
+        });
+}
+
+void emul_quad_public_fast(unsigned char* pk, unsigned char* sk, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    const u32* wide = wide_tables();
+    std::vector<unsigned short> cols(WB_COLS * 64);
+    for (size_t base = 0; base < n; base += quad::ELEMS_PER_WAVE)
+        emul_coop::run_block(64, [&] {
+            const size_t e = base + (threadIdx.x >> 2);
+            if (e >= n) return;
+            quad::public_fast_element(pk, sk, e, wide, cols.data() + threadIdx.x, 64);
         });
 }
 

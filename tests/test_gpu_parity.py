@@ -1580,6 +1580,52 @@ def test_verification_walk_on_four_lanes_per_element(api, oracle):
             assert np.array_equal(ok, oracle.ed25519_verify(bsig, pub, bmsg))
 
 
+def test_fixed_base_operations_on_four_lanes_per_element(api, oracle):
+    """k_ed25519_keypair_quad / k_ed25519_sign_quad / k_x25519_public_fast_quad (quad25519.cuh: the walk over the wide comb with a
+    quad of lanes per element, inversion, encoding, the last hash and S in the same launch) -- what calls of 2^11 .. 2^14 elements
+    run.  Forced (QUAD_MIN = 0) for the RFC 8032 / reference vectors at every message length, the fixture at 1 / 15 / 16 / 17 / 1000
+    elements (a lone quad, a wave short of one quad, exactly one wave, one quad into the next workgroup), ragged messages; at
+    their own sizes by default (1025, 5000, 2^14) against the oracle and against the per-wave / one-lane kernels (QUAD_MAX = 0)
+    and the LDS comb (BASE_COMB = 0)."""
+    from curve25519_amd import _lib
+    g = R1024
+    with _lib.tunable("QUAD_MIN", 0), _lib.tunable("QUAD_MAX", 1 << 20):
+        for r in KAT["ed25519"]:
+            msg = np.frombuffer(bytes.fromhex(r["msg"]), np.uint8).reshape(1, -1).copy()
+            pub, priv = api.ed25519_CreateKeyPair(h2a(r["sk"]))
+            assert pub.tobytes().hex() == r["pk"] and priv.tobytes().hex() == r["priv"], r["name"]
+            assert api.ed25519_SignMessage(priv, msg).tobytes().hex() == r["sig"], r["name"]
+        recs = KAT["x25519_public"]
+        pub, clamped = api.curve25519_dh_CalculatePublicKey(np.concatenate([h2a(r["sk"]) for r in recs]), fast=True)
+        for i, r in enumerate(recs):
+            assert pub[i].tobytes().hex() == r["pk"] and clamped[i].tobytes().hex() == r["sk_clamped"], r["name"]
+        for n in (1, 15, 16, 17, 1000):
+            pub, priv = api.ed25519_CreateKeyPair(g["ed_sk"][:n])
+            assert np.array_equal(pub, g["ed_pub"][:n]) and np.array_equal(priv, g["ed_priv"][:n]), n
+            assert np.array_equal(api.ed25519_SignMessage(priv, g["ed_msg"][:n]), g["ed_sig"][:n]), n
+        n = 333                                                        # ragged messages through the same kernel
+        msgs = [synth.random_bytes(((i * 7) % 200, 1), 0x7a61 + i).reshape(-1).tobytes() for i in range(n)]
+        got = api.ed25519_SignMessage_ragged(g["ed_priv"][:n], msgs)
+        for i in range(0, n, 9):
+            m = np.frombuffer(msgs[i], np.uint8).reshape(1, -1)
+            assert np.array_equal(got[i:i + 1], oracle.ed25519_sign(g["ed_priv"][i:i + 1], m)), i
+    for n in (1025, 5000, 1 << 14):                                    # the sizes the dispatch gives to the quads by itself
+        sk, msg = synth.random_bytes((n, 32), 0x4f1 + n), synth.random_bytes((n, 45), 0x4f2 + n)
+        pub, priv = api.ed25519_CreateKeyPair(sk)
+        sig = api.ed25519_SignMessage(priv, msg)
+        xpub, xclamped = api.curve25519_dh_CalculatePublicKey(sk, fast=True)
+        for knob, val in (("QUAD_MAX", 0), ("BASE_COMB", 0)):
+            with _lib.tunable(knob, val):
+                lpub, lpriv = api.ed25519_CreateKeyPair(sk)
+                lxpub, lxclamped = api.curve25519_dh_CalculatePublicKey(sk, fast=True)
+                assert np.array_equal(pub, lpub) and np.array_equal(priv, lpriv), (n, knob)
+                assert np.array_equal(sig, api.ed25519_SignMessage(priv, msg)), (n, knob)
+                assert np.array_equal(xpub, lxpub) and np.array_equal(xclamped, lxclamped), (n, knob)
+        if n <= 5000:
+            epub, epriv = oracle.ed25519_keypair(sk)
+            assert np.array_equal(pub, epub) and np.array_equal(priv, epriv) and np.array_equal(sig, oracle.ed25519_sign(priv, msg)), n
+
+
 def test_a_remembered_key_comb_serves_batches_of_any_size(api, oracle):
     """One ed25519_Verify_Init, many ed25519_Verify_Check calls (ed25519_verify.c:282-286): the comb a batch of >= 2^16 pairs builds
     for its key stays with the calling thread, and every later call of more than 1024 pairs whose context is that one walks the

@@ -34,6 +34,7 @@ def lib():
     lib.emul_mad_overflow_count.restype = C.c_ulonglong
     lib.emul_coop_sync_points.restype = C.c_ulonglong
     for name, args in {"emul_quad_x25519": [vp, vp, vp, sz], "emul_quad_verify": [vp, vp, vp, vp, vp, sz, sz],
+                       "emul_quad_keypair": [vp, vp, vp, sz], "emul_quad_sign": [vp, vp, vp, sz, sz], "emul_quad_public_fast": [vp, vp, sz],
                        "emul_ed25519_verify_fast": [vp, vp, vp, vp, vp, sz, sz]}.items():
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = None
@@ -120,3 +121,36 @@ def test_degenerate_vectors_through_the_quad_walk(lib):
     decided = slow == 0
     assert decided.sum() >= n // 2 and np.array_equal(ok[decided], exp[decided]) and np.array_equal(ok[decided], lane_ok[decided])
     assert exp[decided].sum() > 10 and (exp[decided] == 0).sum() > 0
+
+
+def test_fixed_base_operations_on_quads_give_the_reference_bytes(lib):
+    """ed25519_CreateKeyPair, ed25519_SignMessage and curve25519_dh_CalculatePublicKey_fast with the walk over the wide comb on quads
+    (quad::base_mult_wide: 20 additions of two product levels from the neutral element, the doublings as a level of squarings and
+    one of products, one field of the packed row -- the fourth the constant 2 in the row's padding -- per lane; inversion,
+    encoding, the last hash and S in the same call): RFC 8032 and the reference's vectors (message lengths 0 .. 1023 bytes), 21
+    rows of the 1024-row fixture (one full wave and five elements of the next), the public keys of the X25519 vectors."""
+    before = lib.emul_coop_sync_points()
+    for r in KAT["ed25519"]:
+        sk, msg = h2a(r["sk"]), np.frombuffer(bytes.fromhex(r["msg"]), np.uint8).reshape(1, -1).copy()
+        pub, priv = np.empty((1, 32), np.uint8), np.empty((1, 64), np.uint8)
+        lib.emul_quad_keypair(ptr(pub), ptr(priv), ptr(sk), 1)
+        assert pub.tobytes().hex() == r["pk"] and priv.tobytes().hex() == r["priv"], r["name"]
+        sig = np.empty((1, 64), np.uint8)
+        lib.emul_quad_sign(ptr(sig), ptr(priv), ptr(msg) if msg.shape[1] else None, msg.shape[1], 1)
+        assert sig.tobytes().hex() == r["sig"], r["name"]
+    g, m = R1024, 21
+    sk = np.ascontiguousarray(g["ed_sk"][300:300 + m])
+    pub, priv = np.empty((m, 32), np.uint8), np.empty((m, 64), np.uint8)
+    lib.emul_quad_keypair(ptr(pub), ptr(priv), ptr(sk), m)
+    assert np.array_equal(pub, g["ed_pub"][300:300 + m]) and np.array_equal(priv, g["ed_priv"][300:300 + m])
+    msg = np.ascontiguousarray(g["ed_msg"][300:300 + m])
+    sig = np.empty((m, 64), np.uint8)
+    lib.emul_quad_sign(ptr(sig), ptr(priv), ptr(msg), msg.shape[1], m)
+    assert np.array_equal(sig, g["ed_sig"][300:300 + m])
+    recs = KAT["x25519_public"]
+    sk = np.concatenate([h2a(r["sk"]) for r in recs])
+    pk = np.empty_like(sk)
+    lib.emul_quad_public_fast(ptr(pk), ptr(sk), len(recs))
+    for i, r in enumerate(recs):
+        assert pk[i].tobytes().hex() == r["pk"] and sk[i].tobytes().hex() == r["sk_clamped"], r["name"]
+    assert lib.emul_coop_sync_points() > before
