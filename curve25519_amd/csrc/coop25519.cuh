@@ -242,13 +242,39 @@ C25519_DEV u32 chain250(u32* lds, const Lane& L, u32 z, u32& x11)
     return mul2(lds, L, t, x50);                          // z^(2^250 - 1)
 }
 
-// z^(p-2) limb-per-lane: the 254 S + 11 M chain of fe_invert (ecp_Inverse, curve25519_mehdi.c:340-409); 0 -> 0
-C25519_DEV u32 invert(u32* lds, const Lane& L, u32 z)
+// z^(p-2) limb-per-lane: the 254 S + 11 M chain of fe_invert_fermat (ecp_Inverse, curve25519_mehdi.c:340-409); 0 -> 0
+C25519_DEV u32 invert_fermat(u32* lds, const Lane& L, u32 z)
 {
     u32 x11;
     u32 t = chain250(lds, L, z, x11);
     t = sqr_n(lds, L, t, 5);
     return mul2(lds, L, t, x11);
+}
+
+// 1 / z of every row's value (0 -> 0), limb per lane in and out.  The chain above is 265 product levels of ~380 cycles for a lone
+// wave (44 us); the division steps of safegcd25519.cuh have no use for sixty-four lanes but are ~14 800 instructions on ONE
+// (~33 us): every lane of a row picks up the row's whole element, runs them on it (the sixteen lanes of a row on the same value,
+// the four rows each on their own), and takes its limb of the result back through the row's slot.
+C25519_DEV u32 invert(u32* lds, const Lane& L, u32 z)
+{
+#if C25519_INVERT_SAFEGCD
+    put_a(lds, L, L.row, z);
+    wave_fence();
+    fe f, r;
+    get_fe(f, lds, L.row);
+    wave_fence();
+    fe_invert_safegcd(r, f);
+    if (L.c == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) lds[L.row * SLOT_WORDS + A_OFF + i] = r.v[i];
+    }
+    wave_fence();
+    const u32 v = lds[L.row * SLOT_WORDS + A_OFF + (L.c < 10 ? L.c : 0)];
+    wave_fence();
+    return v;
+#else
+    return invert_fermat(lds, L, z);
+#endif
 }
 
 // z^((p-5)/8) = z^(2^252 - 3)   (fe_pow2523)

@@ -74,6 +74,23 @@ C25519_DEV float fast_div(float a, float b) { return __fdividef(a, b); }
 // (hi:lo) >> s, low 32 bits   (v_alignbit_b32)
 C25519_DEV u32 alignbit32(u32 hi, u32 lo, int s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
 
+// acc + x * y, signed 32 x 32 + 64 -> 64 (v_mad_i64_i32): the matrix applications of safegcd25519.cuh.  The compiler, left to
+// itself, turns a signed matrix entry times a masked (known non-negative) limb into v_mad_u64_u32 plus a v_mul_lo_u32 correction.
+C25519_DEV int64_t mad_i64_i32(int64_t acc, int32_t x, int32_t y)
+{
+    u64 carry_out;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry_out) : "v"(x), "v"(y));
+    return acc;
+}
+// acc + x0 * y0 + x1 * y1: one row of a 2 x 2 matrix times a column of limbs, one asm statement (the compiler pads asm boundaries)
+C25519_DEV int64_t mad2_i64_i32(int64_t acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1)
+{
+    u64 carry_out;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0" : "+v"(acc), "=s"(carry_out) : "v"(x0), "v"(y0), "v"(x1), "v"(y1));
+    return acc;
+}
+
 // acc += sum x[t]*y[t]: one asm statement per column, so the compiler cannot reassociate the chain (it would move
 // the carry-in to the end and re-create a separate 64-bit add) and does not pad every MAD with a wait state (it pads
 // asm boundaries only).  The SGPR pair receives the (never set) carry-out.

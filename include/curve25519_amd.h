@@ -214,7 +214,8 @@ int c25519_amd_verify_point_dev(void *out, const void *sig, const void *pk, cons
 
 /* device field arithmetic on n pairs of 32-byte little-endian values taken mod p = 2^255-19 (host pointers):
  * out[i] = canonical(op(a[i], b[i])), op 0 mul, 1 square, 2 add, 3 sub, 4 inverse, 5 a^((p-5)/8),
- * 6 canonicalise, 7 (a-b)*(a+b), 8 a^2-b, 9 2a^2+(a+b)-b, 10 a+121665b, 11 9a.
+ * 6 canonicalise, 7 (a-b)*(a+b), 8 a^2-b, 9 2a^2+(a+b)-b, 10 a+121665b, 11 9a, 12 inverse as a^(p-2) (the reference's
+ * ecp_Inverse chain), 13 inverse by constant-time division steps (what op 4 and every kernel run; 0 -> 0 either way).
  * The unit-test hook for the L0 layer (the reference's ECP_SELF_TEST checks, test/curve25519_selftest.c:640-741). */
 int c25519_amd_fe_selftest(unsigned char *out, const unsigned char *a, const unsigned char *b, size_t n, int op);
 

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "curve25519_amd", "csrc")
 LIB = os.path.join(HERE, "libc25519_emul.so")
-HEADERS = ["valu_gfx950.cuh", "fe25519.cuh", "sc25519.cuh", "sha512.cuh", "ge25519.cuh", "x25519.cuh", "lanes.cuh",
+HEADERS = ["valu_gfx950.cuh", "safegcd25519.cuh", "fe25519.cuh", "sc25519.cuh", "sha512.cuh", "ge25519.cuh", "x25519.cuh", "lanes.cuh",
            "curve_constants.cuh", "verify_fast.cuh", "coop25519.cuh", "coop_ops.cuh", "quad25519.cuh"]
 
 

@@ -100,6 +100,14 @@ inline u64 mad64(u64 acc, u32 x, u32 y)
     if (r < acc) emul_mad_overflows++;
     return r;
 }
+inline int64_t mad_i64_i32(int64_t acc, int32_t x, int32_t y)      // v_mad_i64_i32; a signed wrap would break safegcd25519.cuh's bounds
+{
+    __atomic_fetch_add(&emul_mad_count, 1ULL, __ATOMIC_RELAXED);
+    int64_t r;
+    if (__builtin_add_overflow(acc, (int64_t)x * y, &r)) emul_mad_overflows++;
+    return r;
+}
+inline int64_t mad2_i64_i32(int64_t acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1) { return mad_i64_i32(mad_i64_i32(acc, x0, y0), x1, y1); }
 inline u64 mad_chain5(u64 acc, const u32 (&x)[5], const u32 (&y)[5])
 {
     for (int t = 0; t < 5; t++) acc = mad64(acc, x[t], y[t]);

@@ -71,6 +71,12 @@ def test_field_layer_against_big_integers(api):
         out = np.empty((n, 32), np.uint8)
         assert L.c25519_amd_fe_selftest(out.ctypes.data, a.ctypes.data, bb.ctypes.data, n, op) == 0
         vectors.check_field(op, out, pairs)
+    # 1 / x three ways (op 4: what the kernels run; 12: x^(p-2); 13: division steps) on the wider set of inversion patterns
+    pairs, a, b = vectors.inversion_cases()
+    for op in (4, 12, 13):
+        out = np.empty((len(pairs), 32), np.uint8)
+        assert L.c25519_amd_fe_selftest(out.ctypes.data, a.ctypes.data, b.ctypes.data, len(pairs), op) == 0
+        vectors.check_field(op, out, pairs)
 
 
 def test_scalar_layer_borrow_paths(api):

@@ -35,9 +35,36 @@ FIELD_OPS = {
     4: lambda x, y: pow(x, P - 2, P), 5: lambda x, y: pow(x, (P - 5) // 8, P), 6: lambda x, y: x,
     7: lambda x, y: (x - y) * (x + y), 8: lambda x, y: x * x - y, 9: lambda x, y: 2 * x * x + x,
     10: lambda x, y: x + 121665 * y, 11: lambda x, y: 9 * x,
+    12: lambda x, y: pow(x, P - 2, P), 13: lambda x, y: pow(x, P - 2, P),
 }
 # ops 8 and 9 take a reduced second operand (the contract of fe_sqr_sub / fe_sqr2_add_sub)
 FIELD_OPS_B_REDUCED = {8, 9}
+
+
+def inversion_cases():
+    """256-bit patterns for the inversions (op 4: what the kernels run, 12: the reference's exponentiation, 13: division steps):
+    every power of two and its neighbours, the same below p, below 2p and below 2^256 (non-canonical inputs are reduced first),
+    small values, values of the form (p +- 1) / 2^k, seeded random.  The division steps' path depends on the bit patterns of p and
+    the input (runs of zeros, of ones, values whose quotient sequence is long), so this is wider than field_cases()."""
+    vals = set(range(0, 40))
+    for k in range(0, 256):
+        for d in (-1, 0, 1):
+            for base in (0, P, 2 * P, 2**256):
+                for sgn in (1, -1):
+                    v = base + sgn * (1 << k) + d
+                    if 0 <= v < 2**256:
+                        vals.add(v)
+    for k in range(1, 64):
+        vals.add(((P + 1) >> 1) * pow(2, -k + 1, P) % P)
+        vals.add((P - 1) // 2 >> k)
+        vals.add(pow(3, k * 5, P))
+        vals.add(P - pow(3, k * 7, P))
+    vals = sorted(vals)
+    rnd = synth.random_bytes((700, 32), 0xFE02)
+    vals += [int.from_bytes(r.tobytes(), "little") for r in rnd]
+    pairs = [(v, 0) for v in vals]
+    a = np.stack([le(x, 32) for x, _ in pairs])
+    return pairs, a, np.zeros_like(a)
 
 
 def scalar_cases():
