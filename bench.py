@@ -48,17 +48,11 @@ sys.path.insert(0, ROOT)
 BATCH = 1 << 20
 BYTES_PER_OP = {"x25519": 96, "sign": 160, "verify": 132}          # SURVEY.md 8(d), compulsory HBM bytes
 MACS_PER_OP = {"x25519": 184104, "sign": 52992, "verify": 245664}  # SURVEY.md 8(a), 32x32 MACs at 72/mul
-# what the device actually issues per operation (v_mad_u64_u32 count from the kernels' ISA): the
-# ladder does the reference's work in 100/55-MAD products; sign walks 3 doublings instead of 31; verification of
-# on-curve keys walks ~134 doublings instead of 255.  verify = walk 138 600 (25.0 rounds of 3 723 above digit 7 for the
-# average wave start at digit 32.0, one round with two and six rounds of 6 551 with four of sigma's 26 comb columns, the
-# first digit's two rows) + two points of
-# 22 900 each (a 258 S + 24 M square root, a window table of 4 doublings, 3 additions, 8 row conversions) + ~2 000 in the
-# scalar kernel (profiles/r03_isa_mix.txt)
-EXECUTED_MACS_PER_OP = {"x25519": 191400, "sign": 25100, "verify": 186400}
-# ... replaced, when the round's count is committed, by profiles/rNN_executed_macs.json: v_mad_u64_u32 instructions counted
-# by running the DEVICE SOURCE one lane at a time against the C model of the gfx950 primitives (tools/executed_macs.py;
-# tests/test_bench_contract.py pins the file against a fresh count)
+# what the device actually issues per operation: profiles/rNN_executed_macs.json -- v_mad_u64_u32 / v_mad_i64_i32 instructions
+# counted by running the DEVICE SOURCE one lane at a time against the C model of the gfx950 primitives (tools/executed_macs.py;
+# tests/test_bench_contract.py pins the file against a fresh count).  No committed count: the line says so (null), it does not
+# fall back on constants.
+EXECUTED_OPS = ("x25519", "sign", "verify")
 
 
 def executed_macs():
@@ -67,10 +61,10 @@ def executed_macs():
         try:
             with open(path) as f:
                 d = json.load(f)["per_op"]
-            return {k: int(d[k]) for k in EXECUTED_MACS_PER_OP}, os.path.basename(path)
+            return {k: int(d[k]) for k in EXECUTED_OPS}, os.path.basename(path)
         except Exception:
             pass
-    return dict(EXECUTED_MACS_PER_OP), None
+    return {k: None for k in EXECUTED_OPS}, None
 
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md
 
@@ -143,6 +137,55 @@ def measured_mad_peak():
     return best, src
 
 
+def live_mad_peak():
+    """The same accumulating v_mad_u64_u32 stream as measured_mad_peak(), measured NOW on this device: tools/ubench/mad_peak --quick
+    (one configuration, ~60 ms of clock ramp + 10 launches of ~1 ms), run by rank 0 behind every timed block.  The denominator
+    of roofline.*.valu when it is there: the numerator's box, clock and run."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "ubench", "mad_peak")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "--quick"], capture_output=True, text=True, timeout=120)
+        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        return rec if rec.get("v_mad_u64_u32") else None
+    except Exception as e:                                   # a measurement leg must not take the bench line down
+        print(f"bench.py: tools/ubench/mad_peak --quick failed ({e!r}); the committed peak stays the denominator", file=sys.stderr)
+        return None
+
+
+def apply_live_peak(valu, live):
+    """valu.peak / frac / frac_executed against the live peak (peak_live); the committed figure stays beside it (peak_committed)."""
+    valu["peak_committed"] = valu.get("peak")
+    valu["peak_committed_source"] = valu.pop("peak_source", None)
+    valu["peak_committed_policy"] = valu.pop("peak_policy", None)
+    valu["frac_vs_committed_peak"] = valu.get("frac")
+    if not live:
+        valu["peak_live"] = None
+        valu["peak_policy"] = "committed (no live measurement in this run): " + str(valu["peak_committed_policy"])
+        return
+    peak = live["v_mad_u64_u32"]
+    valu["peak_live"] = round(peak / 1e12, 4)
+    valu["peak"] = valu["peak_live"]
+    valu["frac"] = round(valu["achieved"] * 1e12 / peak, 4)
+    if valu.get("executed_macs_per_op") and valu.get("algorithmic_macs_per_op"):
+        valu["frac_executed"] = round(valu["achieved"] * 1e12 * valu["executed_macs_per_op"] / valu["algorithmic_macs_per_op"] / peak, 4)
+    valu["peak_policy"] = ("live: tools/ubench/mad_peak --quick on this device behind this run's timed blocks (the 8-waves-per-SIMD "
+                           "accumulating v_mad_u64_u32 stream, best of 10 launches after a 60 ms ramp)")
+
+
+def valu_issue(kernels):
+    """How busy the vector ALUs are in every kernel of a pass, from the committed counter passes of this bench: VALU-busy against
+    chip peak (north_star) and the issue utilisation by instruction class (tools/valu_issue.py)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import valu_issue as vi
+        return vi.for_pass(kernels)
+    except Exception as e:
+        print(f"bench.py: tools/valu_issue.py failed ({e!r})", file=sys.stderr)
+        return None
+
+
 def measured_traffic(kernels):
     """HBM bytes per pass from the committed rocprofv3 PMC passes (separate --pmc runs of this same bench,
     summarised by tools/rocpd_summary.py): WRITE_SIZE + 2 x FETCH_SIZE, both in KiB -- the x2 is the gfx950
@@ -202,8 +245,9 @@ def roofline_for(wl, n, kernel_ms, probe=None):
             "algorithmic_macs_per_op": MACS_PER_OP[wl],
             "executed_macs_per_op": executed[wl],
             "executed_macs_source": f"profiles/{executed_src} (device source run against the C model of the primitives, "
-                                    "tools/executed_macs.py)" if executed_src else "bench.py constants (ISA counts x trip counts)",
-            "frac_executed": round(executed[wl] * n / kernel_s / peak_mac, 4) if peak_mac else None,
+                                    "tools/executed_macs.py)" if executed_src else None,
+            "frac_executed": round(executed[wl] * n / kernel_s / peak_mac, 4) if peak_mac and executed[wl] else None,
+            "issue": valu_issue(kernels),
             "peak_source": f"profiles/{peak_src}" if peak_src else None,
             "peak_policy": "the fastest box's 8-waves-per-SIMD v_mad_u64_u32 stream of all committed rounds (wall-clock rate)"}
     if probe:
@@ -736,6 +780,18 @@ def main():
         attach_probe(primary["roofline"]["valu"], probe)
         primary["roofline"]["binding_frac"] = binding_frac(primary["roofline"]["valu"])
 
+    # ---- ... and the roof itself: the multiplier's issue peak on THIS device in THIS run (rank 0; the other ranks wait at the
+    # closing barrier of the last block)
+    live_peak = live_mad_peak() if rank == 0 and not args.no_side else None
+    if rank == 0:
+        for q in [primary] + [side[k] for k in ("verify", "sign") if isinstance(side.get(k), dict)]:
+            v = q["roofline"]["valu"]
+            apply_live_peak(v, live_peak)
+            if wl != "mixed":
+                q["roofline"]["binding_frac"] = binding_frac(v)
+            else:
+                q["roofline"]["binding_frac"] = v.get("frac")
+
     result = None
     if rank == 0:
         roof = primary["roofline"]
@@ -753,6 +809,10 @@ def main():
                               "valu_frac_algorithmic": q["roofline"]["valu"]["frac"],
                               "valu_frac_executed": q["roofline"]["valu"]["frac_executed"],
                               "executed_macs_per_op": q["roofline"]["valu"]["executed_macs_per_op"],
+                              "valu_peak": q["roofline"]["valu"]["peak"], "valu_peak_live": q["roofline"]["valu"]["peak_live"],
+                              "valu_busy": (q["roofline"]["valu"].get("issue") or {}).get("valu_busy"),
+                              "valu_issue_util": (q["roofline"]["valu"].get("issue") or {}).get("valu_issue_util"),
+                              "valu_issue": q["roofline"]["valu"].get("issue"),
                               "kernel": q["roofline"]["kernel"]}
         # bit-exactness of everything this run timed, against the reference's portable-C outputs (committed digests)
         flat = [b for _, r in runs for b in r["bit_exact"]] + [b for _, r in runs for b in r.get("gathered_rows_bit_exact", [])]

@@ -20,6 +20,7 @@ struct FastScratch {
     u32 *slow_count;        // ... and how many; [1], [2]: how many elements `order` holds from its front / from its back
     u32 *order;             // the walk's lane j takes element order[j]: elements whose scalars start at digit 32 or below
                             // from the front, the few longer ones from the back, so that a wave of 64 rarely holds one
+    u32 *pflags;            // [2n], the quad path only (k_ed25519_verify_quad_prep): all-ones iff key e (R of e, at n + e) decoded onto the curve
     u32 *slow_report;       // a word that outlives the call's scratch: the count again, for c25519_amd_verify_last_slow_elements
     int lat_cap_bits;       // longest short vector the walk takes (LAT_CAP_BITS; lower only under the test knob VERIFY_LAT_CAP_BITS)
 };

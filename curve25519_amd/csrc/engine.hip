@@ -681,13 +681,8 @@ constexpr int WALK_BLOCK = C25519_WALK_BLOCK;
 #define C25519_VD_WAVES 3            // ... and the point decoding + table kernel
 #endif
 
-// step 1: hash, short lattice vector, sigma -- integer work only
-__global__ void __launch_bounds__(FS_BLOCK) k_ed25519_verify_fast_scalars(FastScratch fs, const void* sig, const void* pk,
-                                                                          Msgs msgs, size_t n)
+C25519_DEV void verify_scalars_lane(const FastScratch& fs, const void* sig, const void* pk, const Msgs& msgs, size_t n, size_t i)
 {
-    const size_t i = (size_t)blockIdx.x * FS_BLOCK + threadIdx.x;
-    if (i == 0) fs.slow_count[0] = fs.slow_count[1] = fs.slow_count[2] = 0;
-    if (i >= n) return;
     u32 pkw[8], Rw[8], Sw[8], cols[SIGMA_WORDS], rho[5], tau[5], tau_neg;
     load32(pkw, pk, i);
     load32(Rw, sig, 2 * i);
@@ -699,6 +694,17 @@ __global__ void __launch_bounds__(FS_BLOCK) k_ed25519_verify_fast_scalars(FastSc
     for (int w = 0; w < 5; w++) { fs.rho[(size_t)w * n + i] = rho[w]; fs.tau[(size_t)w * n + i] = tau[w]; }
     const int top = lat_ok ? walk_top_digit(tau, rho) : 0;
     fs.flags[i] = (lat_ok & FLAG_FITS) | (tau_neg & FLAG_TAU_NEG) | ((u32)top << 8);
+}
+
+
+// step 1: hash, short lattice vector, sigma -- integer work only
+__global__ void __launch_bounds__(FS_BLOCK) k_ed25519_verify_fast_scalars(FastScratch fs, const void* sig, const void* pk,
+                                                                          Msgs msgs, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * FS_BLOCK + threadIdx.x;
+    if (i == 0) fs.slow_count[0] = fs.slow_count[1] = fs.slow_count[2] = 0;
+    if (i >= n) return;
+    verify_scalars_lane(fs, sig, pk, msgs, n, i);
 }
 
 // step 2: the two points of an element, one per lane: lane j < n decodes key j, lane n + j decodes R of signature j (a
@@ -777,24 +783,49 @@ __global__ void __launch_bounds__(WALK_BLOCK, C25519_VW_WAVES) k_ed25519_verify_
     verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
 }
 
-// step 3 on QUADS (quad25519.cuh: quad::walk_is_neutral): what batches of 2^11 .. 2^15 signatures run -- the walk is two thirds of
-// a verification's chain, and four lanes per element walk it in two product levels per addition and a level of squarings and
-// one of products per doubling (~2.3 x shorter).  64 elements (four waves) per workgroup share one staged comb table; slot j of
-// the grid takes element order[j] like the one-lane walk's lane j.
+// Batches of 2^11 .. 2^15 signatures leave most of the chip idle under one-lane kernels (2^14 elements: 256 waves on 1024 SIMDs), so
+// their path is shaped for the LENGTH of the chain, not for instructions per element:
+//  * k_ed25519_verify_quad_prep -- ONE launch for steps 1 and 2: the first workgroups hash and reduce (50 us), the others decode the
+//    two points of every element and build their window tables (92 us) AT THE SAME TIME.  The points cannot know tau's sign yet:
+//    they tabulate the key as decoded, and the walk flips the rows' signs where tau < 0.  Each lane reports its point in a word of
+//    its own (pflags), so nothing here is ordered against the scalar workgroups.
+//  * k_ed25519_verify_quad_walk -- step 3 on QUADS (quad25519.cuh: quad::walk_is_neutral): four lanes per element walk an addition
+//    in two product levels and a doubling in a level of squarings and one of products (~2.3 x shorter than a lane's); it also
+//    makes the slow list (an element the walk cannot decide: off-curve key, over-long vector) for step 5 behind it.  64 elements
+//    (four waves) per workgroup share one staged comb table; element order (no long / short sorting: 16 elements per wave).
+__global__ void __launch_bounds__(ED_BLOCK, C25519_VD_WAVES) k_ed25519_verify_quad_prep(FastScratch fs, const void* sig, const void* pk,
+                                                                                         Msgs msgs, size_t n, unsigned scalar_blocks)
+{
+    static_assert(FS_BLOCK == ED_BLOCK, "one workgroup shape for both roles");
+    if (blockIdx.x < scalar_blocks) {
+        const size_t i = (size_t)blockIdx.x * FS_BLOCK + threadIdx.x;
+        if (i == 0) fs.slow_count[0] = fs.slow_count[1] = fs.slow_count[2] = 0;
+        if (i >= n) return;
+        verify_scalars_lane(fs, sig, pk, msgs, n, i);
+        return;
+    }
+    const size_t j = (size_t)(blockIdx.x - scalar_blocks) * ED_BLOCK + threadIdx.x;
+    if (j >= 2 * n) return;
+    const bool is_r = j >= n;
+    const size_t e = is_r ? j - n : j;
+    u32 w[8];
+    if (is_r) load32(w, sig, 2 * e); else load32(w, pk, e);
+    fe X, Y;
+    const u32 ok = ed_verify_fast_decode(X, Y, w, is_r ? 0xffffffffu : 0u, 0u);
+    fs.pflags[j] = ok;
+    wtable_build(fs.tables + e * FAST_TABLE_WORDS + (is_r ? WTABLE_WORDS : 0), X, Y);
+}
+
 constexpr int QW_BLOCK = 256;
 __global__ void __launch_bounds__(QW_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2)))
 k_ed25519_verify_quad_walk(FastScratch fs, int* verdict, size_t n, const u32* __restrict__ g_tbl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[SC_TBL_WORDS];
     lds_stage_words(lds_tbl, g_tbl + SC_TBL_OFFSET, SC_TBL_WORDS);
-    const size_t slot = (size_t)blockIdx.x * (QW_BLOCK / 4) + (threadIdx.x >> 2);
-#if C25519_WALK_SORTED
-    const size_t i = slot < n ? fs.order[slot] : n;
-#else
-    const size_t i = slot;
-#endif
-    const u32 f = i < n ? fs.flags[i] : FLAG_SLOW;
-    const bool walks = !(f & FLAG_SLOW);
+    const size_t i = (size_t)blockIdx.x * (QW_BLOCK / 4) + (threadIdx.x >> 2);
+    const u32 f = i < n ? fs.flags[i] : 0u;
+    const u32 key_ok = i < n ? fs.pflags[i] : 0u, r_ok = i < n ? fs.pflags[n + i] : 0u;
+    const bool walks = (f & FLAG_FITS) && key_ok;
     int top = walks ? (int)((f >> 8) & 63u) : 0;           // the wave walks from its longest element's first digit
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -802,12 +833,16 @@ k_ed25519_verify_quad_walk(FastScratch fs, int* verdict, size_t n, const u32* __
         top = other > top ? other : top;
     }
     top = __builtin_amdgcn_readfirstlane(top);
-    if (!walks) return;                                   // (whole quads leave)
     const quad::Roles R = quad::roles();
+    if (!walks) {                                         // (whole quads leave)
+        if (i < n && R.is0) fs.slow_list[atomicAdd(fs.slow_count, 1u)] = (u32)i;
+        return;
+    }
     const u32* tq = fs.tables + i * FAST_TABLE_WORDS;
     const WalkScalars sc{ fs.sigma, fs.tau, fs.rho, n, i };
-    const u32 neutral = quad::walk_is_neutral(sc, tq, tq + WTABLE_WORDS, lds_tbl, top < 8 ? 8 : top, R);
-    if (R.is0) verdict[i] = (neutral & f & FLAG_R_OK) ? 1 : 0;
+    const u32 q_flip = (f & FLAG_TAU_NEG) ? 0xffffffffu : 0u;
+    const u32 neutral = quad::walk_is_neutral(sc, tq, tq + WTABLE_WORDS, lds_tbl, top < 8 ? 8 : top, R, q_flip);
+    if (R.is0) verdict[i] = (neutral & r_ok) ? 1 : 0;
 }
 
 // The whole lattice path of ONE element in ONE launch, for a call of a few elements: a workgroup of THREE waves per element
@@ -1328,7 +1363,7 @@ int launch_invert(const ProjScratch& scr, size_t n, const Fin& fin, hipStream_t 
 // the fast path's scalars, flags and slow list
 constexpr size_t VERIFY_TABLE_WORDS = FAST_TABLE_WORDS > QTABLE_LIMB_WORDS ? FAST_TABLE_WORDS : QTABLE_LIMB_WORDS;
 static_assert(FAST_TABLE_WORDS % 32 == 0 && VERIFY_TABLE_WORDS % 32 == 0, "per-lane tables must keep their rows 128-byte aligned");
-inline size_t verify_scalar_words(size_t n) { return round_up(SIGMA_WORDS * n, 4) + 2 * round_up(5 * n, 4) + 3 * round_up(n, 4) + 4; }
+inline size_t verify_scalar_words(size_t n) { return round_up(SIGMA_WORDS * n, 4) + 2 * round_up(5 * n, 4) + 5 * round_up(n, 4) + 4; }
 inline size_t verify_scratch_bytes(size_t n)
 {
     return (n * VERIFY_TABLE_WORDS + proj_words(n) + verify_scalar_words(n)) * sizeof(u32);
@@ -1372,6 +1407,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
         fs.slow_list = fs.flags + round_up(n, 4);
         fs.order = fs.slow_list + round_up(n, 4);
         fs.slow_count = fs.order + round_up(n, 4);
+        fs.pflags = fs.slow_count + 4;
         fs.slow_report = report;
         {   // test knob: a lower cap sends ordinary signatures down the over-long-vector branch (slow list, reference order)
             const long cap = c25519_host::tunable_or(c25519_host::T_VERIFY_LAT_CAP_BITS, LAT_CAP_BITS);
@@ -1381,13 +1417,18 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
             C25519_TRY(hipMemsetAsync(fs.slow_count, 0, 3 * sizeof(u32), stream));
             k_ed25519_verify_one_per_group<<<(unsigned)n, 192, 0, stream>>>(fs, verdict, sig, pk, msgs, n, tbl);
             C25519_TRY(hipGetLastError());
+        } else if (verify_quad_for(n)) {                   // four lanes per element walk; scalars and points side by side in one launch
+            const unsigned sb = grid_for(n, FS_BLOCK);
+            k_ed25519_verify_quad_prep<<<sb + grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, sig, pk, msgs, n, sb);
+            C25519_TRY(hipGetLastError());
+            k_ed25519_verify_quad_walk<<<grid_for(n, QW_BLOCK / 4), QW_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
+            C25519_TRY(hipGetLastError());
         } else {
             k_ed25519_verify_fast_scalars<<<grid_for(n, FS_BLOCK), FS_BLOCK, 0, stream>>>(fs, sig, pk, msgs, n);
             C25519_TRY(hipGetLastError());
             k_ed25519_verify_fast_points<<<grid_for(2 * n, ED_BLOCK), ED_BLOCK, 0, stream>>>(fs, sig, pk, n);
             C25519_TRY(hipGetLastError());
-            if (verify_quad_for(n)) k_ed25519_verify_quad_walk<<<grid_for(n, QW_BLOCK / 4), QW_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
-            else k_ed25519_verify_fast_walk<<<grid_for(n, WALK_BLOCK), WALK_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
+            k_ed25519_verify_fast_walk<<<grid_for(n, WALK_BLOCK), WALK_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
             C25519_TRY(hipGetLastError());
         }
         k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
@@ -1441,8 +1482,8 @@ bool x25519_two_waves_for(size_t n)
 }
 // four lanes per element (k_x25519_quad): between the per-wave kernels and the batches that give every SIMD a wave of one-lane
 // elements.  X25519: the quad's step is 679 instructions against the lane's 1246, so up to 2^14 elements (1024 quad-waves, one per
-// SIMD) a call takes 0.39 ms instead of 0.71 (21 / 42 M/s at 2^13 / 2^14 against 11.6 / 23.1); two quad-waves per SIMD (2^15
-// elements) still beat the 512 one-lane waves, 0.63 against 0.71 ms; below ~3600 elements a wave per element is faster.
+// SIMD) a call takes 0.34 ms instead of 0.71 (23 / 48 M/s at 2^13 / 2^14 against 11.6 / 23.1); two quad-waves per SIMD (2^15
+// elements) still beat the 512 one-lane waves, 0.62 against 0.71 ms; below ~3600 elements a wave per element is faster.
 // Tunables QUAD_MIN / QUAD_MAX (tools/mid_batch_sweep.py, profiles/r06_mid_batch_sweep.txt).
 bool quad_for(size_t n, size_t dflt_min, size_t dflt_max)
 {
@@ -1453,10 +1494,10 @@ bool quad_for(size_t n, size_t dflt_min, size_t dflt_max)
     return m > mn && m <= mx;
 }
 bool x25519_quad_for(size_t n) { return quad_for(n, 3584, (size_t)1 << 15); }
-bool verify_quad_for(size_t n) { return quad_for(n, 1024, (size_t)1 << 15); }      // the walk kernel only
-// the fixed-base operations on quads (k_ed25519_*_quad; over the wide comb, without a blinding context): one chain of ~110 us up to
-// 2^14 elements (one quad-wave per SIMD) against 115 us for 1024 per-wave operations and the one-lane path's 127-156 us of three
-// launches (profiles/r06_mid_batch_sweep.txt)
+bool verify_quad_for(size_t n) { return quad_for(n, 1024, (size_t)1 << 15); }      // k_ed25519_verify_quad_prep + _quad_walk: 0.30-0.31 ms up to 2^14, 0.48 at 2^15 (one-lane kernels: 0.52-0.63)
+// the fixed-base operations on quads (k_ed25519_*_quad; over the wide comb, without a blinding context): one chain of 53-89 us up to
+// 2^14 elements (one quad-wave per SIMD) against 81 us for 1024 per-wave signatures and the one-lane path's three launches
+// (134-144 us at 2^15 / 2^16); profiles/r06_mid_batch_sweep.txt
 bool fixed_base_quad_for(size_t n) { return quad_for(n, 1024, (size_t)1 << 14); }
 bool fixed_base_coop_for(size_t n) { return coop_for(n, 2048); }
 bool verify_coop_for(size_t n) { return coop_for(n, 2048); }       // three waves per element: 0.13-0.55 against 0.60 ms (1.02 at 4096)

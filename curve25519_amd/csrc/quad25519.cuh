@@ -290,7 +290,10 @@ C25519_DEV void comb_field(fe& mult, const u32* tbl, u32 c, const Roles& R)
 // ge_walk_is_neutral (verify_fast.cuh) by a quad: W = sigma*B + tau*Q + rho*Rn from the element's two window tables, its biased
 // scalars and the LDS comb; all-ones iff W is the neutral element.  Same digits, same rows, same order of operations; the walk
 // starts from the neutral element (one more addition than the one-lane walk's "first row as the starting point").
-C25519_DEV u32 walk_is_neutral(const WalkScalars& sc, const u32* tq, const u32* tr, const u32* lds_tbl, int top, const Roles& R)
+// q_flip (all-ones or zero): the table at tq holds the point as decoded and the walk wants its negative (tau < 0: the rows'
+// signs flip, nothing else -- the points were decoded and tabulated beside the scalar work, before tau's sign was known).
+C25519_DEV u32 walk_is_neutral(const WalkScalars& sc, const u32* tq, const u32* tr, const u32* lds_tbl, int top, const Roles& R,
+                               u32 q_flip = 0)
 {
     fe own, mult;
     ge_neutral(own, R);
@@ -298,7 +301,7 @@ C25519_DEV u32 walk_is_neutral(const WalkScalars& sc, const u32* tq, const u32* 
         u32 neg;
         field_raw rq, rr;
         const u32 mq = signed16_of(neg, sc.tau_word(top >> 3), top & 7);
-        row_field_fetch(rq, tq + mq * ROW_WORDS, neg);
+        row_field_fetch(rq, tq + mq * ROW_WORDS, neg ^ q_flip);
         const u32 mr = signed16_of(neg, sc.rho_word(top >> 3), top & 7);
         row_field_fetch(rr, tr + mr * ROW_WORDS, neg);
         row_field_unpack(mult, rq, R);
@@ -312,7 +315,7 @@ C25519_DEV u32 walk_is_neutral(const WalkScalars& sc, const u32* tq, const u32* 
         u32 neg;
         field_raw rq, rr;                               // the round's two rows: in flight under the doublings
         const u32 mq = signed16_of(neg, tw, i & 7);
-        row_field_fetch(rq, tq + mq * ROW_WORDS, neg);
+        row_field_fetch(rq, tq + mq * ROW_WORDS, neg ^ q_flip);
         const u32 mr = signed16_of(neg, rw, i & 7);
         row_field_fetch(rr, tr + mr * ROW_WORDS, neg);
         if (i >= SC_ROUNDS) {

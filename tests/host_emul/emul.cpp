@@ -637,8 +637,8 @@ void emul_quad_public_fast(unsigned char* pk, unsigned char* sk, size_t n)
 }
 
 // the lattice path with the WALK on quads (quad::walk_is_neutral): scalars, decoding and window tables by the one-lane code, as
-// k_ed25519_verify_fast_scalars / _points run them; then 16 elements per wave walk together from the wave's top digit
-// (k_ed25519_verify_quad_walk).  need_slow: the elements the walk does not decide (their verdict stays 0).
+// k_ed25519_verify_quad_prep runs them (side by side: the points are tabulated as decoded, tau's sign reaches the walk as a flip of
+// the key rows' signs); then 16 elements per wave walk together from the wave's top digit (k_ed25519_verify_quad_walk).  need_slow: the elements the walk does not decide (their verdict stays 0).
 void emul_quad_verify(int* verdict, int* need_slow, const unsigned char* sig, const unsigned char* pk, const unsigned char* msg,
                       size_t len, size_t n)
 {
@@ -649,7 +649,7 @@ void emul_quad_verify(int* verdict, int* need_slow, const unsigned char* sig, co
     for (size_t base = 0; base < n; base += G) {
         const int m = (int)std::min<size_t>(G, n - base);
         int wave_top = 0;
-        u32 r_ok[G] = {}, walks[G] = {};
+        u32 r_ok[G] = {}, walks[G] = {}, flip[G] = {};
         for (int j = 0; j < m; j++) {
             const size_t i = base + j;
             u32 pkw[8], Rw[8], Sw[8], c[SIGMA_WORDS], rh[5], ta[5], tau_neg;
@@ -658,8 +658,9 @@ void emul_quad_verify(int* verdict, int* need_slow, const unsigned char* sig, co
             rd32(Sw, sig, 2 * i + 1);
             const u32 lat_ok = ed_verify_fast_scalars(c, rh, ta, tau_neg, pkw, Rw, Sw, msg + len * i, len);
             fe QX, QY, RX, RY;
-            const u32 q_ok = ed_verify_fast_decode(QX, QY, pkw, 0u, tau_neg);
-            r_ok[j] = ed_verify_fast_decode(RX, RY, Rw, 0xffffffffu, tau_neg);
+            const u32 q_ok = ed_verify_fast_decode(QX, QY, pkw, 0u, 0u);       // as k_ed25519_verify_quad_prep: tau's sign is not known yet
+            r_ok[j] = ed_verify_fast_decode(RX, RY, Rw, 0xffffffffu, 0u);
+            flip[j] = tau_neg;                                                 // ... the walk flips the key rows' signs instead
             need_slow[i] = (lat_ok && q_ok) ? 0 : 1;
             verdict[i] = 0;
             walks[j] = !need_slow[i];
@@ -677,7 +678,7 @@ void emul_quad_verify(int* verdict, int* need_slow, const unsigned char* sig, co
             const quad::Roles R = quad::roles();
             const WalkScalars sc{ cols.data(), tau.data(), rho.data(), (size_t)G, (size_t)j };
             const u32* tq = tabs.data() + (size_t)j * 2 * WTABLE_WORDS;
-            const u32 neutral = quad::walk_is_neutral(sc, tq, tq + WTABLE_WORDS, tbl, wave_top, R);
+            const u32 neutral = quad::walk_is_neutral(sc, tq, tq + WTABLE_WORDS, tbl, wave_top, R, flip[j]);
             if (R.is0) verdict[base + j] = (r_ok[j] && neutral) ? 1 : 0;
         });
     }

@@ -48,10 +48,10 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.c25519_amd_version()
     # per element: the larger of the two per-lane table formats (two 9-row window tables of the fast path in packed
     # 128-byte rows, 576 words; the reference-order kernels' 16-row 4-fold table of 40-limb rows is 640), the (X, Y, Z, prefix) projective scratch (the fast path's decoded points), and the
-    # fast path's scalars (sigma as 14 words of comb columns, rho, tau), flags, slow list, the walk's element order and their counters
+    # fast path's scalars (sigma as 14 words of comb columns, rho, tau), flags, slow list, the walk's element order, the quad path's two point flags and the counters
     r4 = lambda x: (x + 3) // 4 * 4  # noqa: E731
     for n in (64, 65, 1 << 20):
-        words = n * 640 + 4 * r4(10 * n) + r4(14 * n) + 2 * r4(5 * n) + 3 * r4(n) + 4
+        words = n * 640 + 4 * r4(10 * n) + r4(14 * n) + 2 * r4(5 * n) + 5 * r4(n) + 4
         assert lib.ed25519_VerifySignature_scratch_bytes(n) == 4 * words
 
 

@@ -57,7 +57,7 @@ def test_roofline_object_from_the_committed_measurements():
 
 def test_executed_macs_are_counted_from_the_device_source():
     """roofline.valu.executed_macs_per_op comes from profiles/rNN_executed_macs.json, which tools/executed_macs.py writes by
-    running the device source on the C model of the gfx950 primitives and counting v_mad_u64_u32: a fresh count equals
+    running the device source on the C model of the gfx950 primitives and counting v_mad_u64_u32 / v_mad_i64_i32: a fresh count equals
     the committed file for all three passes, the ladder's count agrees with the ISA's 739 MADs per step
     (profiles/r04_isa_mix.txt, tools/cycle_probe.py), and bench.py uses the file."""
     bench = load(os.path.join(ROOT, "bench.py"), "c25519_bench_macs")
@@ -77,6 +77,60 @@ def test_executed_macs_are_counted_from_the_device_source():
     # executed <= the reference's algorithmic count for the re-designed passes, a few per cent above it for the ladder
     assert 1.0 < used["x25519"] / bench.MACS_PER_OP["x25519"] < 1.05
     assert used["sign"] < 0.5 * bench.MACS_PER_OP["sign"] and used["verify"] < 0.8 * bench.MACS_PER_OP["verify"]
+
+
+def test_valu_issue_figures_are_the_counter_files_arithmetic():
+    """roofline.*.valu.issue (north_star: "VALU-busy against chip peak"): per kernel of a pass, from the committed
+    rocprofv3 counter passes and the committed instruction classes of the kernels' hot loops (tools/valu_issue.py) -- recomputed
+    here by hand from the same two files, for the ladder, the verification walk and points kernels and the signing walk."""
+    import glob
+    bench = load(os.path.join(ROOT, "bench.py"), "c25519_bench_issue")
+    vi = load(os.path.join(ROOT, "tools", "valu_issue.py"), "c25519_valu_issue")
+    pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))[-1]
+    cls_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_isa_classes.json")))[-1]
+    with open(pmc_path) as f:
+        pmc = json.load(f)
+    with open(cls_path) as f:
+        cls = json.load(f)
+    seen = 0
+    for wl in ("x25519", "verify", "sign"):
+        got = bench.valu_issue(bench.PASS_KERNELS[wl])
+        assert got and os.path.basename(pmc_path) in got["source"] and os.path.basename(cls_path) in got["source"]
+        cyc = busy = 0.0
+        for k, r in got["per_kernel"].items():
+            rec = vi.find(pmc, k)
+            simd_cycles = rec["GRBM_GUI_ACTIVE"] / 8                       # shader cycles the dispatch was resident, per XCD
+            per_simd = rec["SQ_INSTS_VALU"] / 1024
+            assert abs(r["simd_cycles"] - simd_cycles) <= 1 and abs(r["valu_insts_per_simd"] - per_simd) <= 1
+            assert abs(r["valu_busy"] - rec["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * simd_cycles)) < 1e-3
+            c = vi.find(cls, k)
+            if c:
+                m = c.get("hot_loop") or c["whole_kernel"]
+                assert m["mad64"] + m["other_four_cycle"] + m["vop2"] == m["valu"]
+                n2 = per_simd * m["vop2"] / m["valu"]
+                assert abs(r["valu_issue_util"] - ((per_simd - n2) * 4 + n2 * 2) / simd_cycles) < 1e-3
+                assert 0.3 < r["valu_issue_util"] < 1.05
+                seen += 1
+            cyc += simd_cycles
+            busy += r["valu_busy"] * simd_cycles
+        assert abs(got["valu_busy"] - busy / cyc) < 1e-3
+    assert seen >= 5                                                       # ladder, walk, points, scalars, sign_mult, ...
+    # the ladder's loop in the committed classes is the loop the issue model prices (739 MADs per step)
+    assert vi.find(cls, "k_x25519_ladder")["hot_loop"]["mad64"] == 739
+
+
+def test_live_peak_replaces_the_committed_one_and_keeps_it_beside():
+    bench = load(os.path.join(ROOT, "bench.py"), "c25519_bench_live")
+    r = bench.roofline_for("sign", 1 << 20, 1.25)
+    v = dict(r["valu"])
+    committed, frac0 = v["peak"], v["frac"]
+    bench.apply_live_peak(v, {"v_mad_u64_u32": 36.0e12})
+    assert v["peak"] == v["peak_live"] == 36.0 and v["peak_committed"] == committed and v["frac_vs_committed_peak"] == frac0
+    assert abs(v["frac"] - v["achieved"] / 36.0) < 1e-3 and v["peak_policy"].startswith("live")
+    assert abs(v["frac_executed"] / v["frac"] - v["executed_macs_per_op"] / v["algorithmic_macs_per_op"]) < 1e-3
+    w = dict(r["valu"])
+    bench.apply_live_peak(w, None)                                         # no live measurement: the committed peak, said so
+    assert w["peak"] == committed and w["peak_live"] is None and w["frac"] == frac0 and w["peak_policy"].startswith("committed")
 
 
 def test_expected_digests_cover_every_rank_of_the_scaling_run():
