@@ -263,7 +263,7 @@ C25519_DEV u32 invert(u32* lds, const Lane& L, u32 z)
     fe f, r;
     get_fe(f, lds, L.row);
     wave_fence();
-    fe_invert_safegcd(r, f);
+    fe_invert_quad(r, f);                                  // (the row's sixteen lanes hold f: every quad of them does)
     if (L.c == 0) {
 #pragma unroll
         for (int i = 0; i < 10; i++) lds[L.row * SLOT_WORDS + A_OFF + i] = r.v[i];

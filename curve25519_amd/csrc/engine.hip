@@ -1194,6 +1194,18 @@ __global__ void __launch_bounds__(64) k_fe_selftest(void* out, const void* a, co
     store32(out, i, ow);
 }
 
+// op 14 (the division steps on a quad of lanes, safegcd25519.cuh): FOUR lanes per record, all on the same values
+__global__ void __launch_bounds__(64) k_fe_selftest_quad(void* out, const void* a, const void* b, size_t n, int op)
+{
+    const size_t i = (size_t)blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (i >= n) return;                                   // (whole quads leave)
+    u32 aw[8], bw[8], ow[8];
+    load32(aw, a, i);
+    load32(bw, b, i);
+    fe_selftest_op(ow, aw, bw, op);
+    if ((threadIdx.x & 3) == 0) store32(out, i, ow);
+}
+
 __global__ void __launch_bounds__(64) k_sc_selftest(void* out, const void* a, const void* b, size_t n, int op)
 {
     const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -2017,7 +2029,8 @@ int c25519_amd_fe_selftest(unsigned char* out, const unsigned char* a, const uns
     if (n == 0) return 0;
     return run_batch(n, { Arr{ a, nullptr, 32 }, Arr{ b, nullptr, 32 }, Arr{ nullptr, out, 32 } },
                      [&](void** d, size_t c, size_t, hipStream_t st) -> int {
-                         k_fe_selftest<<<grid_for(c, 64), 64, 0, st>>>(d[2], d[0], d[1], c, op);
+                         if (op == 14) k_fe_selftest_quad<<<grid_for(c, 16), 64, 0, st>>>(d[2], d[0], d[1], c, op);
+                         else k_fe_selftest<<<grid_for(c, 64), 64, 0, st>>>(d[2], d[0], d[1], c, op);
                          C25519_TRY(hipGetLastError());
                          return 0;
                      });

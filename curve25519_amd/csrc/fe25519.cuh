@@ -450,6 +450,20 @@ C25519_DEV void fe_invert(fe& r, const fe& z)
 #endif
 }
 
+// r = 1 / z where the four lanes of an aligned quad (lane & 3; all active) hold the same z: the division steps' three pairs on
+// three lanes (sg_divsteps30_quad) -- the operations that have a quad (quad25519.cuh) or a wave (coop25519.cuh) to themselves
+C25519_DEV void fe_invert_quad(fe& r, const fe& z)
+{
+#if C25519_INVERT_SAFEGCD
+    u32 w[8], o[8];
+    fe_to_words(w, z);
+    sg_invert_words_quad(o, w);
+    fe_from_words(r, o);
+#else
+    fe_invert_fermat(r, z);
+#endif
+}
+
 // r = x^((p-5)/8) = x^(2^252 - 3)
 C25519_DEV void fe_pow2523(fe& r, const fe& x)
 {

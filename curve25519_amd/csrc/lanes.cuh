@@ -353,6 +353,7 @@ C25519_DEV void fe_selftest_op(u32 (&ow)[8], const u32 (&aw)[8], const u32 (&bw)
     case 10: fe_mul121665_add(r, x, y); break;                // x + 121665 y
     case 12: fe_invert_fermat(r, x); break;                   // 1/x the reference's way: x^(p-2)
     case 13: fe_invert_safegcd(r, x); break;                  // 1/x by division steps (safegcd25519.cuh)
+    case 14: fe_invert_quad(r, x); break;                     // ... with a quad of lanes on the same x (k_fe_selftest_quad)
     default: fe_mul_small(r, x, 9); break;                    // 9 x
     }
     fe_to_words(ow, r);

@@ -168,7 +168,7 @@ C25519_DEV void x25519_element(void* out, const void* pk, void* sk, size_t e)
 #pragma unroll 1
     for (int i = 0; i < 3; i++) mont_double(PX, PZ);
     fe zi;
-    fe_invert(zi, PZ);                                 // z = 0 gives 0, like the reference's z^(p-2)
+    fe_invert_quad(zi, PZ);                            // z = 0 gives 0, like the reference's z^(p-2)
     fe_mul(PX, PX, zi);
     u32 w[8];
     fe_to_words(w, PX);
@@ -403,7 +403,7 @@ C25519_DEV void encode_point(u32 (&enc)[8], const fe& own)
 {
     fe Z, zi, a;
     fe_qperm<3, 3, 3, 3>(Z, own);
-    fe_invert(zi, Z);
+    fe_invert_quad(zi, Z);
     fe_mul(a, own, zi);                                    // q0: x   q1: y
     u32 w[8];
     fe_to_words(w, a);
@@ -469,7 +469,7 @@ C25519_DEV void public_fast_element(void* pk, void* sk, size_t e, const u32* __r
     fe_qperm<3, 3, 3, 3>(Z, own);
     fe_add(t, Z, Y);  fe_carry32(num, t);
     fe_sub(t, Z, Y);  fe_carry32(den, t);
-    fe_invert(zi, den);                                    // Z = Y (the neutral element) gives 0, like the reference's inversion
+    fe_invert_quad(zi, den);                               // Z = Y (the neutral element) gives 0, like the reference's inversion
     fe_mul(num, num, zi);
     fe_to_words(w, num);
     if (R.is0) store32(pk, e, w);

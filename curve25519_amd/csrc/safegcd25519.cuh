@@ -29,25 +29,17 @@ constexpr u32 SG_P_INV30 = 0x179435e5u;                  // p^-1 mod 2^30
 struct sg30 { i32 v[9]; };                               // sum v[i] 2^(30 i); v[0..7] in [0, 2^30), v[8] signed
 struct sg_mat { i32 u, v, q, r; };                       // one batch's transition matrix, scaled by 2^30
 
-// 30 division steps on the low words of f (odd) and g: zeta' and the matrix t with  2^30 (f', g') = t (f, g)
+// 30 division steps on the low words of f (odd) and g: zeta' and the matrix t with  2^30 (f', g') = t (f, g).
+// The steps run in the UNSHIFTED form: at step i the pair (X, Y) is (f, g) 2^i, (u, q) or (v, r) -- "g odd" is bit i of Y(f, g), g
+// is never halved, and every pair runs the same recurrence
+//      Y <- Y + (g odd ? (swap ? -X : X) : 0)        X <- 2 (swap ? the old Y : X)          swap: g odd and zeta < 0
+// (the halving of g and the doubling of the matrix's f-row are the one doubling of X; all of it mod 2^32, which keeps the low
+// 30 bits of f and g and the whole matrix exact); zeta <- -zeta - 2 on a swap, zeta - 1 otherwise.  sg_steps30 (valu_gfx950.cuh;
+// the CPU model's is valu_model.h) is the thirty steps' instruction sequence: 17 a step, no secret-dependent branch or address.
 C25519_DEV i32 sg_divsteps30(i32 zeta, u32 f, u32 g, sg_mat& t)
 {
     u32 u = 1, v = 0, q = 0, r = 1;
-#pragma unroll
-    for (int i = 0; i < 30; i++) {
-        const u32 c1 = (u32)(zeta >> 31);                // all-ones: zeta < 0 (delta > 0)
-        const u32 c2 = (u32)0 - (g & 1u);                // all-ones: g odd
-        const u32 m = c1 & c2;                           // ... both: the step that swaps
-        const u32 n = m >> 31;
-        // g odd: g <- g + f, or g - f where zeta < 0; (f ^ c1) - c1 negates, and under an all-or-nothing mask
-        // ((f ^ c1) - c1) & c2 = ((f ^ c1) & c2) + n: one three-input logic op and one three-input add per variable
-        g = g + ((f ^ c1) & c2) + n;
-        q = q + ((u ^ c1) & c2) + n;
-        r = r + ((v ^ c1) & c2) + n;
-        zeta = (i32)(((u32)zeta ^ m) - 1u);              // zeta <- -zeta - 2 on a swap, zeta - 1 otherwise
-        f += g & m;  u += q & m;  v += r & m;            // swap: the new f is the old g's successor
-        g >>= 1;  u <<= 1;  v <<= 1;
-    }
+    sg_steps30(zeta, f, g, u, q, v, r);
     t.u = (i32)u; t.v = (i32)v; t.q = (i32)q; t.r = (i32)r;
     return zeta;
 }
@@ -111,11 +103,9 @@ C25519_DEV void sg_normalize(sg30& d, i32 sign)
     for (int i = 0; i < 8; i++) { d.v[i + 1] += d.v[i] >> 30;  d.v[i] &= SG_M30; }
 }
 
-// out = 1 / in mod p as canonical words; in: canonical words of a value in [0, p).  0 -> 0.
-C25519_DEV void sg_invert_words(u32 (&out)[8], const u32 (&in)[8])
+// 30-bit limbs of 256-bit words (limb i = bits 30 i .. 30 i + 29) and back
+C25519_DEV void sg_from_words(sg30& g, const u32 (&in)[8])
 {
-    sg30 f, g, d, e;
-    // 30-bit limbs of the input: limb i = bits 30 i .. 30 i + 29
     g.v[0] = (i32)(in[0] & (u32)SG_M30);
 #pragma unroll
     for (int i = 1; i < 8; i++) {
@@ -123,12 +113,25 @@ C25519_DEV void sg_invert_words(u32 (&out)[8], const u32 (&in)[8])
         g.v[i] = (i32)(alignbit32(in[w + 1], in[w], s) & (u32)SG_M30);
     }
     g.v[8] = (i32)(in[7] >> 16);
-    f.v[0] = SG_M30 - 18;                                // p = 2^255 - 19
+}
+C25519_DEV void sg_to_words(u32 (&out)[8], const sg30& d)
+{
+    out[0] = (u32)d.v[0] | ((u32)d.v[1] << 30);
 #pragma unroll
-    for (int i = 1; i < 8; i++) f.v[i] = SG_M30;
-    f.v[8] = (1 << 15) - 1;
+    for (int w = 1; w < 8; w++) {
+        const int lo = (32 * w) / 30, s = 32 * w - 30 * lo;          // word w starts s = 2 w bits into limb lo = w: two limbs cover it
+        out[w] = ((u32)d.v[lo] >> s) | ((u32)d.v[lo + 1] << (30 - s));
+    }
+}
+C25519_DEV i32 sg_p_limb(int i) { return i == 0 ? SG_M30 - 18 : i == 8 ? (1 << 15) - 1 : SG_M30; }    // p = 2^255 - 19
+
+// out = 1 / in mod p as canonical words; in: canonical words of a value in [0, p).  0 -> 0.
+C25519_DEV void sg_invert_words(u32 (&out)[8], const u32 (&in)[8])
+{
+    sg30 f, g, d, e;
+    sg_from_words(g, in);
 #pragma unroll
-    for (int i = 0; i < 9; i++) { d.v[i] = 0; e.v[i] = 0; }
+    for (int i = 0; i < 9; i++) { f.v[i] = sg_p_limb(i); d.v[i] = 0; e.v[i] = 0; }
     e.v[0] = 1;
     i32 zeta = -1;
 #pragma unroll 1
@@ -140,12 +143,70 @@ C25519_DEV void sg_invert_words(u32 (&out)[8], const u32 (&in)[8])
     }
     // g = 0 and f = +-1 now (+-p for in = 0, where d = 0): 1/in = sign(f) d
     sg_normalize(d, f.v[8]);
-    out[0] = (u32)d.v[0] | ((u32)d.v[1] << 30);
+    sg_to_words(out, d);
+}
+
+// The same value by the FOUR LANES OF AN ALIGNED QUAD (lane & 3; all four active, all holding the same `in`): what an operation
+// with a quad (quad25519.cuh) or a wave (coop25519.cuh: the sixteen lanes of a row) to itself runs.  Both halves of a batch split:
+//  * the thirty steps: one pair per lane (sg_divsteps30_quad's recurrences; lane 0 (f, g), lane 1 (u, q), lane 2 (v, r));
+//  * the matrix application: lane 0 computes the new f, lane 1 the new g, lane 2 the new d, lane 3 the new e -- a lane keeps
+//    `own` (the number it computes) and `other` (its partner's: lane ^ 1), its row of the matrix as (a, b) with
+//    own' = (a own + b other [+ p md]) / 2^30: (u, v) on the even lanes, (r, q) on the odd ones; the partners then swap their
+//    results (nine v_mov_b32_dpp quad_perm:[1,0,3,2]).  The multiple of p that makes the division exact is d's and e's only
+//    (`de`: all-ones on lanes 2, 3); the formula for md is symmetric in (own, other) with (a, b).
+// 20 multiply-adds and ~75 other instructions a batch instead of 76 and ~100; ~8 300 instructions an inversion against the one
+// lane's ~13 700.
+template <int CTRL>
+C25519_DEV u32 sg_quad_perm(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
+
+C25519_DEV void sg_invert_words_quad(u32 (&out)[8], const u32 (&in)[8])
+{
+    const u32 q = threadIdx.x & 3u;
+    const u32 lane1 = q == 1 ? 0xffffffffu : 0u, lane2 = q == 2 ? 0xffffffffu : 0u;
+    const u32 odd = (u32)0 - (q & 1u), de = (u32)0 - (q >> 1);
+    sg30 own, other;
+    {
+        sg30 z;
+        sg_from_words(z, in);
 #pragma unroll
-    for (int w = 1; w < 8; w++) {
-        const int lo = (32 * w) / 30, s = 32 * w - 30 * lo;          // word w starts s = 2 w bits into limb lo = w: two limbs cover it
-        out[w] = ((u32)d.v[lo] >> s) | ((u32)d.v[lo + 1] << (30 - s));
+        for (int i = 0; i < 9; i++) {                     // lane 0: (p, z)   lane 1: (z, p)   lane 2: (0, 1)   lane 3: (1, 0)
+            const u32 zi = (u32)z.v[i], pi = (u32)sg_p_limb(i), one = i == 0 ? 1u : 0u;
+            own.v[i] = (i32)((((zi & odd) | (pi & ~odd)) & ~de) | (one & odd & de));
+            other.v[i] = (i32)((((pi & odd) | (zi & ~odd)) & ~de) | (one & ~odd & de));
+        }
     }
+    i32 zeta = -1;
+#pragma unroll 1
+    for (int it = 0; it < 20; it++) {
+        // lane 0's pair is (f, g) = (own, other); lanes 1 and 2 start from the identity's columns; lane 3 idles along
+        u32 X = (((u32)own.v[0] | ((u32)own.v[1] << 30)) & ~(lane1 | lane2)) | (lane1 & 1u);
+        u32 Y = (((u32)other.v[0] | ((u32)other.v[1] << 30)) & ~(lane1 | lane2)) | (lane2 & 1u);
+        sg_steps30_quad(zeta, X, Y);
+        // u = X of lane 1, q = Y of lane 1, v = X of lane 2, r = Y of lane 2;  (a, b) = (u, v) on even lanes, (r, q) on odd ones
+        const i32 a = (i32)sg_quad_perm<0x99>((X & ~lane2) | (Y & lane2));     // quad_perm:[1,2,1,2]
+        const i32 b = (i32)sg_quad_perm<0x66>((Y & ~lane2) | (X & lane2));     // quad_perm:[2,1,2,1]
+        const i32 s_own = own.v[8] >> 31, s_other = other.v[8] >> 31;          // a negative d (e) adds its matrix column to the multiple of p
+        i32 md = ((a & s_own) + (b & s_other)) & (i32)de;
+        i64 c = mad2_i64_i32(0, a, own.v[0], b, other.v[0]);
+        md = (md - (i32)((SG_P_INV30 * (u32)c + (u32)md) & (u32)SG_M30)) & (i32)de;
+        c = mad_i64_i32(c, -19, md);                      // p = (-19, 0, ..., 0, 2^15) in signed limbs
+        c >>= 30;
+#pragma unroll
+        for (int i = 1; i < 9; i++) {
+            c = mad2_i64_i32(c, a, own.v[i], b, other.v[i]);
+            if (i == 8) c = mad_i64_i32(c, 1 << 15, md);
+            own.v[i - 1] = (i32)c & SG_M30;  c >>= 30;
+        }
+        own.v[8] = (i32)c;
+#pragma unroll
+        for (int i = 0; i < 9; i++) other.v[i] = (i32)sg_quad_perm<0xb1>((u32)own.v[i]);   // quad_perm:[1,0,3,2]
+    }
+    // g = 0 and f = +-1 now (+-p for in = 0, where d = 0): 1/in = sign(f) d -- d is lane 2's own, f lane 0's
+    sg30 d;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d.v[i] = (i32)sg_quad_perm<0xaa>((u32)own.v[i]);           // quad_perm:[2,2,2,2]
+    sg_normalize(d, (i32)sg_quad_perm<0x00>((u32)own.v[8]));
+    sg_to_words(out, d);
 }
 
 }  // namespace c25519

@@ -91,6 +91,47 @@ C25519_DEV int64_t mad2_i64_i32(int64_t acc, int32_t x0, int32_t y0, int32_t x1,
     return acc;
 }
 
+// Thirty Bernstein-Yang division steps on low words (safegcd25519.cuh: sg_step_pair is the arithmetic, these are its instruction
+// sequences; one asm statement for all thirty, so that no asm boundary is padded and the compiler does not re-derive the step's
+// conditions its own, longer way -- 14 instructions a step from the C++ source, 10 here).  At step i, with g0 = the (f, g) pair's Y:
+//      c2 = bit i of g0 as a mask (v_bfe_i32)     c1 = zeta < 0 (v_ashrrev_i32)     m = c1 & c2     n = m >> 31
+//      per pair:  T = (X ^ c1) & c2 (v_bitop3_b32, truth table 0x28)   Y += T + n (v_add3_u32)   X = (X + (Y & m)) << 1 (v_and_b32, v_add_lshl_u32)
+//      zeta = (zeta ^ m) - 1 (v_xad_u32)
+#define C25519_SG_COND(I, G0)                    \
+    "v_bfe_i32 %[c2], " G0 ", " #I ", 1\n\t"      \
+    "v_ashrrev_i32 %[c1], 31, %[zeta]\n\t"        \
+    "v_and_b32 %[m], %[c1], %[c2]\n\t"            \
+    "v_lshrrev_b32 %[n], 31, %[m]\n\t"
+#define C25519_SG_PAIR(X, Y)                                 \
+    "v_bitop3_b32 %[t], " X ", %[c1], %[c2] bitop3:0x28\n\t"  \
+    "v_add3_u32 " Y ", " Y ", %[t], %[n]\n\t"                 \
+    "v_and_b32 %[t], " Y ", %[m]\n\t"                         \
+    "v_add_lshl_u32 " X ", " X ", %[t], 1\n\t"
+#define C25519_SG_ZETA() "v_xad_u32 %[zeta], %[zeta], %[m], -1\n\t"
+#define C25519_SG_STEP1(I) C25519_SG_COND(I, "%[y0]") C25519_SG_PAIR("%[x0]", "%[y0]") C25519_SG_PAIR("%[x1]", "%[y1]") C25519_SG_PAIR("%[x2]", "%[y2]") C25519_SG_ZETA()
+#define C25519_SG_STEPQ(I) "v_mov_b32_dpp %[g0], %[y0] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    C25519_SG_COND(I, "%[g0]") C25519_SG_PAIR("%[x0]", "%[y0]") C25519_SG_ZETA()
+#define C25519_SG_30(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7) S(8) S(9) S(10) S(11) S(12) S(13) S(14) S(15) S(16) S(17) S(18) S(19) \
+    S(20) S(21) S(22) S(23) S(24) S(25) S(26) S(27) S(28) S(29)
+
+// one lane: the pairs (f, g) 2^i, (u, q), (v, r)
+C25519_DEV void sg_steps30(int32_t& zeta, u32& f, u32& g, u32& u, u32& q, u32& v, u32& r)
+{
+    u32 c1, c2, m, n, t;
+    asm(C25519_SG_30(C25519_SG_STEP1)
+        : [zeta] "+v"(zeta), [x0] "+v"(f), [y0] "+v"(g), [x1] "+v"(u), [y1] "+v"(q), [x2] "+v"(v), [y2] "+v"(r),
+          [c1] "=&v"(c1), [c2] "=&v"(c2), [m] "=&v"(m), [n] "=&v"(n), [t] "=&v"(t));
+}
+// a quad of lanes, one pair each; the step's "g odd" comes from lane 0 of the quad.  (The DPP move reads the Y that v_add3_u32
+// wrote three instructions earlier -- beyond the two wait states a DPP source needs; the s_nop covers the first step.)
+C25519_DEV void sg_steps30_quad(int32_t& zeta, u32& X, u32& Y)
+{
+    u32 c1, c2, m, n, t, g0;
+    asm("s_nop 1\n\t" C25519_SG_30(C25519_SG_STEPQ)
+        : [zeta] "+v"(zeta), [x0] "+v"(X), [y0] "+v"(Y),
+          [c1] "=&v"(c1), [c2] "=&v"(c2), [m] "=&v"(m), [n] "=&v"(n), [t] "=&v"(t), [g0] "=&v"(g0));
+}
+
 // acc += sum x[t]*y[t]: one asm statement per column, so the compiler cannot reassociate the chain (it would move
 // the carry-in to the end and re-create a separate 64-bit add) and does not pad every MAD with a wait state (it pads
 // asm boundaries only).  The SGPR pair receives the (never set) carry-out.

@@ -174,8 +174,10 @@ unsigned long long emul_mad_overflow_count(void) { return emul_mad_overflows; }
 // v_mad_u64_u32 instructions issued since the last call (valu_model.h: mad64)
 unsigned long long emul_mad_count_take(void) { return __atomic_exchange_n(&emul_mad_count, 0ULL, __ATOMIC_RELAXED); }
 
+static void emul_fe_op_quad(unsigned char* out, const unsigned char* a, const unsigned char* b, size_t n, int op);
 void emul_fe_op(unsigned char* out, const unsigned char* a, const unsigned char* b, size_t n, int op)
 {
+    if (op == 14) return emul_fe_op_quad(out, a, b, n, op);        // four lock-step lanes per record (k_fe_selftest_quad)
     for (size_t i = 0; i < n; i++) {
         u32 aw[8], bw[8], ow[8];
         rd32(aw, a, i); rd32(bw, b, i);
@@ -579,6 +581,20 @@ void emul_coop_x25519_two_waves(unsigned char* out, const unsigned char* pk, uns
     std::vector<u32> lds(coop::X2_LDS_WORDS);
     for (size_t e = 0; e < n; e++)
         emul_coop::run_block(128, [&] { coop::x25519_two_waves(lds.data(), out, pk, sk, e); });
+}
+
+static void emul_fe_op_quad(unsigned char* out, const unsigned char* a, const unsigned char* b, size_t n, int op)
+{
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    for (size_t base = 0; base < n; base += 16)
+        emul_coop::run_block(64, [&] {
+            const size_t i = base + (threadIdx.x >> 2);
+            if (i >= n) return;
+            u32 aw[8], bw[8], ow[8];
+            rd32(aw, a, i); rd32(bw, b, i);
+            fe_selftest_op(ow, aw, bw, op);
+            if ((threadIdx.x & 3) == 0) wr32(out, i, ow);
+        });
 }
 
 // ---- four lanes per element (csrc/quad25519.cuh): a wave of 64 lock-step lanes carries 16 elements; the kernel is

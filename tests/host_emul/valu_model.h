@@ -108,6 +108,32 @@ inline int64_t mad_i64_i32(int64_t acc, int32_t x, int32_t y)      // v_mad_i64_
     return r;
 }
 inline int64_t mad2_i64_i32(int64_t acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1) { return mad_i64_i32(mad_i64_i32(acc, x0, y0), x1, y1); }
+// thirty division steps on low words (valu_gfx950.cuh: sg_steps30 / sg_steps30_quad), instruction by instruction
+inline void sg_model_pair(u32& X, u32& Y, u32 c1, u32 c2, u32 m, u32 n)
+{
+    const u32 t = (X ^ c1) & c2;                  // v_bitop3_b32 0x28
+    Y = Y + t + n;                                // v_add3_u32
+    X = (X + (Y & m)) << 1;                       // v_and_b32, v_add_lshl_u32
+}
+inline void sg_steps30(int32_t& zeta, u32& f, u32& g, u32& u, u32& q, u32& v, u32& r)
+{
+    for (int i = 0; i < 30; i++) {
+        const u32 c2 = (u32)0 - ((g >> i) & 1u), c1 = (u32)(zeta >> 31), m = c1 & c2, n = m >> 31;
+        sg_model_pair(f, g, c1, c2, m, n);
+        sg_model_pair(u, q, c1, c2, m, n);
+        sg_model_pair(v, r, c1, c2, m, n);
+        zeta = (int32_t)(((u32)zeta ^ m) - 1u);   // v_xad_u32
+    }
+}
+inline void sg_steps30_quad(int32_t& zeta, u32& X, u32& Y)
+{
+    for (int i = 0; i < 30; i++) {
+        const u32 g0 = (u32)__builtin_amdgcn_update_dpp(0, (int)Y, 0, 0xf, 0xf, true);     // quad_perm:[0,0,0,0]
+        const u32 c2 = (u32)0 - ((g0 >> i) & 1u), c1 = (u32)(zeta >> 31), m = c1 & c2, n = m >> 31;
+        sg_model_pair(X, Y, c1, c2, m, n);
+        zeta = (int32_t)(((u32)zeta ^ m) - 1u);
+    }
+}
 inline u64 mad_chain5(u64 acc, const u32 (&x)[5], const u32 (&y)[5])
 {
     for (int t = 0; t < 5; t++) acc = mad64(acc, x[t], y[t]);

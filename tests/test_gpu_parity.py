@@ -73,7 +73,7 @@ def test_field_layer_against_big_integers(api):
         vectors.check_field(op, out, pairs)
     # 1 / x three ways (op 4: what the kernels run; 12: x^(p-2); 13: division steps) on the wider set of inversion patterns
     pairs, a, b = vectors.inversion_cases()
-    for op in (4, 12, 13):
+    for op in (4, 12, 13, 14):
         out = np.empty((len(pairs), 32), np.uint8)
         assert L.c25519_amd_fe_selftest(out.ctypes.data, a.ctypes.data, b.ctypes.data, len(pairs), op) == 0
         vectors.check_field(op, out, pairs)

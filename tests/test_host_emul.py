@@ -106,7 +106,7 @@ def test_inversions_agree_with_big_integers(emul):
     exponentiation x^(p-2) and the constant-time division steps of safegcd25519.cuh; 0 (and p, 2p) give 0.  The model of
     v_mad_i64_i32 reports a signed wrap (the emul fixture's overflow count)."""
     pairs, a, b = vectors.inversion_cases()
-    for op in (4, 12, 13):
+    for op in (4, 12, 13, 14):
         out = np.empty((len(pairs), 32), np.uint8)
         emul.emul_fe_op(ptr(out), ptr(a), ptr(b), len(pairs), op)
         vectors.check_field(op, out, pairs)

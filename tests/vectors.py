@@ -35,14 +35,14 @@ FIELD_OPS = {
     4: lambda x, y: pow(x, P - 2, P), 5: lambda x, y: pow(x, (P - 5) // 8, P), 6: lambda x, y: x,
     7: lambda x, y: (x - y) * (x + y), 8: lambda x, y: x * x - y, 9: lambda x, y: 2 * x * x + x,
     10: lambda x, y: x + 121665 * y, 11: lambda x, y: 9 * x,
-    12: lambda x, y: pow(x, P - 2, P), 13: lambda x, y: pow(x, P - 2, P),
+    12: lambda x, y: pow(x, P - 2, P), 13: lambda x, y: pow(x, P - 2, P), 14: lambda x, y: pow(x, P - 2, P),
 }
 # ops 8 and 9 take a reduced second operand (the contract of fe_sqr_sub / fe_sqr2_add_sub)
 FIELD_OPS_B_REDUCED = {8, 9}
 
 
 def inversion_cases():
-    """256-bit patterns for the inversions (op 4: what the kernels run, 12: the reference's exponentiation, 13: division steps):
+    """256-bit patterns for the inversions (op 4: what the kernels run, 12: the reference's exponentiation, 13: division steps, 14: division steps on a quad of lanes):
     every power of two and its neighbours, the same below p, below 2p and below 2^256 (non-canonical inputs are reduced first),
     small values, values of the form (p +- 1) / 2^k, seeded random.  The division steps' path depends on the bit patterns of p and
     the input (runs of zeros, of ones, values whose quotient sequence is long), so this is wider than field_cases()."""

@@ -69,6 +69,7 @@ def measure(lib_path, n=1 << 20, fused=False, reps=6, verbose=False):
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     L.c25519_amd_tunable_set.argtypes = [C.c_char_p, C.c_long]
     assert L.c25519_amd_tunable_set(b"XF_SPLIT", 0 if fused else 1) == 0          # the probe library's own knob table
+    assert L.c25519_amd_tunable_set(b"QUAD_MAX", 0) == 0                           # the stamps are the one-lane kernels': no quads at 2^12 .. 2^15
     try:
         assert L.c25519_amd_probe_set(p(buf)) == 0
         best = None
@@ -87,6 +88,7 @@ def measure(lib_path, n=1 << 20, fused=False, reps=6, verbose=False):
         L.c25519_amd_probe_set(None)
     finally:
         L.c25519_amd_tunable_set(b"XF_SPLIT", -1)
+        L.c25519_amd_tunable_set(b"QUAD_MAX", -1)
     return best
 
 
