@@ -239,6 +239,13 @@ struct ThreadState {
     bool bctx_valid = false;
     void* hbuf[SETS][SLOTS] = {};          // pinned host staging (hipHostMalloc)
     size_t hcap[SETS][SLOTS] = {};
+    // The completion word of a call of ONE element (host_pipeline.hpp: zero-copy calls): pinned host memory the call's last
+    // kernel stores done_seq into behind its results, and the calling thread spins on -- the runtime's own completion path
+    // (event record + hipEventSynchronize) costs 4.6 us more (tools/scratch/launch_latency.hip, profiles/r06_launch_latency.txt).
+    // done_offered: run_batch is inside `launch` and would wait for the word; done_taken: a kernel of this call has it.
+    unsigned* done_word = nullptr;
+    unsigned done_seq = 0;
+    bool done_offered = false, done_taken = false;
     // work scratch of the *_dev entry points: grow-only slabs, CALLER_SLABS PER DEVICE (a thread may drive several GPUs, see
     // multi_device.hip).  Consecutive calls on one stream reuse one slab in stream order; calls on up to CALLER_SLABS
     // different streams get a slab each and may overlap on the device (a caller that splits a mixed batch over streams
@@ -442,6 +449,8 @@ struct ThreadState {
                 *e = nullptr;
             }
         }
+        if (done_word) { (void)hipHostFree(done_word); done_word = nullptr; }
+        done_offered = done_taken = false;
         if (vctx) { (void)hipMemset(vctx, 0, 2080); (void)hipFree(vctx); vctx = nullptr; }
         vctx_valid = false;
         if (bctx) { (void)hipMemset(bctx, 0, 192); (void)hipFree(bctx); bctx = nullptr; }

@@ -261,26 +261,41 @@ __global__ void __launch_bounds__(XL_BLOCK, C25519_XF_WAVES) k_x25519_ladder(u32
 #endif
 }
 
+// The completion word of a call of ONE element through the host-pointer prototypes (capi_common.hpp: ThreadState::done_word): the
+// call's last kernel stores `seq` into pinned host memory BEHIND its results -- by the thread that stored them, or behind a wave's
+// own stores: the fence waits for every store of the wave -- and the calling thread, which spins on the word, returns 4.6 us before
+// the runtime's event would let it (profiles/r06_launch_latency.txt).  word == nullptr: nobody is waiting that way.
+struct DoneWord { u32* word; u32 seq; };
+C25519_DEV void signal_done(const DoneWord& d)
+{
+    if (d.word) {
+        __threadfence_system();
+        __hip_atomic_store(d.word, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // One operation per WAVE (coop25519.cuh): what a call of a few elements runs -- the reference's own single-call
 // prototypes above all.  Ladder, doublings, inversion and the last multiplication are cooperative (a field element
 // limb-per-lane, up to four products at a time); only the decoding of the inputs and the canonical encoding of the result
 // are the batch kernels' per-lane code, run by every lane on the same values.
 template <bool BASE9>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop(void* out, const void* pk, void* sk, size_t n)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop(void* out, const void* pk, void* sk, size_t n, DoneWord done)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::ROWQ_OFF];
     if (blockIdx.x >= n) return;
     coop::x25519_one<BASE9>(lds, coop::make_lane(threadIdx.x), out, pk, sk, blockIdx.x);
+    if (threadIdx.x == 0) signal_done(done);
 }
 
 // ... and on TWO waves per element (coop::x25519_two_waves: a ladder step in two product levels -- the differential addition with
 // x1 times the sum carried along on one wave, the doubling on the other, one workgroup barrier per step): what ONE
 // curve25519_dh_CreateSharedKey call and calls of up to 512 run -- 183 -> 168 us per call
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop2(void* out, const void* pk, void* sk, size_t n)
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop2(void* out, const void* pk, void* sk, size_t n, DoneWord done)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::X2_LDS_WORDS];
     if (blockIdx.x >= n) return;
     coop::x25519_two_waves(lds, out, pk, sk, blockIdx.x);
+    if (threadIdx.x == 0) signal_done(done);               // (wave 0 stores; wave 1 has left inside)
 }
 
 // FOUR LANES per element (quad25519.cuh): what a call of 2^12 .. 2^14 elements runs -- too many for a wave each, too few to
@@ -529,31 +544,34 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_finish(void* sig, 
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u32* __restrict__ g_tbl,
-                       const u32* __restrict__ blind_ctx)
+                       const u32* __restrict__ blind_ctx, DoneWord done)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
     if (blockIdx.x >= n) return;
     coop::keypair_one<WIDE>(lds, coop::make_lane(threadIdx.x), pub, priv, sk, blockIdx.x, g_tbl, blind_ctx);
+    if (threadIdx.x == 0) signal_done(done);
 }
 
 // curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189): S = clamp(sk) * B on the Edwards side, u = (Z + Y) / (Z - Y)
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
-k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ g_tbl)
+k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ g_tbl, DoneWord done)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
     if (blockIdx.x >= n) return;
     coop::public_fast_one<WIDE>(lds, coop::make_lane(threadIdx.x), pk, sk, blockIdx.x, g_tbl);
+    if (threadIdx.x == 0) signal_done(done);
 }
 
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32* __restrict__ g_tbl,
-                    const u32* __restrict__ blind_ctx)
+                    const u32* __restrict__ blind_ctx, DoneWord done)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
     if (blockIdx.x >= n) return;
     coop::sign_one<WIDE>(lds, coop::make_lane(threadIdx.x), sig, priv, msgs, blockIdx.x, g_tbl, blind_ctx);
+    if (threadIdx.x == 0) signal_done(done);
 }
 
 // The same three operations on FOUR lanes per element (quad25519.cuh), for calls between the per-wave kernels and the batches
@@ -602,10 +620,11 @@ __global__ void __launch_bounds__(256) k_ed25519_blinding_init(u32* ctx, const u
 // ... and with the whole wave (the wide comb's rows fetched from device memory, t * B and its affine conversion cooperative): what
 // ed25519_Blinding_Init runs unless the LDS comb is selected -- 196 -> ~70 us per context
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
-k_ed25519_blinding_init_coop(u32* ctx, const uint8_t* seed, size_t seed_len, const u32* __restrict__ wide)
+k_ed25519_blinding_init_coop(u32* ctx, const uint8_t* seed, size_t seed_len, const u32* __restrict__ wide, DoneWord done)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
     coop::blinding_init_one(lds, coop::make_lane(threadIdx.x), ctx, seed, seed_len, wide);
+    if (threadIdx.x == 0) signal_done(done);
 }
 
 // ed25519_Verify_Init (ed25519_verify.c:179-232): decompress -A (inverted parity :192-195, no validation) and
@@ -869,10 +888,14 @@ k_ed25519_verify_one_per_group(FastScratch fs, int* verdict, const void* sig, co
 // when the walk's last round drained, profiles/r03_ab_verify_structure.txt; a fixed small grid striding over the list --
 // any loop around the body makes the compiler keep ~60 field constants in registers across trips: 268 instead of 200.)
 __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_slow(FastScratch fs, int* verdict, const void* sig, const void* pk,
-                                                                     Msgs msgs, const u32* __restrict__ g_tbl)
+                                                                     Msgs msgs, const u32* __restrict__ g_tbl, DoneWord done)
 {
+    // done: a call of ONE element only (its list holds at most that element, which thread 0 of block 0 then decides)
     const u32 count = *fs.slow_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *fs.slow_report = count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *fs.slow_report = count;
+        if (count == 0) signal_done(done);
+    }
     if ((size_t)blockIdx.x * ED_BLOCK >= count) return;
     __shared__ __attribute__((aligned(16))) u32 lds_tbl[PA_WORDS * 256];
     lds_stage_words(lds_tbl, g_tbl + REF_TBL_OFFSET, REF_TBL_WORDS);
@@ -884,6 +907,7 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_slow(FastScratch
     load32(Rw, sig, 2 * i);
     load32(Sw, sig, 2 * i + 1);
     verdict[i] = ed_verify_reference_order(pkw, Rw, Sw, msgs.ptr(i), msgs.len(i), fs.tables + i * FAST_TABLE_WORDS, lds_tbl);
+    if (k == 0) signal_done(done);
 }
 
 // Same check with ONE key for the whole batch (the reference's two-phase use: Verify_Init once, many
@@ -936,22 +960,28 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_verify_check_shared(Pro
 // code: a cooperative one would be no faster), the table by the whole wave (coop::qtable_build_coop).  501 us per call in the
 // per-lane kernel (a lone lane's 192 doublings), ~130 here.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
-k_ed25519_verify_init_coop(const void* pk, size_t n, u32* ctx_rows /* n contexts, stride_words apart, the 16 rows of each */, size_t stride_words)
+k_ed25519_verify_init_coop(const void* pk, size_t n, u32* ctx_rows /* n contexts, stride_words apart, the 16 rows of each */, size_t stride_words,
+                           DoneWord done)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::Q_LDS_WORDS];
     if (blockIdx.x >= n) return;
-    coop::verify_init_one(lds, coop::make_lane(threadIdx.x), pk, blockIdx.x, ctx_rows + blockIdx.x * stride_words);
+    u32* rows = ctx_rows + blockIdx.x * stride_words;
+    coop::verify_init_one(lds, coop::make_lane(threadIdx.x), pk, blockIdx.x, rows);
+    if (threadIdx.x < 8) rows[(int)threadIdx.x - 8] = ((const u32*)pk)[blockIdx.x * 8 + threadIdx.x];   // the context's first 32 bytes: the key
+    if (threadIdx.x == 0) signal_done(done);               // (rows and key are this one wave's stores: the fence waits for them all)
 }
 
 // ed25519_Verify_Check for a call of a few pairs (the reference's prototype is a call of ONE): one pair per wave, the
 // reference's own operation order (coop::poly_mult), one shared-nothing inversion per pair.  454 us per call in the per-lane
 // kernel above (a lone lane walks 63 doublings and 96 additions); ~125 here.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
-k_ed25519_verify_check_coop(int* verdict, const void* sig, const u32* __restrict__ ctx, Msgs msgs, size_t n, const u32* __restrict__ g_tbl)
+k_ed25519_verify_check_coop(int* verdict, const void* sig, const u32* __restrict__ ctx, Msgs msgs, size_t n, const u32* __restrict__ g_tbl,
+                            DoneWord done)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::Q_LDS_WORDS];
     if (blockIdx.x >= n) return;
     coop::verify_check_one(lds, coop::make_lane(threadIdx.x), verdict, sig, ctx, msgs, blockIdx.x, g_tbl + REF_TBL_OFFSET);
+    if (threadIdx.x == 0) signal_done(done);
 }
 
 // ---- one key, a big batch: both scalars over wide combs ------------------------------------------------------------------
@@ -1304,9 +1334,20 @@ inline bool base_comb_wide() { return c25519_host::tunable_or(c25519_host::T_BAS
 // *_dev arguments: n in range, pointers 16-byte aligned and -- unless C25519_AMD_NO_PTR_CHECK is set -- device (or
 // managed) memory of the CURRENT device: a pointer of another GPU or a host pointer is an error here, not a fault
 // inside a kernel.
+// the completion word for the LAST kernel of a call of one element, if the caller (host_pipeline.hpp: run_batch on a zero-copy
+// call) is going to spin on it; taken at most once per call
+DoneWord take_done_word(size_t n)
+{
+    ThreadState& t = tls();
+    if (n != 1 || !t.done_offered || t.done_taken) return DoneWord{ nullptr, 0 };
+    t.done_taken = true;
+    return DoneWord{ t.done_word, ++t.done_seq };
+}
+
 int check_dev_args(size_t n, std::initializer_list<const void*> ptrs)
 {
-    static const bool check_owner = getenv("C25519_AMD_NO_PTR_CHECK") == nullptr;
+    static const bool check_owner_env = getenv("C25519_AMD_NO_PTR_CHECK") == nullptr;
+    const bool check_owner = check_owner_env && !c25519_host::zero_copy_call();   // (a tiny *_batch call hands over this library's own pinned staging: host_pipeline.hpp)
     if (n > ((size_t)1 << 31)) return bad_arg("batch too large (n > 2^31)");
     int dev = 0;
     if (check_owner && n) C25519_TRY(hipGetDevice(&dev));
@@ -1443,7 +1484,7 @@ int verify_run(const void* sig, const void* pk, Msgs msgs, size_t n, hipStream_t
             k_ed25519_verify_fast_walk<<<grid_for(n, WALK_BLOCK), WALK_BLOCK, 0, stream>>>(fs, verdict, n, tbl);
             C25519_TRY(hipGetLastError());
         }
-        k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl);
+        k_ed25519_verify_slow<<<grid, ED_BLOCK, 0, stream>>>(fs, verdict, sig, pk, msgs, tbl, take_done_word(n));
         C25519_TRY(hipGetLastError());
         tl_last_verify.count = report; tl_last_verify.stream = stream;
         tl_last_verify.generation = tls().generation;       // the report word and the stream die with the thread's slabs
@@ -1625,9 +1666,9 @@ static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t
         return 0;
     }
     if (x25519_coop_for(n)) {
-        if (pk && x25519_two_waves_for(n)) k_x25519_coop2<<<(unsigned)n, 128, 0, stream>>>(out, pk, sk, n);
-        else if (pk) k_x25519_coop<false><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n);
-        else    k_x25519_coop<true><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n);
+        if (pk && x25519_two_waves_for(n)) k_x25519_coop2<<<(unsigned)n, 128, 0, stream>>>(out, pk, sk, n, take_done_word(n));
+        else if (pk) k_x25519_coop<false><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n, take_done_word(n));
+        else    k_x25519_coop<true><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n, take_done_word(n));
         C25519_TRY(hipGetLastError());
         return 0;
     }
@@ -1691,8 +1732,8 @@ int curve25519_dh_CalculatePublicKey_fast_dev(void* pk, void* sk, size_t n, void
         if (wide_comb) {
             const u32* wide = nullptr;
             C25519_RC(wide_tables(&wide));
-            k_x25519_public_fast_coop<true><<<(unsigned)n, 64, 0, stream>>>(pk, sk, n, wide);
-        } else k_x25519_public_fast_coop<false><<<(unsigned)n, 64, 0, stream>>>(pk, sk, n, tbl);
+            k_x25519_public_fast_coop<true><<<(unsigned)n, 64, 0, stream>>>(pk, sk, n, wide, take_done_word(n));
+        } else k_x25519_public_fast_coop<false><<<(unsigned)n, 64, 0, stream>>>(pk, sk, n, tbl, take_done_word(n));
         C25519_TRY(hipGetLastError());
         return 0;
     }
@@ -1731,8 +1772,8 @@ static int keypair_dev(void* pub, void* priv, const void* sk, const void* blindi
         if (wide_comb) {
             const u32* wide = nullptr;
             C25519_RC(wide_tables(&wide));
-            k_ed25519_keypair_coop<true><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, wide, (const u32*)blinding);
-        } else k_ed25519_keypair_coop<false><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, tbl, nullptr);
+            k_ed25519_keypair_coop<true><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, wide, (const u32*)blinding, take_done_word(n));
+        } else k_ed25519_keypair_coop<false><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, tbl, nullptr, take_done_word(n));
         C25519_TRY(hipGetLastError());
         return 0;
     }
@@ -1786,8 +1827,8 @@ static int sign_dev(void* sig, const void* priv, const void* blinding, Msgs msgs
         if (wide_comb) {
             const u32* wide = nullptr;
             C25519_RC(wide_tables(&wide));
-            k_ed25519_sign_coop<true><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, wide, (const u32*)blinding);
-        } else k_ed25519_sign_coop<false><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, tbl, nullptr);
+            k_ed25519_sign_coop<true><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, wide, (const u32*)blinding, take_done_word(n));
+        } else k_ed25519_sign_coop<false><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, tbl, nullptr, take_done_word(n));
         C25519_TRY(hipGetLastError());
         return 0;
     }
@@ -1853,7 +1894,7 @@ int ed25519_Blinding_Init_dev(void* ctx, const void* seed, size_t seed_len, void
     if (base_comb_wide()) {
         const u32* wide = nullptr;
         C25519_RC(wide_tables(&wide));
-        k_ed25519_blinding_init_coop<<<1, 64, 0, (hipStream_t)stream>>>((u32*)ctx, (const uint8_t*)seed, seed_len, wide);
+        k_ed25519_blinding_init_coop<<<1, 64, 0, (hipStream_t)stream>>>((u32*)ctx, (const uint8_t*)seed, seed_len, wide, take_done_word(1));
     } else {
         k_ed25519_blinding_init<<<1, 256, 0, (hipStream_t)stream>>>((u32*)ctx, (const uint8_t*)seed, seed_len, tbl);
     }
@@ -1926,12 +1967,13 @@ int ed25519_Verify_Init_dev(void* ctx, const void* pk, size_t n, void* stream)
     if (!ctx || !pk) return bad_arg("null pointer");
     if (int rc = check_dev_args(n, { ctx, pk })) return rc;
     if (n == 0) return 0;
-    C25519_TRY(hipMemcpy2DAsync(ctx, 2080, pk, 32, 32, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    if (coop_for(n, 1024))                                  // a few keys: one per wave
-        k_ed25519_verify_init_coop<<<(unsigned)n, 64, 0, (hipStream_t)stream>>>(pk, n, (u32*)ctx + 8, 2080 / 4);
-    else
+    if (coop_for(n, 1024))                                  // a few keys: one per wave (which also copies its key into the context)
+        k_ed25519_verify_init_coop<<<(unsigned)n, 64, 0, (hipStream_t)stream>>>(pk, n, (u32*)ctx + 8, 2080 / 4, take_done_word(n));
+    else {
+        C25519_TRY(hipMemcpy2DAsync(ctx, 2080, pk, 32, 32, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
         k_ed25519_verify_init<QTableCanon><<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, (hipStream_t)stream>>>(
             pk, n, (u32*)ctx + 8, 2080 / 4);
+    }
     C25519_TRY(hipGetLastError());
     return 0;
 }
@@ -1960,7 +2002,7 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
     tl_last_check.ran = true;
     if (!try_wide && small) {                               // a few pairs: one per wave, the reference's order
         k_ed25519_verify_check_coop<<<(unsigned)n, 64, 0, stream>>>((int*)verdict, sig, (const u32*)ctx,
-                                                                    Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl);
+                                                                    Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl, take_done_word(n));
         C25519_TRY(hipGetLastError());
         return 0;
     }

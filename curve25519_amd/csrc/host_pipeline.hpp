@@ -323,6 +323,11 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
         }
     static const bool zero_copy_on = [] { const char* e = getenv("C25519_AMD_ZERO_COPY"); return !(e && atoi(e) == 0); }();
     const bool zero_copy = zero_copy_on && n <= ZERO_COPY_MAX_ROWS && row * n <= ZERO_COPY_MAX_BYTES && nchunks == 1 && !any_dev;
+    static const bool done_word_on = [] { const char* e = getenv("C25519_AMD_DONE_WORD"); return !(e && atoi(e) == 0); }();
+    if (zero_copy && n == 1 && done_word_on && !t.done_word) {
+        C25519_TRY(hipHostMalloc((void**)&t.done_word, 64, hipHostMallocDefault));
+        *t.done_word = 0;
+    }
     for (int l = 0; l < sets; l++)
         for (int a = 0; a < na; a++) {
             if (!arr[a].dev && !zero_copy) C25519_RC(t.reserve_dev(l, a, arr[a].elem * chunk));
@@ -356,7 +361,10 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
         if (zero_copy) {                                   // (one piece, one stream: `sequential` below)
             for (int a = 0; a < na; a++) dptr[a] = t.hbuf[l][a];
             zero_copy_call() = true;
+            t.done_taken = false;
+            t.done_offered = done_word_on && n == 1 && t.done_word != nullptr;     // a call of one: its last kernel may signal completion itself
             const int rc = launch(dptr, cnt, lo, kern);
+            t.done_offered = false;
             zero_copy_call() = false;
             C25519_RC(rc);
             C25519_TRY(hipEventRecord(t.done[l], kern));
@@ -389,7 +397,19 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
         size_t lo, cnt;
         span(c, lo, cnt);
         const int l = (int)(c % sets);
-        C25519_TRY(hipEventSynchronize(t.done[l]));
+        if (zero_copy && t.done_taken) {
+            // the call's last kernel stores done_seq behind its results (engine.hip: take_done_word / signal_done): spin on the
+            // word; the event is the way out if the stream gets past the kernel without it (a failed launch, a fault)
+            t.done_taken = false;
+            for (unsigned long spins = 1;; spins++) {
+                if (__atomic_load_n(t.done_word, __ATOMIC_ACQUIRE) == t.done_seq) break;
+                if ((spins & 0x3fff) == 0 && hipEventQuery(t.done[l]) != hipErrorNotReady) {
+                    C25519_TRY(hipEventSynchronize(t.done[l]));
+                    break;
+                }
+            }
+        } else
+            C25519_TRY(hipEventSynchronize(t.done[l]));
         for (int a = 0; a < na; a++)
             if (arr[a].out && !direct[a] && cnt * arr[a].elem) copy_bytes((char*)arr[a].out + lo * arr[a].elem, t.hbuf[l][a], cnt * arr[a].elem);
         return 0;

@@ -1696,3 +1696,66 @@ def test_single_calls_with_large_messages_are_uploaded_not_read_over_pcie(api, o
         msg[0, mlen // 2] ^= 1
         assert api.ed25519_VerifySignature(sig, pub, msg)[0] == 0
     assert took[1 << 20] < 2.0, took                                    # a lone lane hashes 1 MiB twice: tens of ms, not minutes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("done_word", ["1", "0"])
+def test_single_calls_return_on_the_completion_word(done_word):
+    """A call of ONE element through the reference's prototypes returns when the call's last kernel has stored the call's
+    sequence number into pinned host memory behind its results (capi_common.hpp: ThreadState::done_word; 4.6 us earlier than the
+    runtime's event, profiles/r06_launch_latency.txt) -- so a few hundred back-to-back calls with FRESH inputs each, every
+    operation in turn, must each return their own results (a word seen early, or a stale sequence number, would hand back the
+    previous call's bytes), from two threads at once; C25519_AMD_DONE_WORD=0 (the event path) gives the same bytes.  Verification
+    includes keys off the curve and corrupted signatures: the slow-list kernel is that call's last kernel and signals either way."""
+    code = r'''
+import ctypes as C, os, sys, threading
+import numpy as np
+sys.path.insert(0, os.path.join(%r, "tests"))
+sys.path.insert(0, %r)
+from oracle_lib import Oracle
+from curve25519_amd import _lib, synth
+L = _lib.load()
+orc = Oracle()
+buf = lambda a: (C.c_ubyte * a.size).from_buffer_copy(a.tobytes())
+def worker(seed, errors):
+    try:
+        n = 96
+        sk, pk = synth.x25519_inputs(n, seed_shift=seed)
+        exp, exp_sk = orc.x25519_shared(pk, sk)
+        esk, msg = synth.ed25519_inputs(n, seed_shift=seed + 1)
+        epub, epriv = orc.ed25519_keypair(esk)
+        esig = orc.ed25519_sign(epriv, msg)
+        bsig, bmsg, bad = synth.corrupt_for_verify(esig, msg)
+        keys = epub.copy()
+        keys[::5] = synth.random_bytes((n, 32), seed + 2)[::5]        # garbage keys: the slow list gets its element
+        everd = orc.ed25519_verify(bsig, keys, bmsg)
+        pub_fast_exp, _ = orc.x25519_public(sk, fast=True)
+        for i in range(n):
+            out, s = (C.c_ubyte * 32)(), buf(sk[i])
+            L.curve25519_dh_CreateSharedKey(out, buf(pk[i]), s)
+            assert bytes(out) == exp[i].tobytes() and bytes(s) == exp_sk[i].tobytes(), ("x25519", i)
+            s = buf(sk[i])
+            L.curve25519_dh_CalculatePublicKey_fast(out, s)
+            assert bytes(out) == pub_fast_exp[i].tobytes(), ("public_fast", i)
+            pub, priv, sig = (C.c_ubyte * 32)(), (C.c_ubyte * 64)(), (C.c_ubyte * 64)()
+            L.ed25519_CreateKeyPair(pub, priv, None, buf(esk[i]))
+            assert bytes(pub) == epub[i].tobytes() and bytes(priv) == epriv[i].tobytes(), ("keypair", i)
+            L.ed25519_SignMessage(sig, priv, None, buf(msg[i]), msg.shape[1])
+            assert bytes(sig) == esig[i].tobytes(), ("sign", i)
+            v = L.ed25519_VerifySignature(buf(bsig[i]), buf(keys[i]), buf(bmsg[i]), bmsg.shape[1])
+            assert v == int(everd[i]), ("verify", i, v, int(everd[i]))
+            ctx = L.ed25519_Verify_Init(None, buf(epub[i]))
+            v = L.ed25519_Verify_Check(ctx, buf(bsig[i]), buf(bmsg[i]), bmsg.shape[1])
+            L.ed25519_Verify_Finish(ctx)
+            assert v == int(orc.ed25519_verify(bsig[i:i + 1], epub[i:i + 1], bmsg[i:i + 1])[0]), ("check", i)
+    except BaseException as e:
+        errors.append(repr(e))
+errors = []
+ts = [threading.Thread(target=worker, args=(0x600 + 16 * t, errors)) for t in range(2)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not errors, errors
+print("ok")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, C25519_AMD_DONE_WORD=done_word)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
