@@ -47,6 +47,21 @@ C25519_DEV u64 rotr64(u64 x, int n)
     return ((u64)alignbit32(a, b, r) << 32) | alignbit32(b, a, r);
 }
 
+// the round's three-input functions on 64-bit words: one v_bitop3_b32 per half (valu_gfx950.cuh).  pair64 keeps the two halves
+// ONE 64-bit value for the additions that follow (left as (hi << 32) | lo, the compiler adds the halves as two 64-bit terms)
+C25519_DEV u64 xor3_64(u64 a, u64 b, u64 c)
+{
+    return pair64(xor3_32((u32)a, (u32)b, (u32)c), xor3_32((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32)));
+}
+C25519_DEV u64 ch_64(u64 e, u64 f, u64 g)
+{
+    return pair64(ch_32((u32)e, (u32)f, (u32)g), ch_32((u32)(e >> 32), (u32)(f >> 32), (u32)(g >> 32)));
+}
+C25519_DEV u64 maj_64(u64 a, u64 b, u64 c)
+{
+    return pair64(maj_32((u32)a, (u32)b, (u32)c), maj_32((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32)));
+}
+
 // big-endian 64-bit word from two little-endian 32-bit words as they sit in memory
 C25519_DEV u64 be64_from_le32(u32 lo_addr_word, u32 hi_addr_word)
 {
@@ -61,15 +76,15 @@ C25519_DEV void sha512_rounds16(u64 (&v)[8], u64 (&w)[16], int r)
     for (int i = 0; i < 16; i++) {
         if (SCHEDULE) {
             const u64 w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
-            const u64 s0 = rotr64(w15, 1) ^ rotr64(w15, 8) ^ (w15 >> 7);
-            const u64 s1 = rotr64(w2, 19) ^ rotr64(w2, 61) ^ (w2 >> 6);
+            const u64 s0 = xor3_64(rotr64(w15, 1), rotr64(w15, 8), w15 >> 7);
+            const u64 s1 = xor3_64(rotr64(w2, 19), rotr64(w2, 61), w2 >> 6);
             w[i] += s0 + w[(i + 9) & 15] + s1;
         }
-        const u64 S1 = rotr64(e, 14) ^ rotr64(e, 18) ^ rotr64(e, 41);
-        const u64 ch = (e & f) ^ (~e & g);
+        const u64 S1 = xor3_64(rotr64(e, 14), rotr64(e, 18), rotr64(e, 41));
+        const u64 ch = ch_64(e, f, g);
         const u64 t1 = h + S1 + ch + SHA512_K[r + i] + w[i];
-        const u64 S0 = rotr64(a, 28) ^ rotr64(a, 34) ^ rotr64(a, 39);
-        const u64 mj = (a & b) ^ (a & c) ^ (b & c);
+        const u64 S0 = xor3_64(rotr64(a, 28), rotr64(a, 34), rotr64(a, 39));
+        const u64 mj = maj_64(a, b, c);
         const u64 t2 = S0 + mj;
         h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }

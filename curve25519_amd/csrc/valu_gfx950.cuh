@@ -71,6 +71,30 @@ C25519_DEV u32 dbl32(u32 x)
 // a / b in single precision, a few ulp off (v_rcp_f32 + v_mul_f32): used only where an estimate is wanted
 C25519_DEV float fast_div(float a, float b) { return __fdividef(a, b); }
 
+// Three-input bitwise functions in ONE instruction (v_bitop3_b32, the truth table as an immediate: bit (4a + 2b + c) of it is the
+// result for input bits a, b, c): SHA-512's three-way XORs, Ch and Maj -- 24 XORs and 6 ANDs of a round become 12 instructions
+// (the compiler does not form them from the two-input source).  Build knob C25519_SHA_BITOP3 = 0: the two-input forms (A/B).
+#ifndef C25519_SHA_BITOP3
+#define C25519_SHA_BITOP3 1
+#endif
+#if C25519_SHA_BITOP3
+C25519_DEV u32 xor3_32(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+C25519_DEV u32 ch_32(u32 e, u32 f, u32 g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xca); }       // e ? f : g
+C25519_DEV u32 maj_32(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8); }
+#else
+C25519_DEV u32 xor3_32(u32 a, u32 b, u32 c) { return a ^ b ^ c; }
+C25519_DEV u32 ch_32(u32 e, u32 f, u32 g) { return (e & f) ^ (~e & g); }
+C25519_DEV u32 maj_32(u32 a, u32 b, u32 c) { return (a & b) ^ (a & c) ^ (b & c); }
+#endif
+
+// (hi:lo) as one 64-bit value the optimiser cannot take apart again (no instruction: the asm is empty)
+C25519_DEV u64 pair64(u32 lo, u32 hi)
+{
+    u64 r = ((u64)hi << 32) | lo;
+    asm("" : "+v"(r));
+    return r;
+}
+
 // (hi:lo) >> s, low 32 bits   (v_alignbit_b32)
 C25519_DEV u32 alignbit32(u32 hi, u32 lo, int s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
 

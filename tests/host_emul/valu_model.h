@@ -81,6 +81,10 @@ extern LatCounters emul_lat_counters;
 
 inline u32 dbl32(u32 x) { return x + x; }
 inline float fast_div(float a, float b) { return a / b; }
+inline u32 xor3_32(u32 a, u32 b, u32 c) { return a ^ b ^ c; }                                  // v_bitop3_b32 0x96
+inline u32 ch_32(u32 e, u32 f, u32 g) { return (e & f) | (~e & g); }                           // 0xca
+inline u32 maj_32(u32 a, u32 b, u32 c) { return (a & b) | (a & c) | (b & c); }                 // 0xe8
+inline u64 pair64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 inline u32 alignbit32(u32 hi, u32 lo, int s) { return (u32)((((u64)hi << 32) | lo) >> s); }
 
 // v_mad_u64_u32 wraps modulo 2^64 exactly like unsigned C arithmetic; the model additionally REPORTS a wrap,
