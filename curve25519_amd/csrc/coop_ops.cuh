@@ -39,11 +39,16 @@ C25519_DEV void setup_one(u32* lds, const Lane& L)
 
 // curve25519_dh_CreateSharedKey / CalculatePublicKey (curve25519_dh.c:94-157, 191-208) for element e.  lds: ROWQ_OFF words.
 template <bool BASE9>
-C25519_DEV void x25519_one(u32* lds, const Lane& L, void* out, const void* pk, void* sk, size_t e)
+C25519_DEV void x25519_one(u32* lds, const Lane& L, void* out, const void* pk, void* sk, size_t e, const CallWords* cw = nullptr)
 {
     u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8];
-    if (!BASE9) load32(u, pk, e);
-    load32(k, sk, e);
+    if (cw && cw->use) {                                 // a call of one: pk in words 0..7, sk in words 8..15 of the arguments
+#pragma unroll
+        for (int i = 0; i < 8; i++) { if (!BASE9) u[i] = cw->w[i]; k[i] = cw->w[8 + i]; }
+    } else {
+        if (!BASE9) load32(u, pk, e);
+        load32(k, sk, e);
+    }
     clamp_words(k);
     if (threadIdx.x == 0) store32(sk, e, k);            // the reference clamps in the caller's buffer
     fe X1, one;
@@ -107,14 +112,19 @@ C25519_DEV void x25519_one(u32* lds, const Lane& L, void* out, const void* pk, v
 // wave 0 the differential addition with x1 times the sum carried along, wave 1 the doubling): 510 levels and 255 barriers instead
 // of 765 levels.  lds_all: X2_LDS_WORDS words.  The set-up
 // and the tail (three doublings, inversion, canonical bytes) are x25519_one's, in a slot region of the wave's own.
-C25519_DEV void x25519_two_waves(u32* lds_all, void* out, const void* pk, void* sk, size_t e)
+C25519_DEV void x25519_two_waves(u32* lds_all, void* out, const void* pk, void* sk, size_t e, const CallWords* cw = nullptr)
 {
     const int wave = threadIdx.x >> 6;
     const Lane L = make_lane(threadIdx.x & 63);
     u32* lds = lds_all + (X2_SHARED_SLOTS + wave * NSLOTS) * SLOT_WORDS;
     u32 u[8], k[8];
-    load32(u, pk, e);
-    load32(k, sk, e);
+    if (cw && cw->use) {                                 // a call of one: the records came with the kernel's arguments
+#pragma unroll
+        for (int i = 0; i < 8; i++) { u[i] = cw->w[i]; k[i] = cw->w[8 + i]; }
+    } else {
+        load32(u, pk, e);
+        load32(k, sk, e);
+    }
     clamp_words(k);
     if (threadIdx.x == 0) store32(sk, e, k);            // the reference clamps in the caller's buffer
     fe X1, one;

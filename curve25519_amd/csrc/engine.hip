@@ -279,22 +279,22 @@ C25519_DEV void signal_done(const DoneWord& d)
 // limb-per-lane, up to four products at a time); only the decoding of the inputs and the canonical encoding of the result
 // are the batch kernels' per-lane code, run by every lane on the same values.
 template <bool BASE9>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop(void* out, const void* pk, void* sk, size_t n, DoneWord done)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop(void* out, const void* pk, void* sk, size_t n, DoneWord done, CallWords cw)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::ROWQ_OFF];
     if (blockIdx.x >= n) return;
-    coop::x25519_one<BASE9>(lds, coop::make_lane(threadIdx.x), out, pk, sk, blockIdx.x);
+    coop::x25519_one<BASE9>(lds, coop::make_lane(threadIdx.x), out, pk, sk, blockIdx.x, &cw);
     if (threadIdx.x == 0) signal_done(done);
 }
 
 // ... and on TWO waves per element (coop::x25519_two_waves: a ladder step in two product levels -- the differential addition with
 // x1 times the sum carried along on one wave, the doubling on the other, one workgroup barrier per step): what ONE
 // curve25519_dh_CreateSharedKey call and calls of up to 512 run -- 183 -> 168 us per call
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop2(void* out, const void* pk, void* sk, size_t n, DoneWord done)
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 4))) k_x25519_coop2(void* out, const void* pk, void* sk, size_t n, DoneWord done, CallWords cw)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::X2_LDS_WORDS];
     if (blockIdx.x >= n) return;
-    coop::x25519_two_waves(lds, out, pk, sk, blockIdx.x);
+    coop::x25519_two_waves(lds, out, pk, sk, blockIdx.x, &cw);
     if (threadIdx.x == 0) signal_done(done);               // (wave 0 stores; wave 1 has left inside)
 }
 
@@ -1344,6 +1344,18 @@ DoneWord take_done_word(size_t n)
     return DoneWord{ t.done_word, ++t.done_seq };
 }
 
+// the two 32-byte records of a one-element call for the kernel's arguments (lanes.cuh: CallWords): only where the "device"
+// pointers are this library's own pinned staging, which the host can read (a zero-copy call, host_pipeline.hpp)
+CallWords call_words(size_t n, const void* rec0, const void* rec1)
+{
+    CallWords cw{};
+    if (n != 1 || !c25519_host::zero_copy_call()) return cw;
+    if (rec0) memcpy(cw.w, rec0, 32);
+    if (rec1) memcpy(cw.w + 8, rec1, 32);
+    cw.use = 1;
+    return cw;
+}
+
 int check_dev_args(size_t n, std::initializer_list<const void*> ptrs)
 {
     static const bool check_owner_env = getenv("C25519_AMD_NO_PTR_CHECK") == nullptr;
@@ -1666,9 +1678,10 @@ static int x25519_dev(void* out, const void* pk, void* sk, size_t n, hipStream_t
         return 0;
     }
     if (x25519_coop_for(n)) {
-        if (pk && x25519_two_waves_for(n)) k_x25519_coop2<<<(unsigned)n, 128, 0, stream>>>(out, pk, sk, n, take_done_word(n));
-        else if (pk) k_x25519_coop<false><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n, take_done_word(n));
-        else    k_x25519_coop<true><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n, take_done_word(n));
+        const CallWords cw = call_words(n, pk, sk);
+        if (pk && x25519_two_waves_for(n)) k_x25519_coop2<<<(unsigned)n, 128, 0, stream>>>(out, pk, sk, n, take_done_word(n), cw);
+        else if (pk) k_x25519_coop<false><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n, take_done_word(n), cw);
+        else    k_x25519_coop<true><<<(unsigned)n, 64, 0, stream>>>(out, pk, sk, n, take_done_word(n), cw);
         C25519_TRY(hipGetLastError());
         return 0;
     }

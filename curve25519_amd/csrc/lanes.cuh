@@ -52,6 +52,11 @@ C25519_DEV void soa_load8(u32 (&v)[8], const u32* base, size_t n, size_t i)
     for (int w = 0; w < 8; w++) v[w] = base[(size_t)w * n + i];
 }
 
+// The input records of a call of ONE element, carried in the kernel's arguments (engine.hip: call_words): the first loads of a
+// zero-copy call read pinned host memory over PCIe -- ~1.1 us before anything can start (profiles/r06_launch_latency.txt) --,
+// the arguments arrive with the dispatch.  use == 0: the records are read from memory as in every other call.
+struct CallWords { u32 w[16]; u32 use; };
+
 // messages of a batch: fixed stride (offsets == nullptr) or ragged (message i = base[offsets[i] .. offsets[i+1]))
 struct Msgs {
     const uint8_t* base;

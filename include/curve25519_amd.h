@@ -126,9 +126,9 @@ int ed25519_SignMessage_ragged_dev(void *sig, const void *priv, const void *msgs
 /* n x ed25519_VerifySignature (reference :67): full Init + Check per element, distinct keys.
  * Cost depends on the INPUT, which an untrusted sender controls: a key that does not decompress onto the curve sends its
  * element through the reference's own operation order in a kernel behind the walk.  Measured at n = 2^20
- * (profiles/r03_verify_worst_case.txt): all keys on the curve 1.00 x, ONE off-curve key in the batch 1.16 x (one lane's
- * latency of the reference-order path, about 1.3 ms), one per 256 elements 1.11 x, every second key 1.52 x (the worst
- * case).  Verdicts are the reference's in every case; a caller that must bound latency can pre-screen keys, or keep
+ * (profiles/r06_verify_worst_case.txt): all keys on the curve 1.00 x (9.5 ms), ONE off-curve key in the batch 1.15 x (one
+ * lane's latency of the reference-order path, about 1.4 ms), one per 256 elements 1.15 x, every second key 1.53 x (the
+ * worst case), every key 1.46 x.  Verdicts are the reference's in every case; a caller that must bound latency can pre-screen keys, or keep
  * batches from different senders apart. */
 int ed25519_VerifySignature_batch(int *verdict, const unsigned char *sig, const unsigned char *pk,
                                   const unsigned char *msg, size_t msg_size, size_t n);

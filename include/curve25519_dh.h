@@ -12,13 +12,16 @@
  *     device is present -- it never falls back to a CPU implementation.
  *
  * A single call is a device batch of one.  Calls of up to a few thousand elements run ONE operation per wave
- * (csrc/coop25519.cuh: a field element limb-per-lane, four field products at a time): 0.19 ms for
- * curve25519_dh_CreateSharedKey, 0.17 ms for curve25519_dh_CalculatePublicKey, 0.06 ms for _fast, end to end
- * (profiles/r04_single_call.txt; round 3's one-operation-per-lane pass took 0.76 ms) against 93 us for the reference on
- * one host core -- the literal drop-in call is correct and four times faster than it was, still not faster than a host
- * core.  Throughput comes from the batch entry points in curve25519_amd.h: a call of 2 operations already beats one host
- * core, ~40 beat sixteen cores (a call of 1024 takes 0.22 ms: profiles/r04_small_batch_sweep.txt); the quoted rates need
- * 2^17 and more per call (2^17: 99 M/s, 2^20: 123 M/s).
+ * (csrc/coop25519.cuh: a field element limb-per-lane, four field products at a time; curve25519_dh_CreateSharedKey: two waves
+ * per element, a ladder step in two product levels), the inversion by division steps on a quad of lanes, and a call of one
+ * returns on a completion word its kernel stores behind the result: 0.14 ms for curve25519_dh_CreateSharedKey, 0.13 ms for
+ * curve25519_dh_CalculatePublicKey, 0.04 ms for _fast, end to end (profiles/r06_single_call.txt; round 5: 0.17 / 0.16 /
+ * 0.07; round 3's one-operation-per-lane pass: 0.76 ms) against 93 / 93 / 43 us for the reference on one host core of the
+ * same box -- the literal drop-in call is correct and five times faster than it was; only _fast is faster than a host core.
+ * Throughput comes from the batch entry points in curve25519_amd.h: a call of 2 operations already beats one host core, ~40
+ * beat sixteen cores (a call of 1024 takes 0.19 ms, one of 2^14 -- four lanes per element, csrc/quad25519.cuh -- 0.33 ms =
+ * 50 M/s: profiles/r06_small_batch_sweep.txt, r06_mid_batch_sweep.txt); the quoted rates need 2^17 and more per call
+ * (2^17: 117 M/s, 2^20: 131-134 M/s).
  */
 #ifndef CURVE25519_AMD_DH_H
 #define CURVE25519_AMD_DH_H

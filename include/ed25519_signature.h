@@ -16,13 +16,17 @@
  * byte-identical with and without a context.
  *
  * Cost of ONE call: these are the reference's single-operation prototypes, and each call runs as a device batch of
- * one.  Calls of up to 2048 elements run ONE operation per wave (csrc/coop25519.cuh): 84 us per ed25519_CreateKeyPair,
- * 110 us per ed25519_SignMessage, 0.26 ms per ed25519_VerifySignature (its walk; decoding and hashing are still one lane's
- * work) end to end (profiles/r04_single_call.txt; 0.18 / 0.21 / 0.65 ms in round 3).  The reference on one host core of the
- * same box: 43 us per signature, 190 us per verification, 93 us per X25519 -- a single call here is slower than there.
- * The device pays off through the *_batch / *_dev forms in curve25519_amd.h: from 3 signatures per call a batch beats one
- * host core (1024 signatures take 0.12 ms), from a few dozen it beats sixteen, and the quoted throughput needs 2^17 and
- * more per call.
+ * one.  Calls of up to 1024-2048 elements run ONE operation per wave (csrc/coop25519.cuh; verification: one launch of three
+ * waves per signature -- hashing and the two square roots side by side, then the three scalar products side by side), the
+ * inversion by division steps on a quad of lanes, and a call of one returns on a completion word its last kernel stores
+ * behind the results: 47 us per ed25519_CreateKeyPair, 71 us per ed25519_SignMessage, 128 us per ed25519_VerifySignature, 129 /
+ * 104 us per ed25519_Verify_Init / _Check, end to end (profiles/r06_single_call.txt; round 5: 76 / 105 / 135, 131 / 133;
+ * round 3: 0.18 / 0.21 / 0.65 ms).  The reference on one host core of the same box: 43 us per key pair and per signature,
+ * 190 us per verification -- a single verification is faster here, a single signature is not.
+ * The device pays off through the *_batch / *_dev forms in curve25519_amd.h: from 2 signatures per call a batch beats one
+ * host core (1024 signatures take 81 us, 2^14 -- four lanes per element, csrc/quad25519.cuh -- 77 us = 212 M/s:
+ * profiles/r06_small_batch_sweep.txt, r06_mid_batch_sweep.txt), from a few dozen it beats sixteen, and the quoted
+ * throughput needs 2^17 and more per call.
  */
 #ifndef CURVE25519_AMD_ED25519_SIGNATURE_H
 #define CURVE25519_AMD_ED25519_SIGNATURE_H

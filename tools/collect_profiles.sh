@@ -3,7 +3,7 @@
 # of the GPU box stripped, the loader's amdgpu.ids complaint dropped); only files that exist in SRC are replaced.
 set -u
 cd "$(dirname "$0")/.."
-O=gpurun_out/$1; R=${2:-r05}; P=profiles
+O=gpurun_out/$1; R=${2:-r06}; P=profiles
 strip() { grep -v "amdgpu.ids" "$1" | sed 's#/tmp/code/msotoodeh__curve25519/repo/##g; s#/root/repo/##g'; }
 for f in bench bench_mixed bench_dist1 pmc cycle_probe mad_peak mad_cycles valu_rates; do [ -f $O/$f.json ] && cp $O/$f.json $P/${R}_$f.json; done
 for f in kernel_stats pmc mad_peak valu_rates field_ab; do [ -f $O/$f.txt ] && strip $O/$f.txt > $P/${R}_$f.txt; done

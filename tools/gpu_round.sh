@@ -1,17 +1,17 @@
 #!/bin/bash
 # tools/gpu_round.sh -- one gpurun call's worth of work: the GPU test suite, bench lines, the instruction-rate
-# microbenchmark, the host-API rates and the rocprofv3 passes.  Everything lands under gpurun_out/$ROUND/ (default r05).
+# microbenchmark, the host-API rates and the rocprofv3 passes.  Everything lands under gpurun_out/$ROUND/ (default r06).
 #   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [tests|bench|ubench|prof|all ...]'
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/${ROUND:-r05}
+OUT=$REPO/gpurun_out/${ROUND:-r06}
 mkdir -p $OUT
 cd $REPO
 WHAT=${*:-all}
 has() { [[ " $WHAT " == *" $1 "* || " $WHAT " == *" all "* ]]; }
 
 if has tests; then
-  timeout 420 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.full 2>&1
+  timeout 600 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.full 2>&1
   echo "pytest rc=$?" > $OUT/pytest_gpu.rc                      # pytest's own exit code, not a pipe's
   tail -30 $OUT/pytest_gpu.full > $OUT/pytest_gpu.log; cat $OUT/pytest_gpu.rc >> $OUT/pytest_gpu.log; rm -f $OUT/pytest_gpu.full
   grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -3; cat $OUT/pytest_gpu.rc
