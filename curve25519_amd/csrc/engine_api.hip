@@ -1,0 +1,521 @@
+// curve25519_amd/csrc/engine_api.hip -- library state and knobs, the argument checks of the *_dev forms, the unit-test hooks, the host-pointer *_batch
+// forms (host_pipeline.hpp) and the reference's single-call prototypes
+// (one of the engine's four translation units: engine_common.cuh says which is which)
+#include "engine_common.cuh"
+
+// ------------------------------------------------------------------------------------------------
+// unit-test hooks (the counterpart of the reference's ECP_SELF_TEST unit checks,
+// test/curve25519_selftest.c:624-741): one lane per input record, operations defined in lanes.cuh
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_fe_selftest(void* out, const void* a, const void* b, size_t n, int op)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    u32 aw[8], bw[8], ow[8];
+    load32(aw, a, i);
+    load32(bw, b, i);
+    fe_selftest_op(ow, aw, bw, op);
+    store32(out, i, ow);
+}
+
+// op 14 (the division steps on a quad of lanes, safegcd25519.cuh): FOUR lanes per record, all on the same values
+__global__ void __launch_bounds__(64) k_fe_selftest_quad(void* out, const void* a, const void* b, size_t n, int op)
+{
+    const size_t i = (size_t)blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (i >= n) return;                                   // (whole quads leave)
+    u32 aw[8], bw[8], ow[8];
+    load32(aw, a, i);
+    load32(bw, b, i);
+    fe_selftest_op(ow, aw, bw, op);
+    if ((threadIdx.x & 3) == 0) store32(out, i, ow);
+}
+
+__global__ void __launch_bounds__(64) k_sc_selftest(void* out, const void* a, const void* b, size_t n, int op)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    u32 lo[8], hi[8], aw[16], bw[8], ow[8];
+    load32(lo, a, 2 * i);
+    load32(hi, a, 2 * i + 1);
+    load32(bw, b, i);
+#pragma unroll
+    for (int j = 0; j < 8; j++) { aw[j] = lo[j]; aw[8 + j] = hi[j]; }
+    sc_selftest_op(ow, aw, bw, op);
+    store32(out, i, ow);
+}
+
+__global__ void __launch_bounds__(64) k_fold_selftest(uint8_t* out /* n x 128 */, const void* k, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    u32 kw[8];
+    load32(kw, k, i);
+    fold_selftest_op(out + 128 * i, kw);
+}
+
+namespace c25519_engine {
+
+// the completion word for the LAST kernel of a call of one element, if the caller (host_pipeline.hpp: run_batch on a zero-copy
+// call) is going to spin on it; taken at most once per call
+DoneWord take_done_word(size_t n)
+{
+    ThreadState& t = tls();
+    if (n != 1 || !t.done_offered || t.done_taken) return DoneWord{ nullptr, 0 };
+    t.done_taken = true;
+    return DoneWord{ t.done_word, ++t.done_seq };
+}
+
+// the two 32-byte records of a one-element call for the kernel's arguments (lanes.cuh: CallWords): only where the "device"
+// pointers are this library's own pinned staging, which the host can read (a zero-copy call, host_pipeline.hpp)
+CallWords call_words(size_t n, const void* rec0, const void* rec1)
+{
+    CallWords cw{};
+    if (n != 1 || !c25519_host::zero_copy_call()) return cw;
+    if (rec0) memcpy(cw.w, rec0, 32);
+    if (rec1) memcpy(cw.w + 8, rec1, 32);
+    cw.use = 1;
+    return cw;
+}
+// *_dev arguments: n in range, pointers 16-byte aligned and -- unless C25519_AMD_NO_PTR_CHECK is set -- device (or
+// managed) memory of the CURRENT device: a pointer of another GPU or a host pointer is an error here, not a fault
+// inside a kernel.
+int check_dev_args(size_t n, std::initializer_list<const void*> ptrs)
+{
+    static const bool check_owner_env = getenv("C25519_AMD_NO_PTR_CHECK") == nullptr;
+    const bool check_owner = check_owner_env && !c25519_host::zero_copy_call();   // (a tiny *_batch call hands over this library's own pinned staging: host_pipeline.hpp)
+    if (n > ((size_t)1 << 31)) return bad_arg("batch too large (n > 2^31)");
+    int dev = 0;
+    if (check_owner && n) C25519_TRY(hipGetDevice(&dev));
+    for (const void* p : ptrs) {
+        if (!p) continue;
+        if (!aligned16(p)) return bad_arg("device pointers must be 16-byte aligned");
+        if (!check_owner || n == 0) continue;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return bad_arg("*_dev entry points take device pointers (this one is unknown to the HIP runtime)");
+        }
+        if (attr.type == hipMemoryTypeHost && c25519_host::zero_copy_call()) continue;   // the pinned staging of a tiny *_batch call (host_pipeline.hpp)
+        if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)
+            return bad_arg("*_dev entry points take device pointers (got host memory)");
+        if (attr.type == hipMemoryTypeDevice && attr.device != dev)
+            return bad_arg("device pointer belongs to another device than the current one");
+    }
+    return 0;
+}
+
+}  // namespace c25519_engine
+
+extern "C" {
+
+
+const char* c25519_amd_version(void) { return "curve25519_amd 0.7 (gfx950)"; }
+const char* c25519_amd_last_error(void) { return c25519_host::last_error().c_str(); }
+
+int c25519_amd_device_count(void)
+{
+    C25519_API_CALL_OR(0);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int c25519_amd_host_register(void* p, size_t bytes)
+{
+    C25519_API_CALL();
+    if (!p || !bytes) return bad_arg("null pointer or empty range");
+    // page locking works on whole pages: a buffer that shares a page with another allocation would get that neighbour
+    // locked, and unlocked, with it (the runtime aborts on the second unregister) -- so only whole pages are accepted
+    if ((reinterpret_cast<uintptr_t>(p) & 4095u) || (bytes & 4095u)) return bad_arg("host_register: the buffer must start on a 4 KiB page and cover whole pages");
+    C25519_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return 0;
+}
+
+int c25519_amd_host_unregister(void* p)
+{
+    C25519_API_CALL();
+    if (!p) return bad_arg("null pointer");
+    C25519_TRY(hipHostUnregister(p));
+    return 0;
+}
+
+// tuning / A-B knobs (capi_common.hpp: Tunable).  name = the part behind C25519_AMD_ of the environment variable that
+// initialises the knob; value < 0 restores the library's built-in choice.
+int c25519_amd_tunable_set(const char* name, long value)
+{
+    if (!name) return bad_arg("null pointer");
+    for (int i = 0; i < c25519_host::T_COUNT; i++)
+        if (!strcmp(name, c25519_host::tunable_names()[i])) {
+            c25519_host::tunable_table()[i].store(value < 0 ? c25519_host::T_UNSET : value, std::memory_order_relaxed);
+            return 0;
+        }
+    return bad_arg("c25519_amd_tunable_set: no such knob");
+}
+
+long c25519_amd_tunable_get(const char* name)
+{
+    if (name)
+        for (int i = 0; i < c25519_host::T_COUNT; i++)
+            if (!strcmp(name, c25519_host::tunable_names()[i])) return c25519_host::tunable((c25519_host::Tunable)i);
+    return -2;
+}
+
+int c25519_amd_usable_cpus(void) { return c25519_host::usable_cpus(); }
+
+int c25519_amd_set_device(int device)
+{
+    C25519_API_CALL();
+    C25519_TRY(hipSetDevice(device));
+    return 0;
+}
+// frees the calling thread's streams, staging buffers (zeroed first) and work scratch
+void c25519_amd_thread_release(void)
+{
+    if (!c25519_host::runtime_alive().load()) return;                   // exit() has begun: the process' memory goes with it
+    C25519_API_CALL_OR((void)0);
+    c25519_host::helper_pool_slot().reset();              // the pipeline's parked helper threads
+    tls().release();
+}
+// ---- unit-test hooks (host pointers) ---------------------------------------------------------------
+int c25519_amd_fe_selftest(unsigned char* out, const unsigned char* a, const unsigned char* b, size_t n, int op)
+{
+    if (!out || !a || !b) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    return run_batch(n, { Arr{ a, nullptr, 32 }, Arr{ b, nullptr, 32 }, Arr{ nullptr, out, 32 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         if (op == 14) k_fe_selftest_quad<<<grid_for(c, 16), 64, 0, st>>>(d[2], d[0], d[1], c, op);
+                         else k_fe_selftest<<<grid_for(c, 64), 64, 0, st>>>(d[2], d[0], d[1], c, op);
+                         C25519_TRY(hipGetLastError());
+                         return 0;
+                     });
+}
+
+int c25519_amd_sc_selftest(unsigned char* out, const unsigned char* a, const unsigned char* b, size_t n, int op)
+{
+    if (!out || !a || !b) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    return run_batch(n, { Arr{ a, nullptr, 64 }, Arr{ b, nullptr, 32 }, Arr{ nullptr, out, 32 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         k_sc_selftest<<<grid_for(c, 64), 64, 0, st>>>(d[2], d[0], d[1], c, op);
+                         C25519_TRY(hipGetLastError());
+                         return 0;
+                     });
+}
+
+int c25519_amd_fold_selftest(unsigned char* out, const unsigned char* k, size_t n)
+{
+    if (!out || !k) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    return run_batch(n, { Arr{ k, nullptr, 32 }, Arr{ nullptr, out, 128 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         k_fold_selftest<<<grid_for(c, 64), 64, 0, st>>>((uint8_t*)d[1], d[0], c);
+                         C25519_TRY(hipGetLastError());
+                         return 0;
+                     });
+}
+
+int c25519_amd_base_table(unsigned char* out)
+{
+    C25519_API_CALL();
+    if (!out) return bad_arg("null pointer");
+    const u32* bytes = nullptr;
+    if (int rc = base_tables(nullptr, &bytes)) return rc;
+    C25519_TRY(hipMemcpy(out, bytes, 256 * 96, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- host-pointer entry points: stage, run the *_dev form, copy back (run_batch above) ---------------
+
+int curve25519_dh_CreateSharedKey_batch(unsigned char* shared, const unsigned char* pk, unsigned char* sk, size_t n)
+{
+    if (!shared || !pk || !sk) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    return run_batch(n, { Arr{ pk, nullptr, 32 }, Arr{ sk, sk, 32 }, Arr{ nullptr, shared, 32 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return curve25519_dh_CreateSharedKey_dev(d[2], d[0], d[1], c, st);
+                     });
+}
+
+static int public_batch(unsigned char* pk, unsigned char* sk, size_t n, bool fast)
+{
+    if (!pk || !sk) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    return run_batch(n, { Arr{ sk, sk, 32 }, Arr{ nullptr, pk, 32 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return fast ? curve25519_dh_CalculatePublicKey_fast_dev(d[1], d[0], c, st)
+                                     : curve25519_dh_CalculatePublicKey_dev(d[1], d[0], c, st);
+                     });
+}
+
+int curve25519_dh_CalculatePublicKey_batch(unsigned char* pk, unsigned char* sk, size_t n) { return public_batch(pk, sk, n, false); }
+int curve25519_dh_CalculatePublicKey_fast_batch(unsigned char* pk, unsigned char* sk, size_t n) { return public_batch(pk, sk, n, true); }
+
+// the blinding context of a host-pointer call: 192 bytes uploaded once per call into the thread's scratch lane
+static int upload_blinding(void** dctx, const void* blinding)
+{
+    ThreadState& t = tls();
+    C25519_RC(t.ensure());
+    // a caller signs many times with one context (the reference's C++ wrapper keeps two static ones, C++/ed25519.cpp): it
+    // is uploaded when its bytes differ from what this thread uploaded last, not with a synchronous copy per call
+    if (!t.bctx) C25519_TRY(hipMalloc(&t.bctx, 4 * BLIND_WORDS));
+    if (!t.bctx_valid || memcmp(t.bctx_host, blinding, 4 * BLIND_WORDS) != 0) {
+        t.bctx_valid = false;
+        C25519_RC(c25519_host::upload_now(t.bctx, blinding, 4 * BLIND_WORDS));
+        memcpy(t.bctx_host, blinding, 4 * BLIND_WORDS);
+        t.bctx_valid = true;
+    }
+    *dctx = t.bctx;
+    return 0;
+}
+
+static int keypair_batch(unsigned char* pub, unsigned char* priv, const void* blinding, const unsigned char* sk, size_t n)
+{
+    C25519_API_CALL();
+    if (!pub || !priv || !sk) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    void* dctx = nullptr;
+    if (blinding) C25519_RC(upload_blinding(&dctx, blinding));
+    return run_batch(n, { Arr{ sk, nullptr, 32 }, Arr{ nullptr, pub, 32 }, Arr{ nullptr, priv, 64 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return keypair_dev(d[1], d[2], d[0], dctx, c, st);
+                     });
+}
+
+int ed25519_CreateKeyPair_batch(unsigned char* pub, unsigned char* priv, const unsigned char* sk, size_t n)
+{
+    return keypair_batch(pub, priv, nullptr, sk, n);
+}
+
+int ed25519_CreateKeyPair_blinded_batch(unsigned char* pub, unsigned char* priv, const void* blinding,
+                                        const unsigned char* sk, size_t n)
+{
+    if (!blinding) return bad_arg("null blinding context");
+    return keypair_batch(pub, priv, blinding, sk, n);
+}
+
+static int sign_batch(unsigned char* sig, const unsigned char* priv, const void* blinding, const unsigned char* msg,
+                      size_t msg_size, size_t n)
+{
+    C25519_API_CALL();
+    if (!sig || !priv || (!msg && msg_size)) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    void* dctx = nullptr;
+    if (blinding) C25519_RC(upload_blinding(&dctx, blinding));
+    return run_batch(n, { Arr{ priv, nullptr, 64 }, Arr{ msg, nullptr, msg_size }, Arr{ nullptr, sig, 64 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return sign_dev(d[2], d[0], dctx, Msgs{ (const uint8_t*)d[1], msg_size, nullptr }, c, st);
+                     });
+}
+
+int ed25519_SignMessage_batch(unsigned char* sig, const unsigned char* priv, const unsigned char* msg,
+                              size_t msg_size, size_t n)
+{
+    return sign_batch(sig, priv, nullptr, msg, msg_size, n);
+}
+
+int ed25519_SignMessage_blinded_batch(unsigned char* sig, const unsigned char* priv, const void* blinding,
+                                      const unsigned char* msg, size_t msg_size, size_t n)
+{
+    if (!blinding) return bad_arg("null blinding context");
+    return sign_batch(sig, priv, blinding, msg, msg_size, n);
+}
+
+int ed25519_VerifySignature_batch(int* verdict, const unsigned char* sig, const unsigned char* pk,
+                                  const unsigned char* msg, size_t msg_size, size_t n)
+{
+    if (!verdict || !sig || !pk || (!msg && msg_size)) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    return run_batch(n, { Arr{ sig, nullptr, 64 }, Arr{ pk, nullptr, 32 }, Arr{ msg, nullptr, msg_size },
+                          Arr{ nullptr, verdict, sizeof(int) } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return ed25519_VerifySignature_dev(d[3], d[0], d[1], d[2], msg_size, c, st);
+                     });
+}
+
+// ragged messages: message i is msgs[offsets[i] .. offsets[i+1]); offsets has n+1 entries (host memory).
+// One piece: the message bytes and the offsets are uploaded whole.
+static int ragged_upload(ThreadState& t, void** d_msgs, void** d_off, const unsigned char* msgs, const uint64_t* offsets,
+                         size_t n)
+{
+    const int L = ThreadState::LANES - 1;
+    C25519_RC(t.reserve_dev(L, 3, (size_t)offsets[n]));
+    C25519_RC(t.reserve_dev(L, 4, sizeof(uint64_t) * (n + 1)));
+    *d_msgs = t.dbuf[L][3];
+    *d_off = t.dbuf[L][4];
+    if (offsets[n]) C25519_TRY(hipMemcpyAsync(*d_msgs, msgs, (size_t)offsets[n], hipMemcpyHostToDevice, t.stream[L]));
+    C25519_TRY(hipMemcpyAsync(*d_off, offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, t.stream[L]));
+    return 0;
+}
+
+int ed25519_SignMessage_ragged_batch(unsigned char* sig, const unsigned char* priv, const unsigned char* msgs,
+                                     const uint64_t* offsets, size_t n)
+{
+    C25519_API_CALL();
+    if (!sig || !priv || !offsets) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    ThreadState& t = tls();
+    C25519_RC(t.ensure());
+    const int L = ThreadState::LANES - 1;
+    hipStream_t st = t.stream[L];
+    void *d_msgs, *d_off;
+    C25519_RC(ragged_upload(t, &d_msgs, &d_off, msgs, offsets, n));
+    C25519_RC(t.reserve_dev(L, 0, 64 * n));
+    C25519_RC(t.reserve_dev(L, 1, 64 * n));
+    C25519_TRY(hipMemcpyAsync(t.dbuf[L][0], priv, 64 * n, hipMemcpyHostToDevice, st));
+    C25519_RC(ed25519_SignMessage_ragged_dev(t.dbuf[L][1], t.dbuf[L][0], d_msgs, (const uint64_t*)d_off, n, st));
+    C25519_TRY(hipMemcpyAsync(sig, t.dbuf[L][1], 64 * n, hipMemcpyDeviceToHost, st));
+    C25519_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int ed25519_VerifySignature_ragged_batch(int* verdict, const unsigned char* sig, const unsigned char* pk,
+                                         const unsigned char* msgs, const uint64_t* offsets, size_t n)
+{
+    C25519_API_CALL();
+    if (!verdict || !sig || !pk || !offsets) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    ThreadState& t = tls();
+    C25519_RC(t.ensure());
+    const int L = ThreadState::LANES - 1;
+    hipStream_t st = t.stream[L];
+    void *d_msgs, *d_off;
+    C25519_RC(ragged_upload(t, &d_msgs, &d_off, msgs, offsets, n));
+    C25519_RC(t.reserve_dev(L, 0, 64 * n));
+    C25519_RC(t.reserve_dev(L, 1, 32 * n));
+    C25519_RC(t.reserve_dev(L, 2, sizeof(int) * n));
+    C25519_TRY(hipMemcpyAsync(t.dbuf[L][0], sig, 64 * n, hipMemcpyHostToDevice, st));
+    C25519_TRY(hipMemcpyAsync(t.dbuf[L][1], pk, 32 * n, hipMemcpyHostToDevice, st));
+    C25519_RC(ed25519_VerifySignature_ragged_dev(t.dbuf[L][2], t.dbuf[L][0], t.dbuf[L][1], d_msgs, (const uint64_t*)d_off, n, st));
+    C25519_TRY(hipMemcpyAsync(verdict, t.dbuf[L][2], sizeof(int) * n, hipMemcpyDeviceToHost, st));
+    C25519_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ---- the reference's single-call API: a device batch of one, fatal on device failure --------------
+
+void curve25519_dh_CalculatePublicKey(unsigned char* pk, unsigned char* sk)
+{
+    if (int rc = curve25519_dh_CalculatePublicKey_batch(pk, sk, 1)) c25519_host::die(__func__, rc);
+}
+
+void curve25519_dh_CalculatePublicKey_fast(unsigned char* pk, unsigned char* sk)
+{
+    if (int rc = curve25519_dh_CalculatePublicKey_fast_batch(pk, sk, 1)) c25519_host::die(__func__, rc);
+}
+
+void curve25519_dh_CreateSharedKey(unsigned char* shared, const unsigned char* pk, unsigned char* sk)
+{
+    if (int rc = curve25519_dh_CreateSharedKey_batch(shared, pk, sk, 1)) c25519_host::die(__func__, rc);
+}
+
+void ed25519_CreateKeyPair(unsigned char* pubKey, unsigned char* privKey, const void* blinding, const unsigned char* sk)
+{
+    if (int rc = keypair_batch(pubKey, privKey, blinding, sk, 1)) c25519_host::die(__func__, rc);
+}
+
+void ed25519_SignMessage(unsigned char* signature, const unsigned char* privKey, const void* blinding,
+                         const unsigned char* msg, size_t msg_size)
+{
+    if (int rc = sign_batch(signature, privKey, blinding, msg, msg_size, 1)) c25519_host::die(__func__, rc);
+}
+
+int ed25519_VerifySignature(const unsigned char* signature, const unsigned char* publicKey, const unsigned char* msg,
+                            size_t msg_size)
+{
+    int verdict = 0;
+    if (int rc = ed25519_VerifySignature_batch(&verdict, signature, publicKey, msg, msg_size, 1))
+        c25519_host::die(__func__, rc);
+    return verdict;
+}
+
+// Blinding contexts (ed25519_sign.c:289-341): 192 bytes, the reference's EDP_BLINDING_CTX shape (bl, zr, BP), derived
+// ON THE DEVICE from the caller's seed; the context lives in the caller's storage or is malloc'ed here, exactly as in
+// the reference.  Signing / key generation with a context computes (k + bl)*B + BP from a randomised starting point
+// (lanes.cuh), so the walk and its table lookups see a scalar that differs per context; outputs are unchanged.
+void* ed25519_Blinding_Init(void* context, const unsigned char* seed, size_t size)
+{
+    C25519_API_CALL_OR(nullptr);
+    void* ctx = context ? context : malloc(4 * BLIND_WORDS);
+    if (!ctx) return nullptr;                  // allocation failure is the only error the reference reports (:306)
+    ThreadState& t = tls();
+    auto run = [&]() -> int {
+        C25519_RC(t.ensure());
+        const int L = ThreadState::LANES - 1;
+        C25519_RC(t.reserve_dev(L, 0, 4 * BLIND_WORDS));
+        C25519_RC(t.reserve_dev(L, 1, size ? size : 1));
+        if (size) C25519_TRY(hipMemcpyAsync(t.dbuf[L][1], seed, size, hipMemcpyHostToDevice, t.stream[L]));
+        C25519_RC(ed25519_Blinding_Init_dev(t.dbuf[L][0], t.dbuf[L][1], size, t.stream[L]));
+        C25519_TRY(hipMemcpyAsync(ctx, t.dbuf[L][0], 4 * BLIND_WORDS, hipMemcpyDeviceToHost, t.stream[L]));
+        C25519_TRY(hipMemsetAsync(t.dbuf[L][0], 0, 4 * BLIND_WORDS, t.stream[L]));
+        if (size) C25519_TRY(hipMemsetAsync(t.dbuf[L][1], 0, size, t.stream[L]));
+        C25519_TRY(hipStreamSynchronize(t.stream[L]));
+        return 0;
+    };
+    if (int rc = run()) c25519_host::die(__func__, rc);
+    return ctx;
+}
+
+void ed25519_Blinding_Finish(void* context)
+{
+    if (context) {
+        memset(context, 0, 4 * BLIND_WORDS);
+        free(context);
+    }
+}
+
+// Two-phase verification.  The context is the reference's EDP_SIGV_CTX shape (2080 bytes: pk, then 16
+// rows of four canonical field elements), filled by the device; it lives in the caller's storage or is
+// malloc'ed here, exactly as in the reference (ed25519_verify.c:179-237).
+int ed25519_Verify_Init_batch(void* ctx, const unsigned char* pk, size_t n)
+{
+    if (!ctx || !pk) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    return run_batch(n, { Arr{ pk, nullptr, 32 }, Arr{ nullptr, ctx, 2080 } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return ed25519_Verify_Init_dev(d[1], d[0], c, st);
+                     });
+}
+
+int ed25519_Verify_Check_batch(int* verdict, const void* ctx, const unsigned char* sig, const unsigned char* msg,
+                               size_t msg_size, size_t n)
+{
+    C25519_API_CALL();
+    if (!verdict || !ctx || !sig || (!msg && msg_size)) return bad_arg("null pointer");
+    if (n == 0) return 0;
+    ThreadState& t = tls();
+    C25519_RC(t.ensure());
+    // the reference's two-phase use is one Verify_Init and MANY Verify_Check calls on the same context
+    // (ed25519_verify.c:282-286): the context has a device buffer of its own per calling thread and is uploaded only when
+    // its bytes differ from what the thread uploaded last (a 2080-byte memcmp against a synchronous ~12 us copy per call)
+    if (!t.vctx) C25519_TRY(hipMalloc(&t.vctx, 2080));
+    void* dctx = t.vctx;
+    if (!t.vctx_valid || memcmp(t.vctx_host, ctx, 2080) != 0) {
+        t.vctx_valid = false;
+        C25519_RC(c25519_host::upload_now(dctx, ctx, 2080));
+        memcpy(t.vctx_host, ctx, 2080);
+        t.vctx_valid = true;
+    }
+    return run_batch(n, { Arr{ sig, nullptr, 64 }, Arr{ msg, nullptr, msg_size }, Arr{ nullptr, verdict, sizeof(int) } },
+                     [&](void** d, size_t c, size_t, hipStream_t st) -> int {
+                         return ed25519_Verify_Check_dev(d[2], dctx, d[0], d[1], msg_size, c, st);
+                     });
+}
+
+void* ed25519_Verify_Init(void* context, const unsigned char* publicKey)
+{
+    void* ctx = context ? context : malloc(2080);
+    if (!ctx) return nullptr;                  // allocation failure is the only error the reference reports
+    if (int rc = ed25519_Verify_Init_batch(ctx, publicKey, 1)) c25519_host::die(__func__, rc);
+    return ctx;
+}
+
+int ed25519_Verify_Check(const void* context, const unsigned char* signature, const unsigned char* msg, size_t msg_size)
+{
+    int verdict = 0;
+    if (int rc = ed25519_Verify_Check_batch(&verdict, context, signature, msg, msg_size, 1))
+        c25519_host::die(__func__, rc);
+    return verdict;
+}
+
+void ed25519_Verify_Finish(void* ctx) { free(ctx); }
+}  // extern "C"
