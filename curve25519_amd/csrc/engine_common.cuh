@@ -119,6 +119,7 @@ C25519_DEV void signal_done(const DoneWord& d)
 // Fin::emit(e, zinv) turns element e's projective value and 1/Z into the operation's output bytes.
 struct FinishX25519 {                       // out = canonical(num / den)           (curve25519_dh.c:175-178)
     const u32* px; void* out; size_t n;
+    C25519_DEV bool skip() const { return false; }
     C25519_DEV void emit(size_t e, const fe& zinv) const
     {
         fe x;
@@ -141,6 +142,7 @@ C25519_DEV void affine_pack(u32 (&enc)[8], const u32* X, const u32* Y, size_t n,
 
 struct FinishPack {                          // 32-byte record `slot` of `stride`-record rows <- enc(x, y)
     const u32 *X, *Y; void* out; size_t n, stride, slot; void* out2; size_t stride2, slot2;
+    C25519_DEV bool skip() const { return false; }
     C25519_DEV void emit(size_t e, const fe& zinv) const
     {
         u32 enc[8];
@@ -152,6 +154,8 @@ struct FinishPack {                          // 32-byte record `slot` of `stride
 
 struct FinishVerify {                        // verdict = (enc(T) == enc(R) bytes)   (ed25519_verify.c:310-312)
     const u32 *X, *Y; const void* sig; int* verdict; size_t n;
+    const u32* done_elsewhere;               // null, or a device word: non-zero = another kernel of the call has written the verdicts
+    C25519_DEV bool skip() const { return done_elsewhere && *done_elsewhere; }
     C25519_DEV void emit(size_t e, const fe& zinv) const
     {
         u32 enc[8], Rw[8];
@@ -177,6 +181,7 @@ template <typename Fin, int K>
 __global__ void __launch_bounds__(INV_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) k_batch_invert(const u32* Z, u32* prefix, size_t n, size_t m, Fin fin)
 {
     (void)prefix;
+    if (fin.skip()) return;                                 // (uniform: a word of the call's scratch)
     constexpr bool PREFIX_IN_LDS = K > 14;
     __shared__ u32 pre_lds[PREFIX_IN_LDS ? (K - 1) * 10 * INV_BLOCK : 1];
     const size_t j = (size_t)blockIdx.x * INV_BLOCK + threadIdx.x;
@@ -333,6 +338,8 @@ inline bool verify_quad_for(size_t n) { return quad_for(n, 1024, (size_t)1 << 15
 // 2^14 elements (one quad-wave per SIMD) against 81 us for 1024 per-wave signatures and the one-lane path's three launches
 // (134-144 us at 2^15 / 2^16); profiles/r06_mid_batch_sweep.txt
 inline bool fixed_base_quad_for(size_t n) { return quad_for(n, 1024, (size_t)1 << 14); }
+// the one-key check over two wide combs on quads: 0.09-0.10 ms up to 2^14 pairs against the one-lane kernel's 0.16-0.18 (profiles/r06_one_key_rate.txt)
+inline bool one_key_quad_for(size_t n) { return quad_for(n, 1024, (size_t)1 << 14); }
 inline bool fixed_base_coop_for(size_t n) { return coop_for(n, 2048); }
 inline bool verify_coop_for(size_t n) { return coop_for(n, 2048); }       // three waves per element: 0.13-0.55 against 0.60 ms (1.02 at 4096)
 

@@ -471,6 +471,22 @@ __global__ void __launch_bounds__(WB_BLOCK, 4) k_ed25519_verify_check_wide(ProjS
     store_proj(scr, n, i, T);
 }
 
+// ... and on FOUR lanes per pair (quad::verify_check_wide_element: an addition in two product levels, inversion, encoding and the
+// comparison in the same launch) for calls of 2^10 .. 2^14 pairs -- where the one-lane kernel above leaves three quarters of the
+// SIMDs idle and every lane walks the whole 0.16 ms chain: what a caller with ONE remembered key and a few thousand signatures
+// per call runs (ed25519_verify.c:282-286).  16 pairs per one-wave workgroup; LDS: the lanes' parked columns of s and h.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_ed25519_verify_check_wide_quad(int* verdict, const void* sig, const u32* __restrict__ ctx, Msgs msgs, size_t n,
+                                 const u32* __restrict__ wide_base, const u32* __restrict__ wide_key, const u32* __restrict__ wide_ok)
+{
+    if (!*wide_ok) return;                                 // k_ed25519_verify_check_shared decides this batch
+    __shared__ unsigned short cols[2 * WB_COLS * 64];
+    const size_t e = (size_t)blockIdx.x * quad::ELEMS_PER_WAVE + (threadIdx.x >> 2);
+    if (e >= n) return;                                    // (whole quads leave)
+    quad::verify_check_wide_element(verdict, sig, ctx, msgs.ptr(e), msgs.len(e), e, wide_base, wide_key, cols + threadIdx.x,
+                                    cols + WB_COLS * 64 + threadIdx.x, 64);
+}
+
 namespace {
 
 // scratch of one verification pass: per-lane tables (the larger of the two paths' formats: they never live at the same
@@ -574,7 +590,7 @@ static int verify_dev(void* verdict, const void* sig, const void* pk, Msgs msgs,
     if (int rc = check_dev_args(n, { verdict, sig, pk })) return rc;
     if (n == 0) return 0;
     return verify_run(sig, pk, msgs, n, stream, (int*)verdict, fast,
-                      [&](const ProjScratch& scr) { return FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }; });
+                      [&](const ProjScratch& scr) { return FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n, nullptr }; });
 }
 
 // test hook: enc(T) instead of the verdict (what Verify_Check compares with enc(R)); device pointers
@@ -673,6 +689,7 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
     C25519_RC(lease.acquire(&w, (proj_words(n) + 4) * sizeof(u32), stream));
     const ProjScratch scr = carve_proj((u32*)w, n);
     u32* wide_ok = nullptr;
+    bool quads = false;
     c25519_host::KeepLease keep_lease;                      // records the kept buffer's event however this call leaves
     if (try_wide) {
         const u32* wide_base = nullptr;
@@ -696,14 +713,20 @@ int ed25519_Verify_Check_dev(void* verdict, const void* ctx, const void* sig, co
             k_ed25519_verify_ctx_remember<<<1, 128, 0, stream>>>(remembered, (const u32*)ctx, wide_ok);
             C25519_TRY(hipGetLastError());
         }
-        k_ed25519_verify_check_wide<<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(
-            scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, wide_base, wide_key, wide_ok);
+        quads = one_key_quad_for(n);
+        if (quads)                                          // four lanes per pair, the verdict in the same launch
+            k_ed25519_verify_check_wide_quad<<<grid_for(n, quad::ELEMS_PER_WAVE), 64, 0, stream>>>(
+                (int*)verdict, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, wide_base, wide_key, wide_ok);
+        else
+            k_ed25519_verify_check_wide<<<grid_for(n, WB_BLOCK), WB_BLOCK, 0, stream>>>(
+                scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, wide_base, wide_key, wide_ok);
         C25519_TRY(hipGetLastError());
     }
     k_ed25519_verify_check_shared<<<grid_for(n, ED_BLOCK), ED_BLOCK, 0, stream>>>(
         scr, sig, (const u32*)ctx, Msgs{ (const uint8_t*)msg, msg_size, nullptr }, n, tbl, wide_ok);
     C25519_TRY(hipGetLastError());
-    C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n }, stream));
+    // (the quad kernel has written the verdicts itself where the combs decided: the shared inversion then finds wide_ok set and leaves)
+    C25519_RC(launch_invert(scr, n, FinishVerify{ scr.a, scr.b, sig, (int*)verdict, n, quads ? wide_ok : nullptr }, stream));
     C25519_RC(keep_lease.release());
     return lease.release();
 }

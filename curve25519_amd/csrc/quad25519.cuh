@@ -397,6 +397,33 @@ C25519_DEV void base_mult_wide(fe& own, const u32* __restrict__ g_wide, const un
     }
 }
 
+// own <- s * B + h * P over TWO wide combs walked together (ge25519.cuh: ge_double_base_mult_wide; the two-phase verification's
+// key comb, engine_verify.hip): 40 additions from the neutral element and the same 4 doublings, the rows of the base point's and
+// of P's tables in turn, the next row fetched under the current addition.  colsB / colsP: this lane's parked columns of s and h.
+C25519_DEV void double_base_mult_wide(fe& own, const u32* __restrict__ wideB, const unsigned short* colsB, const u32* __restrict__ wideP,
+                                      const unsigned short* colsP, int stride, const Roles& R)
+{
+    fe mult;
+    field_raw cur, nxt;
+    ge_neutral(own, R);
+    wide_field_fetch(cur, wideB, colsB[0]);
+    nxt = cur;
+#pragma unroll 1
+    for (int k = 0; k < 2 * WB_COLS; k++) {
+        const int s = k >> 1, t = s & (WB_NT - 1);
+        if (k + 1 < 2 * WB_COLS) {
+            const int s1 = (k + 1) >> 1, t1 = s1 & (WB_NT - 1);
+            const u32* tb = ((k + 1) & 1) ? wideP : wideB;
+            const unsigned short* cc = ((k + 1) & 1) ? colsP : colsB;
+            wide_field_fetch(nxt, tb + (size_t)t1 * WB_ROWS * WB_ROW_WORDS, cc[s1 * stride]);
+        }
+        if (!(k & 1) && t == 0 && s) ge_double(own, R);
+        row_field_unpack(mult, cur, R);
+        ge_add_fields(own, mult, R);
+        cur = nxt;
+    }
+}
+
 // enc(P) (ed25519_PackPoint, curve25519_utils.c:77-98: y with the parity of x in bit 255) of own = (X, Y, T, Z), in every lane.
 // One inversion (ed25519_sign.c:265) by all four lanes; then x on q0 and y on q1 are one product.
 C25519_DEV void encode_point(u32 (&enc)[8], const fe& own)
@@ -473,6 +500,42 @@ C25519_DEV void public_fast_element(void* pk, void* sk, size_t e, const u32* __r
     fe_mul(num, num, zi);
     fe_to_words(w, num);
     if (R.is0) store32(pk, e, w);
+}
+
+// ed25519_Verify_Check (ed25519_verify.c:287-313) for pair e under ONE key whose wide comb exists (wideP: built for -A, the
+// context's row 1): T = s * B + h * (-A) over the two combs, enc(T) compared with the signature's R bytes -- the one-lane
+// kernel's steps (k_ed25519_verify_check_wide + the shared inversion) in one launch of quads.  An even h walks h + 1 and one -A
+// comes off again (never h + L: a key may carry torsion); s + L when even (L * B = O).
+C25519_DEV void verify_check_wide_element(int* verdict, const void* sig, const u32* __restrict__ ctx, const uint8_t* msg, size_t len, size_t e,
+                                          const u32* __restrict__ wideB, const u32* __restrict__ wideP, unsigned short* cs, unsigned short* ch,
+                                          int stride)
+{
+    const Roles R = roles();
+    u32 pkw[8], Sw[8], h[8], Rw[8], enc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) pkw[j] = ctx[j];
+    load32(Rw, sig, 2 * e);
+    ed_hram(h, Rw, pkw, msg, len);
+    sc_mod(h);
+    load32(Sw, sig, 2 * e + 1);                            // raw 256 bits: no s < L check (ed25519_verify.c:308)
+    wb_columns(cs, stride, Sw);
+    const u32 h_even = wb_columns<false>(ch, stride, h);
+    fe own, mult, neutral;
+    double_base_mult_wide(own, wideB, cs, wideP, ch, stride, R);
+    // - (-A) if h was even, + O otherwise: one more addition either way.  -A = row 1 of the context, (Y+X | Y-X | 2dT | 2Z = 2);
+    // the neutral element's row is (1 | 1 | 0 | 2)
+    field_raw rf;
+    row_field_fetch(rf, ctx + 8 + 32, 0xffffffffu);
+    row_field_unpack(mult, rf, R);
+    fe_set_u32(neutral, 0);
+    neutral.v[0] = ((R.is0 | R.is1) & 1u) | (R.is3 & 2u);
+    q_sel(mult, h_even, mult, neutral);
+    ge_add_fields(own, mult, R);
+    encode_point(enc, own);
+    u32 diff = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) diff |= enc[j] ^ Rw[j];
+    if (R.is0) verdict[e] = diff == 0 ? 1 : 0;
 }
 
 }  // namespace quad

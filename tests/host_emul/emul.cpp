@@ -652,6 +652,38 @@ void emul_quad_public_fast(unsigned char* pk, unsigned char* sk, size_t n)
         });
 }
 
+// ed25519_Verify_Check over two wide combs on quads (k_ed25519_verify_check_wide_quad: quad::verify_check_wide_element): the key's
+// context by the emulated Verify_Init, its comb as emul_ed25519_verify_check_wide builds it.  Returns 1 if the path applies.
+int emul_quad_verify_check_wide(int* verdict, const unsigned char* sig, const unsigned char* pk, const unsigned char* msg, size_t len, size_t n)
+{
+    u32 pkw[8], yw[8];
+    rd32(pkw, pk, 0);
+    for (int i = 0; i < 8; i++) yw[i] = pkw[i];
+    const u32 parity = yw[7] >> 31;
+    yw[7] &= 0x7fffffffu;
+    ge_ext Q;
+    fe_from_words(Q.Y, yw);
+    if (!ge_calc_x_checked(Q.X, Q.Y, ~parity)) return 0;
+    std::vector<u32> ctx(2080 / 4);
+    emul_ed25519_verify_init(reinterpret_cast<unsigned char*>(ctx.data()), pk, 1);
+    ge_pa P;
+    { u32 w[8]; memcpy(w, ctx.data() + 8 + 32, 32); fe_from_words(P.ypx, w); memcpy(w, ctx.data() + 8 + 40, 32); fe_from_words(P.ymx, w);
+      memcpy(w, ctx.data() + 8 + 48, 32); fe_from_words(P.t2d, w); }
+    std::vector<u32> wide_key;
+    build_wide_of(wide_key, P);
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    const u32* wide = wide_tables();
+    std::vector<unsigned short> cols(2 * WB_COLS * 64);
+    for (size_t base = 0; base < n; base += quad::ELEMS_PER_WAVE)
+        emul_coop::run_block(64, [&] {
+            const size_t e = base + (threadIdx.x >> 2);
+            if (e >= n) return;
+            quad::verify_check_wide_element(verdict, sig, ctx.data(), msg + len * e, len, e, wide, wide_key.data(), cols.data() + threadIdx.x,
+                                            cols.data() + WB_COLS * 64 + threadIdx.x, 64);
+        });
+    return 1;
+}
+
 // the lattice path with the WALK on quads (quad::walk_is_neutral): scalars, decoding and window tables by the one-lane code, as
 // k_ed25519_verify_quad_prep runs them (side by side: the points are tabulated as decoded, tau's sign reaches the walk as a flip of
 // the key rows' signs); then 16 elements per wave walk together from the wave's top digit (k_ed25519_verify_quad_walk).  need_slow: the elements the walk does not decide (their verdict stays 0).

@@ -268,12 +268,19 @@ def test_one_key_verification_over_two_wide_combs(dev, emul, oracle):
     the path must decline."""
     emul.emul_ed25519_verify_check_wide.argtypes = [vp, vp, vp, vp, sz, sz]
     emul.emul_ed25519_verify_check_wide.restype = C.c_int
+    emul.emul_quad_verify_check_wide.argtypes = [vp, vp, vp, vp, sz, sz]
+    emul.emul_quad_verify_check_wide.restype = C.c_int
 
     def wide(sig, key, msg):
         ok = np.full(sig.shape[0], -1, np.int32)
         msg = np.ascontiguousarray(msg)
         applies = emul.emul_ed25519_verify_check_wide(ptr(ok), ptr(np.ascontiguousarray(sig)), ptr(np.ascontiguousarray(key)),
                                                       ptr(msg), msg.shape[1], sig.shape[0])
+        # ... and on four lock-step lanes per pair (quad::verify_check_wide_element: what calls of 2^10 .. 2^14 pairs run)
+        okq = np.full(sig.shape[0], -1, np.int32)
+        appq = emul.emul_quad_verify_check_wide(ptr(okq), ptr(np.ascontiguousarray(sig)), ptr(np.ascontiguousarray(key)),
+                                                ptr(msg), msg.shape[1], sig.shape[0])
+        assert appq == applies and np.array_equal(okq, ok), "the quad kernel's verdicts differ from the one-lane kernel's"
         return applies, ok
 
     n = 96

@@ -58,12 +58,14 @@ def host_ms(n, reps=30):
 
 
 print(f"# tools/one_key_rate.py on {torch.cuda.get_device_name(0)}: ed25519_Verify_Check with ONE context, 32-byte messages; ms per call | M pairs/s")
-print(f"{'pairs':>8} {'remembered comb, _dev':>26} {'reference order, _dev':>26} {'x':>5} {'remembered comb, _batch':>28} {'reference order, _batch':>28} {'x':>5}")
+print(f"{'pairs':>8} {'remembered comb, _dev':>26} {'(one lane per pair)':>20} {'reference order, _dev':>26} {'x':>5} {'remembered comb, _batch':>28} {'reference order, _batch':>28} {'x':>5}")
 for lg in (11, 12, 13, 14, 15, 16):
     n = 1 << lg
     w_dev, w_host = dev_ms(n), host_ms(n)
     assert L.c25519_amd_verify_check_last_wide() == 1, n
+    with _lib.tunable("QUAD_MAX", 0):                                   # the combs walked by one lane per pair (what 2^15 pairs and more run)
+        l_dev = dev_ms(n)
     with _lib.tunable("ONE_KEY_WIDE", 0):
         r_dev, r_host = dev_ms(n), host_ms(n)
     cell = lambda ms: f"{ms:8.3f} ms {n / ms / 1e3:9.1f} M/s"  # noqa: E731
-    print(f"{'2^' + str(lg):>8} {cell(w_dev):>26} {cell(r_dev):>26} {r_dev / w_dev:5.2f} {cell(w_host):>28} {cell(r_host):>28} {r_host / w_host:5.2f}")
+    print(f"{'2^' + str(lg):>8} {cell(w_dev):>26} {l_dev:17.3f} ms {cell(r_dev):>26} {r_dev / w_dev:5.2f} {cell(w_host):>28} {cell(r_host):>28} {r_host / w_host:5.2f}")
