@@ -168,6 +168,9 @@ struct FinishVerify {                        // verdict = (enc(T) == enc(R) byte
     }
 };
 
+#ifndef C25519_INV_QUAD
+#define C25519_INV_QUAD 1            // A/B switch: 0 = every lane of k_batch_invert inverts its own product (profiles/r06_ab_inv_quad.txt)
+#endif
 constexpr int INV_BLOCK = 64;
 constexpr int INV_MAX_K = 16;
 
@@ -185,13 +188,13 @@ __global__ void __launch_bounds__(INV_BLOCK) __attribute__((amdgpu_waves_per_eu(
     constexpr bool PREFIX_IN_LDS = K > 14;
     __shared__ u32 pre_lds[PREFIX_IN_LDS ? (K - 1) * 10 * INV_BLOCK : 1];
     const size_t j = (size_t)blockIdx.x * INV_BLOCK + threadIdx.x;
-    if (j >= m) return;
+    const bool live = j < m;                                // (a lane past the end stays: its quad shares the inversion below)
     fe z[K], pre[PREFIX_IN_LDS ? 1 : K];
     u32 zero_mask = 0;
 #pragma unroll
     for (int t = 0; t < K; t++) {
         const size_t e = j + (size_t)t * m;
-        if (e < n) soa_load_fe(z[t], Z, n, e);
+        if (live && e < n) soa_load_fe(z[t], Z, n, e);
         else fe_set_u32(z[t], 1);                           // past the end: a factor of one
     }
     fe acc;
@@ -205,8 +208,24 @@ __global__ void __launch_bounds__(INV_BLOCK) __attribute__((amdgpu_waves_per_eu(
             else pre[t] = acc;
         }
     }
+    // ONE inversion per QUAD of lanes (4 K elements): the pairs' products, the quad's product T, 1 / T by the four lanes together
+    // (fe_invert_quad: the division steps' three pairs on three lanes, ~7 700 instructions instead of one lane's ~13 700), then
+    // each lane's own 1 / acc = (1 / T) * (the other pair's product) * (its partner's product)
     fe inv;
+#if C25519_INV_QUAD
+    {
+        fe partner, pair, other_pair, total;
+        quad::fe_qperm<1, 0, 3, 2>(partner, acc);
+        fe_mul(pair, acc, partner);
+        quad::fe_qperm<2, 3, 0, 1>(other_pair, pair);
+        fe_mul(total, pair, other_pair);
+        fe_invert_quad(inv, total);
+        fe_mul(inv, inv, other_pair);
+        fe_mul(inv, inv, partner);
+    }
+#else
     fe_invert(inv, acc);
+#endif
 #pragma unroll
     for (int t = K - 1; t >= 0; t--) {
         const size_t e = j + (size_t)t * m;
@@ -224,7 +243,7 @@ __global__ void __launch_bounds__(INV_BLOCK) __attribute__((amdgpu_waves_per_eu(
         fe zero;
         fe_set_u32(zero, 0);
         fe_select(zi, was_zero, zero, zi);
-        if (e < n) fin.emit(e, zi);
+        if (live && e < n) fin.emit(e, zi);
     }
 }
 
