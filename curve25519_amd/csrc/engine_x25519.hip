@@ -112,7 +112,20 @@ __global__ void __launch_bounds__(BLOCK, C25519_XF_WAVES) k_x25519_fused(void* o
             if (t < K - 1) lds_put_fe(pbuf + t * 640, 64, tid, acc);
         }
         fe inv;
+#if C25519_INV_QUAD
+        {   // one inversion per quad of the wave's lanes (k_batch_invert's exchange, engine_common.cuh)
+            fe partner, pair, other_pair, total;
+            quad::fe_qperm<1, 0, 3, 2>(partner, acc);
+            fe_mul(pair, acc, partner);
+            quad::fe_qperm<2, 3, 0, 1>(other_pair, pair);
+            fe_mul(total, pair, other_pair);
+            fe_invert_quad(inv, total);
+            fe_mul(inv, inv, other_pair);
+            fe_mul(inv, inv, partner);
+        }
+#else
         fe_invert(inv, acc);
+#endif
 #pragma unroll 1
         for (int t = K - 1; t >= 0; t--) {
             fe zi;
