@@ -4,7 +4,8 @@
 encodings of tests/vectors.py sprinkled through every batch.  Every round: 2^20 X25519 shared keys, 2^18 key pairs +
 signatures (unblinded and with a fresh blinding context), 2^18 verifications with corrupted entries, garbage keys and S + L
 rewrites, three one-key two-phase batches (honest / garbage / edge key); and, for the one-operation-per-wave
-kernels small calls run (csrc/coop25519.cuh), --small-calls calls of 1..2048 elements of every operation built the same way.
+kernels small calls run (csrc/coop25519.cuh), --small-calls calls of 1..2048 elements of every operation built the same way,
+--mid-calls calls of 2049 .. 2^15 elements (csrc/quad25519.cuh: four lanes per element; the one-key check with a remembered comb).
 
     python tests/long_differential.py [--rounds 8] [--seed 1]
 """
@@ -29,6 +30,7 @@ ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--small-calls", type=int, default=12, help="calls of a few elements per round and operation")
+ap.add_argument("--mid-calls", type=int, default=3, help="calls of 2049 .. 2^15 elements per round and operation (four lanes per element)")
 args = ap.parse_args()
 assert Reference.available(), "oracle/_ref is not built (make -C oracle ref)"
 ref = Reference()
@@ -144,5 +146,31 @@ for r in range(args.rounds):
         assert np.array_equal(one, want1), f"round {r}: small two-phase call {c} (n = {kk}) differs"
         for key in ("x25519", "keypair", "sign", "verify"):
             total["small " + key] = total.get("small " + key, 0) + k
+    # calls of a few thousand elements: four lanes per element (csrc/quad25519.cuh), and the one-key check with a comb the thread
+    # remembers from a call of 2^16 pairs with the same context
+    for c in range(args.mid_calls):
+        k = int(rng.integers(2049, (1 << 15) + 1))
+        lo = int(rng.integers(0, m - k))
+        a, b = api.curve25519_dh_CreateSharedKey(pk[lo:lo + k], sk[lo:lo + k])
+        assert np.array_equal(a, want[lo:lo + k]) and np.array_equal(b, want_sk[lo:lo + k]), f"round {r}: mid-size X25519 call {c} (n = {k}) differs"
+        fast, _ = api.curve25519_dh_CalculatePublicKey(sk[lo:lo + k], fast=True)
+        assert np.array_equal(fast, ref.x25519_public(sk[lo:lo + k], fast=True)[0]), f"round {r}: mid-size public-key call {c} (n = {k}) differs"
+        p2, q2 = api.ed25519_CreateKeyPair(esk[lo:lo + k])
+        assert np.array_equal(p2, pub[lo:lo + k]) and np.array_equal(q2, priv[lo:lo + k]), f"round {r}: mid-size keypair call {c} (n = {k}) differs"
+        assert np.array_equal(api.ed25519_SignMessage(priv[lo:lo + k], msg[lo:lo + k]), rsig[lo:lo + k]), f"round {r}: mid-size sign call {c} (n = {k}) differs"
+        assert np.array_equal(api.ed25519_VerifySignature(bsig[lo:lo + k], vpk[lo:lo + k], bmsg[lo:lo + k]), rok[lo:lo + k]), f"round {r}: mid-size verify call {c} (n = {k}) differs"
+        j = int(rng.integers(0, m))
+        big = 1 << 16
+        lo1 = int(rng.integers(0, m - big))
+        one_priv = np.ascontiguousarray(np.broadcast_to(priv[j], (big, 64)))
+        s1 = api.ed25519_SignMessage(one_priv, msg[lo1:lo1 + big])
+        s1b, m1, _ = synth.corrupt_for_verify(s1, msg[lo1:lo1 + big]) if mlen else (s1.copy(), msg[lo1:lo1 + big], None)
+        ctx = api.ed25519_Verify_Init(pub[j][None, :])[0]
+        rv = ref.ed25519_verify_threaded(s1b, np.ascontiguousarray(np.broadcast_to(pub[j], (big, 32))), m1, T)
+        assert np.array_equal(api.ed25519_Verify_Check(ctx, s1b, m1), rv), f"round {r}: one-key verdicts differ (n = 2^16)"
+        off = int(rng.integers(0, big - k))
+        assert np.array_equal(api.ed25519_Verify_Check(ctx, s1b[off:off + k], m1[off:off + k]), rv[off:off + k]), f"round {r}: one-key verdicts with the remembered comb differ (n = {k})"
+        for key in ("x25519", "keypair", "sign", "verify", "one-key verify"):
+            total["mid-size " + key] = total.get("mid-size " + key, 0) + k
     print(f"round {r}: ok (msg {mlen} B, accepted {int(ok.sum())} of {m})   {time.time() - t0:.0f} s", flush=True)
 print("long differential ok:", total)
