@@ -403,6 +403,7 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
             t.done_taken = false;
             for (unsigned long spins = 1;; spins++) {
                 if (__atomic_load_n(t.done_word, __ATOMIC_ACQUIRE) == t.done_seq) break;
+                __builtin_ia32_pause();                    // (a spin-wait hint: the sibling hyperthread keeps its issue slots)
                 if ((spins & 0x3fff) == 0 && hipEventQuery(t.done[l]) != hipErrorNotReady) {
                     C25519_TRY(hipEventSynchronize(t.done[l]));
                     break;

@@ -46,9 +46,13 @@ int  c25519_amd_set_device(int device);                /* device used by this ho
  * default 65536; a call of more than 1024 pairs whose context is the one the calling thread's last such batch built a comb for
  * walks that comb whatever its size; 0 = never), LADDER2_MAX (curve25519_dh_CreateSharedKey_*: the largest call that runs the
  * ladder on two waves per element, default 512; 0 = never), QUAD_MIN / QUAD_MAX (calls of more than QUAD_MIN and at most QUAD_MAX
- * elements run FOUR LANES per element -- X25519: the whole operation, defaults 3584 / 32768; ed25519_VerifySignature_*: the walk,
- * defaults 1024 / 32768; QUAD_MAX = 0: never).
- * _get returns -1 for "built-in choice", -2 for an unknown name. */
+ * elements run FOUR LANES per element -- X25519: the whole operation, defaults 3584 / 32768; ed25519_VerifySignature_*: scalars
+ * and point tables side by side, the walk on quads, defaults 1024 / 32768; key pairs, signatures, CalculatePublicKey_fast and the
+ * one-key ed25519_Verify_Check_* with a comb: the whole operation in one launch, defaults 1024 / 16384; QUAD_MAX = 0: never).
+ * _get returns -1 for "built-in choice", -2 for an unknown name.
+ * Environment only (read once): C25519_AMD_DONE_WORD=0 -- a host-pointer call of ONE element waits for the stream's event instead of
+ * the completion word its last kernel stores behind the results (5 us later; same bytes); C25519_AMD_ZERO_COPY=0 -- calls of a
+ * few elements are staged through device buffers like any batch. */
 int  c25519_amd_tunable_set(const char *name, long value);
 long c25519_amd_tunable_get(const char *name);
 int  c25519_amd_usable_cpus(void);                     /* CPUs this process may use (affinity mask cut to the cgroup quota) */
