@@ -124,11 +124,18 @@ C25519_DEV u32 carry_small(const Lane& L, u64 S)
 }
 
 // zero `words` words of the kernel's LDS (operand forms of secret intermediates, fetched table rows) before it returns
-C25519_DEV void wipe(u32* lds, int words)
+C25519_DEV void wipe(u32* lds, int words /* a multiple of 4; lds 16-byte aligned */)
 {
     wave_fence();
-    for (int i = (int)threadIdx.x; i < words; i += 64) lds[i] = 0;
+    uint4* p = reinterpret_cast<uint4*>(lds);
+    for (int i = (int)threadIdx.x; i < words / 4; i += 64) p[i] = make_uint4(0, 0, 0, 0);
     wave_fence();
+}
+// ... behind the completion word, if the caller waits for one (thread 0 has stored the results)
+C25519_DEV void finish(u32* lds, int words, const DoneWord* done)
+{
+    if (done && threadIdx.x == 0) signal_done(*done);
+    wipe(lds, words);
 }
 
 // a value's word offset in LDS for this lane's stores (idle lanes: the dump slot)

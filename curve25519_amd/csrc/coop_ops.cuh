@@ -39,7 +39,7 @@ C25519_DEV void setup_one(u32* lds, const Lane& L)
 
 // curve25519_dh_CreateSharedKey / CalculatePublicKey (curve25519_dh.c:94-157, 191-208) for element e.  lds: ROWQ_OFF words.
 template <bool BASE9>
-C25519_DEV void x25519_one(u32* lds, const Lane& L, void* out, const void* pk, void* sk, size_t e, const CallWords* cw = nullptr)
+C25519_DEV void x25519_one(u32* lds, const Lane& L, void* out, const void* pk, void* sk, size_t e, const CallWords* cw = nullptr, const DoneWord* done = nullptr)
 {
     u32 u[8] = { 9, 0, 0, 0, 0, 0, 0, 0 }, k[8];
     if (cw && cw->use) {                                 // a call of one: pk in words 0..7, sk in words 8..15 of the arguments
@@ -105,14 +105,14 @@ C25519_DEV void x25519_one(u32* lds, const Lane& L, void* out, const void* pk, v
     u32 wds[8];
     fe_to_words(wds, R);
     if (threadIdx.x == 0) store32(out, e, wds);         // written last: `out` may alias `pk`
-    wipe(lds, ROWQ_OFF);
+    finish(lds, ROWQ_OFF, done);
 }
 
 // curve25519_dh_CreateSharedKey for element e by a workgroup of TWO waves (coop25519.cuh: the ladder step in two product levels,
 // wave 0 the differential addition with x1 times the sum carried along, wave 1 the doubling): 510 levels and 255 barriers instead
 // of 765 levels.  lds_all: X2_LDS_WORDS words.  The set-up
 // and the tail (three doublings, inversion, canonical bytes) are x25519_one's, in a slot region of the wave's own.
-C25519_DEV void x25519_two_waves(u32* lds_all, void* out, const void* pk, void* sk, size_t e, const CallWords* cw = nullptr)
+C25519_DEV void x25519_two_waves(u32* lds_all, void* out, const void* pk, void* sk, size_t e, const CallWords* cw = nullptr, const DoneWord* done = nullptr)
 {
     const int wave = threadIdx.x >> 6;
     const Lane L = make_lane(threadIdx.x & 63);
@@ -178,7 +178,7 @@ C25519_DEV void x25519_two_waves(u32* lds_all, void* out, const void* pk, void* 
     u32 wds[8];
     fe_to_words(wds, R);
     if (threadIdx.x == 0) store32(out, e, wds);         // written last: `out` may alias `pk`
-    wipe(lds_all, X2_LDS_WORDS);
+    finish(lds_all, X2_LDS_WORDS, done);
 }
 
 // the fixed-base walk of the three operations below: over the wide comb (rows from device memory; a blinding context if given)
@@ -193,7 +193,7 @@ C25519_DEV u32 base_mult_one(u32* lds, const Lane& L, const u32 (&k)[8], const u
 // ed25519_CreateKeyPair (ed25519_sign.c:344-367) for element e.  lds: LDS_WORDS words.
 template <bool WIDE>
 C25519_DEV void keypair_one(u32* lds, const Lane& L, void* pub, void* priv, const void* sk, size_t e, const u32* __restrict__ g_tbl,
-                            const u32* __restrict__ blind_ctx)
+                            const u32* __restrict__ blind_ctx, const DoneWord* done = nullptr)
 {
     u32 seed[8], a[8], xw[8], yw[8], enc[8];
     u64 b_words[4];
@@ -208,12 +208,12 @@ C25519_DEV void keypair_one(u32* lds, const Lane& L, void* pub, void* priv, cons
         store32(priv, 2 * e + 1, enc);
         store32(pub, e, enc);
     }
-    wipe(lds, LDS_WORDS);
+    finish(lds, LDS_WORDS, done);
 }
 
 // curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189): S = clamp(sk) * B on the Edwards side, u = (Z + Y) / (Z - Y)
 template <bool WIDE>
-C25519_DEV void public_fast_one(u32* lds, const Lane& L, void* pk, void* sk, size_t e, const u32* __restrict__ g_tbl)
+C25519_DEV void public_fast_one(u32* lds, const Lane& L, void* pk, void* sk, size_t e, const u32* __restrict__ g_tbl, const DoneWord* done = nullptr)
 {
     u32 k[8], wds[8];
     load32(k, sk, e);
@@ -233,13 +233,13 @@ C25519_DEV void public_fast_one(u32* lds, const Lane& L, void* pk, void* sk, siz
     get_fe(R, lds, 0);
     fe_to_words(wds, R);
     if (threadIdx.x == 0) store32(pk, e, wds);
-    wipe(lds, LDS_WORDS);
+    finish(lds, LDS_WORDS, done);
 }
 
 // ed25519_SignMessage (ed25519_sign.c:370-422) for element e
 template <bool WIDE>
 C25519_DEV void sign_one(u32* lds, const Lane& L, void* sig, const void* priv, const Msgs& msgs, size_t e, const u32* __restrict__ g_tbl,
-                         const u32* __restrict__ blind_ctx)
+                         const u32* __restrict__ blind_ctx, const DoneWord* done = nullptr)
 {
     u32 seed[8], pkw[8], a[8], r[8], xw[8], yw[8], enc[8], s[8];
     load32(seed, priv, 2 * e);
@@ -254,11 +254,12 @@ C25519_DEV void sign_one(u32* lds, const Lane& L, void* sig, const void* priv, c
         store32(sig, 2 * e, enc);
         store32(sig, 2 * e + 1, s);
     }
-    wipe(lds, LDS_WORDS);
+    finish(lds, LDS_WORDS, done);
 }
 
 // ed25519_Blinding_Init (ed25519_sign.c:289-331) for one context: t * B over the wide comb and its affine conversion by the wave
-C25519_DEV void blinding_init_one(u32* lds, const Lane& L, u32* ctx, const uint8_t* seed, size_t seed_len, const u32* __restrict__ wide)
+C25519_DEV void blinding_init_one(u32* lds, const Lane& L, u32* ctx, const uint8_t* seed, size_t seed_len, const u32* __restrict__ wide,
+                                  const DoneWord* done = nullptr)
 {
     u32 t[8], bl[8], zr[8], xw[8], yw[8];
     ed_blinding_scalars(t, bl, zr, seed, seed_len);
@@ -266,7 +267,7 @@ C25519_DEV void blinding_init_one(u32* lds, const Lane& L, u32* ctx, const uint8
     const u32 v = ge_base_mult_wide(lds, L, t, wide);
     ge_affine_words(xw, yw, lds, L, v);
     if (threadIdx.x == 0) ed_blinding_store(ctx, bl, zr, xw, yw);
-    wipe(lds, LDS_WORDS);
+    finish(lds, LDS_WORDS, done);
 }
 
 // ed25519_Verify_Init (ed25519_verify.c:179-232) for key e: the square root and the 16-row table by the whole wave.  lds: Q_LDS_WORDS words; rows: the context's 16 rows.

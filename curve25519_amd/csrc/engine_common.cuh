@@ -96,18 +96,7 @@ C25519_DEV void store_proj(const ProjScratch& scr, size_t n, size_t i, const ge_
 
 constexpr int WB_BLOCK = 256;             // lanes per workgroup of the kernels that walk the wide comb (their parked column numbers: 10 KiB of LDS)
 
-// The completion word of a call of ONE element through the host-pointer prototypes (capi_common.hpp: ThreadState::done_word): the
-// call's last kernel stores `seq` into pinned host memory BEHIND its results -- by the thread that stored them, or behind a wave's
-// own stores: the fence waits for every store of the wave -- and the calling thread, which spins on the word, returns 4.6 us before
-// the runtime's event would let it (profiles/r06_launch_latency.txt).  word == nullptr: nobody is waiting that way.
-struct DoneWord { u32* word; u32 seq; };
-C25519_DEV void signal_done(const DoneWord& d)
-{
-    if (d.word) {
-        __threadfence_system();
-        __hip_atomic_store(d.word, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
+// (DoneWord / signal_done, the completion word of a call of ONE element: valu_gfx950.cuh)
 
 // ------------------------------------------------------------------------------------------------
 // batched inversion + output encoding

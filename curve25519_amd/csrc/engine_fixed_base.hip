@@ -223,8 +223,7 @@ k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u3
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
     if (blockIdx.x >= n) return;
-    coop::keypair_one<WIDE>(lds, coop::make_lane(threadIdx.x), pub, priv, sk, blockIdx.x, g_tbl, blind_ctx);
-    if (threadIdx.x == 0) signal_done(done);
+    coop::keypair_one<WIDE>(lds, coop::make_lane(threadIdx.x), pub, priv, sk, blockIdx.x, g_tbl, blind_ctx, &done);
 }
 
 // curve25519_dh_CalculatePublicKey_fast (curve25519_dh.c:162-189): S = clamp(sk) * B on the Edwards side, u = (Z + Y) / (Z - Y)
@@ -234,8 +233,7 @@ k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ 
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
     if (blockIdx.x >= n) return;
-    coop::public_fast_one<WIDE>(lds, coop::make_lane(threadIdx.x), pk, sk, blockIdx.x, g_tbl);
-    if (threadIdx.x == 0) signal_done(done);
+    coop::public_fast_one<WIDE>(lds, coop::make_lane(threadIdx.x), pk, sk, blockIdx.x, g_tbl, &done);
 }
 
 template <bool WIDE>
@@ -245,8 +243,7 @@ k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32*
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
     if (blockIdx.x >= n) return;
-    coop::sign_one<WIDE>(lds, coop::make_lane(threadIdx.x), sig, priv, msgs, blockIdx.x, g_tbl, blind_ctx);
-    if (threadIdx.x == 0) signal_done(done);
+    coop::sign_one<WIDE>(lds, coop::make_lane(threadIdx.x), sig, priv, msgs, blockIdx.x, g_tbl, blind_ctx, &done);
 }
 
 // The same three operations on FOUR lanes per element (quad25519.cuh), for calls between the per-wave kernels and the batches
@@ -298,8 +295,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_blinding_init_coop(u32* ctx, const uint8_t* seed, size_t seed_len, const u32* __restrict__ wide, DoneWord done)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
-    coop::blinding_init_one(lds, coop::make_lane(threadIdx.x), ctx, seed, seed_len, wide);
-    if (threadIdx.x == 0) signal_done(done);
+    coop::blinding_init_one(lds, coop::make_lane(threadIdx.x), ctx, seed, seed_len, wide, &done);
 }
 
 namespace {

@@ -219,8 +219,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::ROWQ_OFF];
     if (blockIdx.x >= n) return;
-    coop::x25519_one<BASE9>(lds, coop::make_lane(threadIdx.x), out, pk, sk, blockIdx.x, &cw);
-    if (threadIdx.x == 0) signal_done(done);
+    coop::x25519_one<BASE9>(lds, coop::make_lane(threadIdx.x), out, pk, sk, blockIdx.x, &cw, &done);    // (signals behind the result, before its LDS wipe)
 }
 
 // ... and on TWO waves per element (coop::x25519_two_waves: a ladder step in two product levels -- the differential addition with
@@ -230,8 +229,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 4))
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::X2_LDS_WORDS];
     if (blockIdx.x >= n) return;
-    coop::x25519_two_waves(lds, out, pk, sk, blockIdx.x, &cw);
-    if (threadIdx.x == 0) signal_done(done);               // (wave 0 stores; wave 1 has left inside)
+    coop::x25519_two_waves(lds, out, pk, sk, blockIdx.x, &cw, &done);    // (wave 0 stores, signals, wipes; wave 1 has left inside)
 }
 
 // FOUR LANES per element (quad25519.cuh): what a call of 2^12 .. 2^14 elements runs -- too many for a wave each, too few to

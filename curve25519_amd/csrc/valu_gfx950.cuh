@@ -156,6 +156,20 @@ C25519_DEV void sg_steps30_quad(int32_t& zeta, u32& X, u32& Y)
           [c1] "=&v"(c1), [c2] "=&v"(c2), [m] "=&v"(m), [n] "=&v"(n), [t] "=&v"(t), [g0] "=&v"(g0));
 }
 
+// The completion word of a call of ONE element through the host-pointer prototypes (capi_common.hpp: ThreadState::done_word): the
+// call's last kernel stores `seq` into pinned host memory BEHIND its results -- by the thread that stored them, or behind a wave's
+// own stores: the fence waits for every store of the wave -- and the calling thread, which spins on the word, returns 4.6 us before
+// the runtime's event would let it (profiles/r06_launch_latency.txt).  word == nullptr: nobody is waiting that way.  The per-wave
+// kernels signal BEFORE they wipe their LDS (coop_ops.cuh): the wipe (1.2-1.6 us) is not the caller's business.
+struct DoneWord { u32* word; u32 seq; };
+C25519_DEV void signal_done(const DoneWord& d)
+{
+    if (d.word) {
+        __threadfence_system();
+        __hip_atomic_store(d.word, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // acc += sum x[t]*y[t]: one asm statement per column, so the compiler cannot reassociate the chain (it would move
 // the carry-in to the end and re-create a separate 64-bit add) and does not pad every MAD with a wait state (it pads
 // asm boundaries only).  The SGPR pair receives the (never set) carry-out.

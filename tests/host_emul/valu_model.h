@@ -84,6 +84,8 @@ inline float fast_div(float a, float b) { return a / b; }
 inline u32 xor3_32(u32 a, u32 b, u32 c) { return a ^ b ^ c; }                                  // v_bitop3_b32 0x96
 inline u32 ch_32(u32 e, u32 f, u32 g) { return (e & f) | (~e & g); }                           // 0xca
 inline u32 maj_32(u32 a, u32 b, u32 c) { return (a & b) | (a & c) | (b & c); }                 // 0xe8
+struct DoneWord { u32* word; u32 seq; };                                                      // (valu_gfx950.cuh: the completion word)
+inline void signal_done(const DoneWord& d) { if (d.word) __atomic_store_n(d.word, d.seq, __ATOMIC_RELEASE); }
 inline u64 pair64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 inline u32 alignbit32(u32 hi, u32 lo, int s) { return (u32)((((u64)hi << 32) | lo) >> s); }
 
