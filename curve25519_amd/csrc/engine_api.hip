@@ -79,6 +79,17 @@ CallWords call_words(size_t n, const void* rec0, const void* rec1)
 // *_dev arguments: n in range, pointers 16-byte aligned and -- unless C25519_AMD_NO_PTR_CHECK is set -- device (or
 // managed) memory of the CURRENT device: a pointer of another GPU or a host pointer is an error here, not a fault
 // inside a kernel.
+// ... a record of up to 64 bytes from word 0 and a message of up to 64 bytes from word 16 (the fixed-base operations)
+CallWords call_record_and_message(size_t n, const void* rec, size_t rec_bytes, const void* msg, size_t msg_bytes)
+{
+    CallWords cw{};
+    if (n != 1 || !c25519_host::zero_copy_call() || rec_bytes > 64 || msg_bytes > 64) return cw;
+    memcpy(cw.w, rec, rec_bytes);
+    if (msg_bytes) memcpy(cw.w + 16, msg, msg_bytes);
+    cw.use = 1;
+    return cw;
+}
+
 int check_dev_args(size_t n, std::initializer_list<const void*> ptrs)
 {
     static const bool check_owner_env = getenv("C25519_AMD_NO_PTR_CHECK") == nullptr;

@@ -98,6 +98,18 @@ constexpr int WB_BLOCK = 256;             // lanes per workgroup of the kernels 
 
 // (DoneWord / signal_done, the completion word of a call of ONE element: valu_gfx950.cuh)
 
+// the records a one-element call carried in its kernel arguments (lanes.cuh: CallWords), laid down in LDS: the per-wave code then
+// loads them through the pointers it is given, as it loads everything else (flat addresses).  One-wave workgroups only.
+C25519_DEV const void* stage_call_words(u32* inl, const CallWords& cw)
+{
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < CALL_WORDS; i++) inl[i] = cw.w[i];
+    }
+    __syncthreads();
+    return inl;
+}
+
 // ------------------------------------------------------------------------------------------------
 // batched inversion + output encoding
 // ------------------------------------------------------------------------------------------------
@@ -255,6 +267,7 @@ int wide_tables(const u32** wide);
 // (engine_api.hip)
 DoneWord take_done_word(size_t n);
 CallWords call_words(size_t n, const void* rec0, const void* rec1);
+CallWords call_record_and_message(size_t n, const void* rec, size_t rec_bytes, const void* msg, size_t msg_bytes);
 int check_dev_args(size_t n, std::initializer_list<const void*> ptrs);
 // (engine_fixed_base.hip) blinding: null or a device-resident 192-byte context
 int keypair_dev(void* pub, void* priv, const void* sk, const void* blinding, size_t n, hipStream_t stream);

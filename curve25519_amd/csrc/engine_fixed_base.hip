@@ -219,10 +219,12 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_finish(void* sig, 
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u32* __restrict__ g_tbl,
-                       const u32* __restrict__ blind_ctx, DoneWord done)
+                       const u32* __restrict__ blind_ctx, DoneWord done, CallWords cw)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) u32 inl[CALL_WORDS];
     if (blockIdx.x >= n) return;
+    if (cw.use) sk = stage_call_words(inl, cw);            // a call of one: the secret came with the arguments (no PCIe read)
     coop::keypair_one<WIDE>(lds, coop::make_lane(threadIdx.x), pub, priv, sk, blockIdx.x, g_tbl, blind_ctx, &done);
 }
 
@@ -239,10 +241,15 @@ k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ 
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32* __restrict__ g_tbl,
-                    const u32* __restrict__ blind_ctx, DoneWord done)
+                    const u32* __restrict__ blind_ctx, DoneWord done, CallWords cw)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) u32 inl[CALL_WORDS];
     if (blockIdx.x >= n) return;
+    if (cw.use) {                                          // a call of one: key and message came with the arguments (three PCIe reads less)
+        priv = stage_call_words(inl, cw);
+        msgs.base = reinterpret_cast<const uint8_t*>(inl + 16);
+    }
     coop::sign_one<WIDE>(lds, coop::make_lane(threadIdx.x), sig, priv, msgs, blockIdx.x, g_tbl, blind_ctx, &done);
 }
 
@@ -425,8 +432,10 @@ int c25519_engine::keypair_dev(void* pub, void* priv, const void* sk, const void
         if (wide_comb) {
             const u32* wide = nullptr;
             C25519_RC(wide_tables(&wide));
-            k_ed25519_keypair_coop<true><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, wide, (const u32*)blinding, take_done_word(n));
-        } else k_ed25519_keypair_coop<false><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, tbl, nullptr, take_done_word(n));
+            k_ed25519_keypair_coop<true><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, wide, (const u32*)blinding, take_done_word(n),
+                                                                         call_record_and_message(n, sk, 32, nullptr, 0));
+        } else k_ed25519_keypair_coop<false><<<(unsigned)n, 64, 0, stream>>>(pub, priv, sk, n, tbl, nullptr, take_done_word(n),
+                                                                               call_record_and_message(n, sk, 32, nullptr, 0));
         C25519_TRY(hipGetLastError());
         return 0;
     }
@@ -480,11 +489,12 @@ int c25519_engine::sign_dev(void* sig, const void* priv, const void* blinding, M
         return 0;
     }
     if ((!blinding || wide_comb) && fixed_base_coop_for(n)) {   // a few elements: one operation per wave
+        const CallWords cw = msgs.offsets ? CallWords{} : call_record_and_message(n, priv, 64, msgs.base, msgs.fixed);
         if (wide_comb) {
             const u32* wide = nullptr;
             C25519_RC(wide_tables(&wide));
-            k_ed25519_sign_coop<true><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, wide, (const u32*)blinding, take_done_word(n));
-        } else k_ed25519_sign_coop<false><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, tbl, nullptr, take_done_word(n));
+            k_ed25519_sign_coop<true><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, wide, (const u32*)blinding, take_done_word(n), cw);
+        } else k_ed25519_sign_coop<false><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, tbl, nullptr, take_done_word(n), cw);
         C25519_TRY(hipGetLastError());
         return 0;
     }

@@ -55,7 +55,11 @@ C25519_DEV void soa_load8(u32 (&v)[8], const u32* base, size_t n, size_t i)
 // The input records of a call of ONE element, carried in the kernel's arguments (engine.hip: call_words): the first loads of a
 // zero-copy call read pinned host memory over PCIe -- ~1.1 us before anything can start (profiles/r06_launch_latency.txt) --,
 // the arguments arrive with the dispatch.  use == 0: the records are read from memory as in every other call.
-struct CallWords { u32 w[16]; u32 use; };
+// X25519: pk in words 0..7, sk in 8..15 (coop_ops.cuh reads them straight from the arguments).  The fixed-base operations: the
+// record (sk, or priv) from word 0, the message from word 16; the kernel lays them down in LDS and the per-wave code reads them
+// there through the pointers it is given (stage_call_words).
+constexpr int CALL_WORDS = 32;
+struct CallWords { u32 w[CALL_WORDS]; u32 use; };
 
 // messages of a batch: fixed stride (offsets == nullptr) or ragged (message i = base[offsets[i] .. offsets[i+1]))
 struct Msgs {

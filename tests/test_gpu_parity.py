@@ -1748,6 +1748,13 @@ def worker(seed, errors):
             v = L.ed25519_Verify_Check(ctx, buf(bsig[i]), buf(bmsg[i]), bmsg.shape[1])
             L.ed25519_Verify_Finish(ctx)
             assert v == int(orc.ed25519_verify(bsig[i:i + 1], epub[i:i + 1], bmsg[i:i + 1])[0]), ("check", i)
+        # a call of one carries its key and a message of up to 64 bytes in the kernel's arguments (lanes.cuh: CallWords): both sides of that
+        for mlen in (0, 1, 31, 63, 64, 65, 100, 257):
+            m1 = synth.random_bytes((1, max(mlen, 1)), seed + 3 + mlen)[:, :mlen]
+            sig = (C.c_ubyte * 64)()
+            L.ed25519_SignMessage(sig, buf(epriv[0]), None, buf(m1[0]) if mlen else None, mlen)
+            assert bytes(sig) == orc.ed25519_sign(epriv[:1], m1)[0].tobytes(), ("sign, message length", mlen)
+            assert L.ed25519_VerifySignature(sig, buf(epub[0]), buf(m1[0]) if mlen else None, mlen) == 1, ("verify, message length", mlen)
     except BaseException as e:
         errors.append(repr(e))
 errors = []
