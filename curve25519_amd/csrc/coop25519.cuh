@@ -600,12 +600,14 @@ C25519_DEV u32 ge_base_mult_wide(u32* lds, const Lane& L, const u32 (&k_in)[8], 
     }
     u32 cols[WB_COLS];                                    // (compile-time indices below: registers)
     wb_columns(cols, 1, k);
-    const u32 lane = L.row * 16 + L.c;
-    // every row fetch is issued before the walk starts (the addresses depend on the scalar alone)
+    // every row fetch is issued before the walk starts (the addresses depend on the scalar alone), the first row's first: the walk
+    // below is unrolled, the rows stay in registers, and an addition waits for ITS row only -- the later rows arrive under the
+    // earlier additions (fetched into LDS in front of a rolled loop, the first level waited ~2 us for all twenty)
+    const u32 ypx = wide_row_limb(wide, L, cols[0], 0), ymx = wide_row_limb(wide, L, cols[0], 1), t2d = wide_row_limb(wide, L, cols[0], 2);
+    u32 rowv[WB_COLS];
 #pragma unroll
     for (int s = 1; s < WB_COLS; s++)
-        lds[ROWQ_OFF + s * 64 + lane] = wide_row_limb(wide + (size_t)(s % WB_NT) * WB_ROWS * WB_ROW_WORDS, L, cols[s], by_row(L, 1, 0, 2, 2));
-    const u32 ypx = wide_row_limb(wide, L, cols[0], 0), ymx = wide_row_limb(wide, L, cols[0], 1), t2d = wide_row_limb(wide, L, cols[0], 2);
+        rowv[s] = wide_row_limb(wide + (size_t)(s % WB_NT) * WB_ROWS * WB_ROW_WORDS, L, cols[s], by_row(L, 1, 0, 2, 2));
     put_y(lds, L, SLOT_KDI, my_limb(lds, L, fe_const(K_DI)));
     const u32 two = L.c == 0 ? 2u : 0u;
     put_a(lds, L, L.row, L.upper ? (L.odd_row ? t2d : two) : (L.odd_row ? ypx + ymx : ypx + L.p2 - ymx));
@@ -615,12 +617,12 @@ C25519_DEV u32 ge_base_mult_wide(u32* lds, const Lane& L, const u32 (&k_in)[8], 
         put_y(lds, L, 4, packed_limb(blind + 8, L));
         v = mul_level(lds, L, L.row, 4);
     }
-#pragma unroll 1
+#pragma unroll
     for (int m = 0; m < WB_STEP; m++) {
         if (m) v = ge_dbl(lds, L, v);
-#pragma unroll 1
+#pragma unroll
         for (int t = m ? 0 : 1; t < WB_NT; t++)
-            v = ge_add(lds, L, v, lds[ROWQ_OFF + (m * WB_NT + t) * 64 + lane]);
+            v = ge_add(lds, L, v, rowv[m * WB_NT + t]);
     }
     if (blind) {                                          // + BP, a precomputed projective point (Y+X, Y-X, 2dT, 2Z)
 #pragma unroll
