@@ -138,6 +138,53 @@ C25519_DEV void finish(u32* lds, int words, const DoneWord* done)
     wipe(lds, words);
 }
 
+// ---- SHA-512 on TWO waves -------------------------------------------------------------------------------------------------
+// The hashes of a signature are three compressions in a row on the call's critical path, each 80 rounds of 47 instructions of
+// which 19 are the message schedule -- work that does not depend on the round state.  A second wave of the workgroup computes
+// it: wave 0 publishes the block's sixteen words, runs rounds 0..15 on its own copy while the helper expands words 16..31 (K
+// added), and from there every sixteen rounds take their words ready-made from LDS (sha512_rounds16_wk: 28 instructions a round)
+// while the helper is a chunk ahead: five workgroup barriers a block, ~2 300 instructions on wave 0 instead of ~3 750.  The
+// helper must serve exactly the compressions wave 0 performs, in order (sha512_blocks counts them); between hashes it waits at a
+// barrier and issues nothing.  wk: 80 64-bit words of LDS.
+struct ShaTwoWaves {
+    u64* wk;
+    C25519_DEV void compress(u64 (&st)[8], u64 (&w)[16]) const
+    {
+        if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) wk[i] = w[i];
+        }
+        __syncthreads();                                  // the helper may read the block
+        u64 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = st[i];
+        sha512_rounds16<false>(v, w, 0);
+#pragma unroll 1
+        for (int r = 16; r < 80; r += 16) {
+            __syncthreads();                              // words r .. r + 15 are there
+            sha512_rounds16_wk(v, wk + r);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) st[i] += v[i];
+    }
+};
+// the helper wave: `blocks` compressions' schedules, then it is done
+C25519_DEV void sha_schedule_server(u64* wk, int blocks)
+{
+#pragma unroll 1
+    for (int b = 0; b < blocks; b++) {
+        __syncthreads();
+        u64 w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = wk[i];
+#pragma unroll 1
+        for (int r = 16; r < 80; r += 16) {
+            sha512_schedule16_wk(w, wk + r, r);
+            __syncthreads();
+        }
+    }
+}
+
 // a value's word offset in LDS for this lane's stores (idle lanes: the dump slot)
 C25519_DEV u32 store_base(const Lane& L, u32 slot) { return ((L.wr ? (u32)SLOT_DUMP : slot)) * SLOT_WORDS; }
 

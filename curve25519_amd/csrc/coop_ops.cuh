@@ -191,14 +191,14 @@ C25519_DEV u32 base_mult_one(u32* lds, const Lane& L, const u32 (&k)[8], const u
 }
 
 // ed25519_CreateKeyPair (ed25519_sign.c:344-367) for element e.  lds: LDS_WORDS words.
-template <bool WIDE>
+template <bool WIDE, typename Sha = ShaPlain>
 C25519_DEV void keypair_one(u32* lds, const Lane& L, void* pub, void* priv, const void* sk, size_t e, const u32* __restrict__ g_tbl,
-                            const u32* __restrict__ blind_ctx, const DoneWord* done = nullptr)
+                            const u32* __restrict__ blind_ctx, const DoneWord* done = nullptr, const Sha& sha = Sha())
 {
     u32 seed[8], a[8], xw[8], yw[8], enc[8];
     u64 b_words[4];
     load32(seed, sk, e);
-    ed_expand_seed(a, b_words, seed);
+    ed_expand_seed(a, b_words, seed, sha);
     setup_one(lds, L);
     const u32 v = base_mult_one<WIDE>(lds, L, a, g_tbl, blind_ctx);
     ge_affine_words(xw, yw, lds, L, v);
@@ -237,19 +237,19 @@ C25519_DEV void public_fast_one(u32* lds, const Lane& L, void* pk, void* sk, siz
 }
 
 // ed25519_SignMessage (ed25519_sign.c:370-422) for element e
-template <bool WIDE>
+template <bool WIDE, typename Sha = ShaPlain>
 C25519_DEV void sign_one(u32* lds, const Lane& L, void* sig, const void* priv, const Msgs& msgs, size_t e, const u32* __restrict__ g_tbl,
-                         const u32* __restrict__ blind_ctx, const DoneWord* done = nullptr)
+                         const u32* __restrict__ blind_ctx, const DoneWord* done = nullptr, const Sha& sha = Sha())
 {
     u32 seed[8], pkw[8], a[8], r[8], xw[8], yw[8], enc[8], s[8];
     load32(seed, priv, 2 * e);
     load32(pkw, priv, 2 * e + 1);
-    ed_sign_nonce(a, r, seed, msgs.ptr(e), msgs.len(e));
+    ed_sign_nonce(a, r, seed, msgs.ptr(e), msgs.len(e), sha);
     setup_one(lds, L);
     const u32 v = base_mult_one<WIDE>(lds, L, r, g_tbl, blind_ctx);
     ge_affine_words(xw, yw, lds, L, v);
     ge_pack(enc, xw, yw);
-    ed_sign_s(s, enc, pkw, msgs.ptr(e), msgs.len(e), a, r);
+    ed_sign_s(s, enc, pkw, msgs.ptr(e), msgs.len(e), a, r, sha);
     if (threadIdx.x == 0) {
         store32(sig, 2 * e, enc);
         store32(sig, 2 * e + 1, s);

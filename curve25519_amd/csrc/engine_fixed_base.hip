@@ -216,6 +216,12 @@ __global__ void __launch_bounds__(ED_BLOCK, 2) k_ed25519_sign_finish(void* sig, 
 // The same three operations for a call of a few elements, ONE operation per wave (coop25519.cuh): hashing and scalar
 // arithmetic by every lane on the same values, the fixed-base walk, the inversion and the affine conversion cooperative.
 // (A blinding context: over the wide comb only -- with the LDS comb a blinded call runs the batch kernels.)
+// Signatures: a workgroup of TWO waves -- the second computes the message schedules of the three hashes' SHA-512 compressions a
+// chunk ahead of the first wave's rounds (coop25519.cuh: ShaTwoWaves) and is gone when the last hash is: one signature 65.8 ->
+// 63.0 us.  (Measured from inside, profiles/r06_sign_stamps.txt: a compression 7.0 -> 5.5 us, not the 4.3 its instruction count
+// promised -- the rounds alone are one dependent chain, which the schedule's instructions used to fill; a key pair's single block
+// gains nothing over the second wave's launch and stays on one wave.)
+constexpr int COOP_SHA_BLOCK = 128;
 template <bool WIDE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_keypair_coop(void* pub, void* priv, const void* sk, size_t n, const u32* __restrict__ g_tbl,
@@ -239,18 +245,24 @@ k_x25519_public_fast_coop(void* pk, void* sk, size_t n, const u32* __restrict__ 
 }
 
 template <bool WIDE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4)))
+__global__ void __launch_bounds__(COOP_SHA_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_ed25519_sign_coop(void* sig, const void* priv, Msgs msgs, size_t n, const u32* __restrict__ g_tbl,
                     const u32* __restrict__ blind_ctx, DoneWord done, CallWords cw)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[coop::LDS_WORDS];
     __shared__ __attribute__((aligned(16))) u32 inl[CALL_WORDS];
+    __shared__ u64 sha_wk[80];
     if (blockIdx.x >= n) return;
     if (cw.use) {                                          // a call of one: key and message came with the arguments (three PCIe reads less)
         priv = stage_call_words(inl, cw);
         msgs.base = reinterpret_cast<const uint8_t*>(inl + 16);
     }
-    coop::sign_one<WIDE>(lds, coop::make_lane(threadIdx.x), sig, priv, msgs, blockIdx.x, g_tbl, blind_ctx, &done);
+    if (threadIdx.x >= 64) {                               // H(sk), H(prefix || m), H(enc(R) || pk || m)
+        const size_t len = msgs.len(blockIdx.x);
+        coop::sha_schedule_server(sha_wk, 1 + sha512_blocks(4, len) + sha512_blocks(8, len));
+        return;
+    }
+    coop::sign_one<WIDE>(lds, coop::make_lane(threadIdx.x), sig, priv, msgs, blockIdx.x, g_tbl, blind_ctx, &done, coop::ShaTwoWaves{ sha_wk });
 }
 
 // The same three operations on FOUR lanes per element (quad25519.cuh), for calls between the per-wave kernels and the batches
@@ -493,8 +505,8 @@ int c25519_engine::sign_dev(void* sig, const void* priv, const void* blinding, M
         if (wide_comb) {
             const u32* wide = nullptr;
             C25519_RC(wide_tables(&wide));
-            k_ed25519_sign_coop<true><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, wide, (const u32*)blinding, take_done_word(n), cw);
-        } else k_ed25519_sign_coop<false><<<(unsigned)n, 64, 0, stream>>>(sig, priv, msgs, n, tbl, nullptr, take_done_word(n), cw);
+            k_ed25519_sign_coop<true><<<(unsigned)n, COOP_SHA_BLOCK, 0, stream>>>(sig, priv, msgs, n, wide, (const u32*)blinding, take_done_word(n), cw);
+        } else k_ed25519_sign_coop<false><<<(unsigned)n, COOP_SHA_BLOCK, 0, stream>>>(sig, priv, msgs, n, tbl, nullptr, take_done_word(n), cw);
         C25519_TRY(hipGetLastError());
         return 0;
     }

@@ -72,11 +72,12 @@ struct Msgs {
 
 // ---- Ed25519 hashing / scalar steps ---------------------------------------------------------------------------
 // a = clamp(first half of SHA-512(seed)); the second half as 4 big-endian stream words   (ed25519_sign.c:355-360)
-C25519_DEV void ed_expand_seed(u32 (&a)[8], u64 (&b_words)[4], const u32 (&seed)[8])
+template <typename Sha = ShaPlain>
+C25519_DEV void ed_expand_seed(u32 (&a)[8], u64 (&b_words)[4], const u32 (&seed)[8], const Sha& sha = Sha())
 {
     u64 pre[4], dg[8];
     sha512_words_from_le32(pre, seed);
-    sha512_prefixed<4>(dg, pre, nullptr, 0);
+    sha512_prefixed<4>(dg, pre, nullptr, 0, sha);
     u32 le[16];
     sha512_digest_le_words(le, dg);
 #pragma unroll
@@ -87,35 +88,38 @@ C25519_DEV void ed_expand_seed(u32 (&a)[8], u64 (&b_words)[4], const u32 (&seed)
 }
 
 // first part of ed25519_SignMessage (:385-397): a = clamp(H(sk)[0..31]), r = H(H(sk)[32..63] || m) mod L, canonical
-C25519_DEV void ed_sign_nonce(u32 (&a)[8], u32 (&r)[8], const u32 (&seed)[8], const uint8_t* msg, size_t len)
+template <typename Sha = ShaPlain>
+C25519_DEV void ed_sign_nonce(u32 (&a)[8], u32 (&r)[8], const u32 (&seed)[8], const uint8_t* msg, size_t len, const Sha& sha = Sha())
 {
     u64 b_words[4], dg[8];
     u32 le[16];
-    ed_expand_seed(a, b_words, seed);
-    sha512_prefixed<4>(dg, b_words, msg, len);
+    ed_expand_seed(a, b_words, seed, sha);
+    sha512_prefixed<4>(dg, b_words, msg, len, sha);
     sha512_digest_le_words(le, dg);
     sc_reduce512(r, le);
     sc_mod(r);
 }
 
 // h = H(enc(R) || pk || m) reduced to 256 bits, congruent mod L (not canonical)   (:404-409 / ed25519_verify.c:298-305)
-C25519_DEV void ed_hram(u32 (&h)[8], const u32 (&encR)[8], const u32 (&pkw)[8], const uint8_t* msg, size_t len)
+template <typename Sha = ShaPlain>
+C25519_DEV void ed_hram(u32 (&h)[8], const u32 (&encR)[8], const u32 (&pkw)[8], const uint8_t* msg, size_t len, const Sha& sha = Sha())
 {
     u32 le[16];
     u64 pre[8], dg[8];
     sha512_words_from_le32(pre, encR);
     sha512_words_from_le32(pre + 4, pkw);
-    sha512_prefixed<8>(dg, pre, msg, len);
+    sha512_prefixed<8>(dg, pre, msg, len, sha);
     sha512_digest_le_words(le, dg);
     sc_reduce512(h, le);
 }
 
 // last part of ed25519_SignMessage (:404-414): S = H(enc(R) || pk || m) * a + r mod L, canonical
+template <typename Sha = ShaPlain>
 C25519_DEV void ed_sign_s(u32 (&s)[8], const u32 (&encR)[8], const u32 (&pkw)[8], const uint8_t* msg, size_t len,
-                          const u32 (&a)[8], const u32 (&r)[8])
+                          const u32 (&a)[8], const u32 (&r)[8], const Sha& sha = Sha())
 {
     u32 h[8];
-    ed_hram(h, encR, pkw, msg, len);
+    ed_hram(h, encR, pkw, msg, len, sha);
     sc_mul(s, h, a);
     sc_add(s, s, r);
     sc_mod(s);

@@ -103,6 +103,41 @@ C25519_DEV void sha512_compress(u64 (&st)[8], u64 (&w)[16])
     for (int i = 0; i < 8; i++) st[i] += v[i];
 }
 
+// sixteen rounds whose schedule words come ready-made, K already added (wk[i] = W[r + i] + K[r + i]): 28 instructions a round
+// instead of 47 -- the rounds' share of a compression whose schedule another wave computes (coop25519.cuh: ShaTwoWaves)
+C25519_DEV void sha512_rounds16_wk(u64 (&v)[8], const u64* wk)
+{
+    u64 a = v[0], b = v[1], c = v[2], d = v[3], e = v[4], f = v[5], g = v[6], h = v[7];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const u64 S1 = xor3_64(rotr64(e, 14), rotr64(e, 18), rotr64(e, 41));
+        const u64 t1 = h + S1 + ch_64(e, f, g) + wk[i];
+        const u64 S0 = xor3_64(rotr64(a, 28), rotr64(a, 34), rotr64(a, 39));
+        const u64 t2 = S0 + maj_64(a, b, c);
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    v[0] = a; v[1] = b; v[2] = c; v[3] = d; v[4] = e; v[5] = f; v[6] = g; v[7] = h;
+}
+// the next sixteen schedule words from the last sixteen (in place), each stored as W + K for sha512_rounds16_wk
+C25519_DEV void sha512_schedule16_wk(u64 (&w)[16], u64* wk_out, int r)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const u64 w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+        const u64 s0 = xor3_64(rotr64(w15, 1), rotr64(w15, 8), w15 >> 7);
+        const u64 s1 = xor3_64(rotr64(w2, 19), rotr64(w2, 61), w2 >> 6);
+        w[i] += s0 + w[(i + 9) & 15] + s1;
+        wk_out[i] = w[i] + SHA512_K[r + i];
+    }
+}
+
+// how a block is compressed: by the calling lane alone (every kernel but the per-wave fixed-base ones)
+struct ShaPlain {
+    C25519_DEV void compress(u64 (&st)[8], u64 (&w)[16]) const { sha512_compress(st, w); }
+};
+// blocks SHA-512(prefix of PW words || len message bytes) takes: what a helper that serves the compressions must count
+C25519_DEV int sha512_blocks(int prefix_words, size_t len) { return (int)((8 * (size_t)prefix_words + len + 17 + 127) / 128); }
+
 // m-th 64-bit big-endian word of  message || 0x80 || 0...  (without the trailing length words)
 C25519_DEV u64 sha512_msg_word(const uint8_t* msg, size_t len, size_t m)
 {
@@ -127,8 +162,8 @@ C25519_DEV u64 sha512_msg_word(const uint8_t* msg, size_t len, size_t m)
 }
 
 // digest = SHA-512(prefix[0..PW) as big-endian words || msg[0..len)).  PW = 4 or 8.
-template <int PW>
-C25519_DEV void sha512_prefixed(u64 (&digest)[8], const u64 (&prefix)[PW], const uint8_t* msg, size_t len)
+template <int PW, typename Sha = ShaPlain>
+C25519_DEV void sha512_prefixed(u64 (&digest)[8], const u64 (&prefix)[PW], const uint8_t* msg, size_t len, const Sha& sha = Sha())
 {
     u64 st[8] = { 0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
                   0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull };
@@ -151,7 +186,7 @@ C25519_DEV void sha512_prefixed(u64 (&digest)[8], const u64 (&prefix)[PW], const
 #ifdef C25519_SHA_LOW_PRIO                               // A/B knob: the compression (no multiplies) as a low-priority run
         C25519_VOP2_RUN_BEGIN();
 #endif
-        sha512_compress(st, w);
+        sha.compress(st, w);
 #ifdef C25519_SHA_LOW_PRIO
         C25519_VOP2_RUN_END();
 #endif

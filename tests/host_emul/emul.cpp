@@ -765,11 +765,14 @@ void emul_coop_sign(unsigned char* sig, const unsigned char* priv, const unsigne
     std::vector<u32> lds(coop::LDS_WORDS);
     const u32* tbl = wide ? wide_tables() : tables();
     const Msgs msgs{ msg, len, nullptr };
+    std::vector<u64> sha_wk(80);                         // as k_ed25519_sign_coop: the second wave serves every compression of the three hashes
     for (size_t e = 0; e < n; e++)
-        emul_coop::run_block(64, [&] {
+        emul_coop::run_block(128, [&] {
+            if (threadIdx.x >= 64) { coop::sha_schedule_server(sha_wk.data(), 1 + sha512_blocks(4, len) + sha512_blocks(8, len)); return; }
             const coop::Lane L = coop::make_lane(threadIdx.x);
-            if (wide) coop::sign_one<true>(lds.data(), L, sig, priv, msgs, e, tbl, reinterpret_cast<const u32*>(blinding));
-            else coop::sign_one<false>(lds.data(), L, sig, priv, msgs, e, tbl, nullptr);
+            const coop::ShaTwoWaves sha{ sha_wk.data() };
+            if (wide) coop::sign_one<true>(lds.data(), L, sig, priv, msgs, e, tbl, reinterpret_cast<const u32*>(blinding), nullptr, sha);
+            else coop::sign_one<false>(lds.data(), L, sig, priv, msgs, e, tbl, nullptr, nullptr, sha);
         });
 }
 
