@@ -186,6 +186,33 @@ def valu_issue(kernels):
         return None
 
 
+def single_call_latencies(L, e, reps=300):
+    """ONE operation through the reference's own prototypes (include/curve25519_dh.h, include/ed25519_signature.h: host pointers, a
+    device batch of one), wall clock per call in microseconds, outputs checked against the device-resident batch's"""
+    import ctypes as C
+    buf = lambda b: (C.c_ubyte * len(b)).from_buffer_copy(bytes(b))  # noqa: E731
+    row = lambda t: t[0].cpu().numpy().tobytes()  # noqa: E731
+    esk, msg, pub_w, priv_w, sig_w = row(e["esk"]), row(e["msg"]), row(e["pub"]), row(e["priv"]), row(e["sig"])
+    pub, priv, sig, shared = (C.c_ubyte * 32)(), (C.c_ubyte * 64)(), (C.c_ubyte * 64)(), (C.c_ubyte * 32)()
+    sk, pk = buf(esk), buf(pub_w)
+
+    def wall(fn):
+        for _ in range(30):
+            fn()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return round((time.perf_counter() - t) / reps * 1e6, 1)
+
+    out = {"curve25519_dh_CreateSharedKey": wall(lambda: L.curve25519_dh_CreateSharedKey(shared, pk, sk)),
+           "ed25519_CreateKeyPair": wall(lambda: L.ed25519_CreateKeyPair(pub, priv, None, buf(esk))),
+           "ed25519_SignMessage": wall(lambda: L.ed25519_SignMessage(sig, priv, None, buf(msg), len(msg))),
+           "ed25519_VerifySignature": wall(lambda: L.ed25519_VerifySignature(sig, pub, buf(msg), len(msg)))}
+    out["bytes_equal_the_batch"] = bool(bytes(pub) == pub_w and bytes(priv) == priv_w and bytes(sig) == sig_w
+                                        and L.ed25519_VerifySignature(sig, pub, buf(msg), len(msg)) == 1)
+    return out
+
+
 def measured_traffic(kernels):
     """HBM bytes per pass from the committed rocprofv3 PMC passes (separate --pmc runs of this same bench,
     summarised by tools/rocpd_summary.py): WRITE_SIZE + 2 x FETCH_SIZE, both in KiB -- the x2 is the gfx950
@@ -930,6 +957,26 @@ def main():
             r0 = run_timed([mk(n)], ramp=False)
             off[name + "_per_s"] = round(n * args.steps / r0["elapsed"], 1)
         extra["clock_ramp_off"] = off
+        # calls of a few thousand elements (four lanes per element: csrc/quad25519.cuh) and ONE call through the reference's own
+        # prototypes (one operation per wave, the completion word): what a caller that does not gather 2^17 operations per call gets.
+        # Device-resident prefixes of the bench's own arrays, HIP events; single calls: wall clock around the C call, host pointers.
+        mid = {}
+        xs = {"sk": up(synth.random_bytes((1 << 14, 32), synth.SEED_X25519_SK + seed_shift)),
+              "pk": up(synth.random_bytes((1 << 14, 32), synth.SEED_X25519_PK + seed_shift))}
+        for lg in (12, 14):
+            m = 1 << lg
+            out_m = torch.empty((m, 32), dtype=torch.uint8, device=dev)
+            sig_m, ok_m = torch.empty((m, 64), dtype=torch.uint8, device=dev), torch.empty((m, 1), dtype=torch.int32, device=dev)
+            skc = xs["sk"][:m].clone()
+            calls = {"x25519": lambda: eng.api.curve25519_dh_CreateSharedKey_dev(out_m, xs["pk"][:m], skc),
+                     "sign": lambda: eng.api.ed25519_SignMessage_dev(sig_m, e["priv"][:m], e["msg"][:m]),
+                     "verify": lambda: eng.api.ed25519_VerifySignature_dev(ok_m, e["sig"][:m], e["pub"][:m], e["msg"][:m])}
+            for name, fn in calls.items():
+                mid.setdefault(name, {})[f"2^{lg}"] = {"ms_per_call": round(timeit(fn, reps=20), 4)}
+                mid[name][f"2^{lg}"]["per_s"] = round(m / (mid[name][f"2^{lg}"]["ms_per_call"] * 1e-3), 1)
+            mid["verify"][f"2^{lg}"]["all_valid"] = bool(int(ok_m.sum().item()) == m)
+        extra["mid_size_calls"] = mid
+        extra["single_call_us"] = single_call_latencies(L, e)
         result["extra"] = extra
 
     if use_dist:
