@@ -175,3 +175,21 @@ def test_rank_attestation_says_what_rccl_saw():
     assert a["devices_distinct"] and a["compute_partitions_of_one_device"] and not a["is_multi_gpu_measurement"]
     one = bench.attest_ranks([ident(0, "GPU-00", "0000:10:00", 0)], 1, None, False)
     assert one["devices_distinct"] and not one["is_multi_gpu_measurement"] and one["backend"] is None
+
+
+def test_the_committed_line_carries_the_mid_size_and_single_call_figures():
+    """The round's work where the driver records it (VERDICT r05 missing #2 / #3): calls of 2^12 / 2^14 elements and ONE call through
+    the reference's prototypes are measured by bench.py itself (`extra.mid_size_calls`, `extra.single_call_us`), checked for
+    correctness in the same run, and the committed line of the round has them."""
+    import glob
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench.json")))[-1]
+    line = json.loads([l for l in open(path) if l.startswith("{")][-1])
+    mid, one = line["extra"]["mid_size_calls"], line["extra"]["single_call_us"]
+    for op in ("x25519", "sign", "verify"):
+        for size in ("2^12", "2^14"):
+            rec = mid[op][size]
+            assert rec["ms_per_call"] > 0 and abs(rec["per_s"] * rec["ms_per_call"] * 1e-3 / (1 << int(size[2:])) - 1) < 1e-3
+    assert mid["verify"]["2^12"]["all_valid"] and mid["verify"]["2^14"]["all_valid"]
+    assert mid["x25519"]["2^14"]["per_s"] > 4 * 9.6e6 and mid["sign"]["2^12"]["per_s"] > 2 * 22.8e6       # round 5: 2^12 X25519 9.6 M/s, 2^12 signatures 22.8 M/s
+    assert one["bytes_equal_the_batch"] is True
+    assert one["curve25519_dh_CreateSharedKey"] < 168 and one["ed25519_SignMessage"] < 105 and one["ed25519_VerifySignature"] < 135   # round 5's
