@@ -68,12 +68,79 @@ C25519_DEV void sc_mod(u32 (&x)[8])
     }
 }
 
-// y = t[0..15] mod-ish L (256 bits, not canonical); t is destroyed.   (eco_DigestToWords / tail of eco_MulReduce)
+// hi[0..N) * 16c -> p[0..N+5)   (16c = -2^256 mod L, 129 bits: K_MINUS_R)
+template <int N>
+C25519_DEV void sc_times_16c(u32 (&p)[N + 5], const u32* hi)
+{
+#pragma unroll
+    for (int i = 0; i < N + 5; i++) p[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        u32 carry = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const u64 q = (u64)hi[i] * K_MINUS_R[j] + p[i + j] + carry;
+            p[i + j] = (u32)q;
+            carry = (u32)(q >> 32);
+        }
+        p[i + 5] = carry;
+    }
+}
+
+// y = t[0..15] mod-ish L (256 bits, not canonical).   (eco_DigestToWords / tail of eco_MulReduce)
+// Two folds of everything above bit 256 with 2^256 = -16c (mod L), each kept non-negative by a multiple of L that exceeds what it
+// subtracts (L << 134 > 2^385, L << 9 > 2^260; "- p" as "+ ~p + 1" in a fixed number of words), then the split at bit 252 of
+// sc_mod: 40 + 25 + 4 multiply-adds and three carry chains, ~250 instructions; the reference's Horner fold of one top word at a
+// time (eco_ReduceHiWord eight times: sc_reduce_hi, still what sc_add uses) is ~650.  Any correct reduction gives the reference's
+// bytes: only canonical results are exported.
 C25519_DEV void sc_reduce512(u32 (&y)[8], u32 (&t)[16])
 {
+#if defined(C25519_SC_REDUCE_HORNER) && C25519_SC_REDUCE_HORNER      // A/B knob: the reference's fold, one top word at a time
 #pragma unroll
     for (int k = 7; k >= 1; k--) sc_reduce_hi(&t[k], t[k + 8], &t[k]);
     sc_reduce_hi(y, t[8], &t[0]);
+    return;
+#endif
+    u32 p1[13], y1[13];
+    sc_times_16c<8>(p1, &t[8]);
+    u64 c = 1;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        c += (u64)(k < 8 ? t[k] : 0u) + K_L_SHL134[k] + (u32)~p1[k];
+        y1[k] = (u32)c;
+        c >>= 32;
+    }
+    u32 p2[10], y2[9];                                     // y1 < 2^387: its part above bit 256 is 131 bits, p2 < 2^260
+    sc_times_16c<5>(p2, &y1[8]);
+    c = 1;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        c += (u64)(k < 8 ? y1[k] : 0u) + K_L_SHL9[k] + (u32)~p2[k];
+        y2[k] = (u32)c;
+        c >>= 32;
+    }
+    // y2 < 2^262:  (y2 mod 2^252) - (y2 >> 252) * c, plus L when that borrows   (c = L - 2^252: the low four words of K_L)
+    const u32 n = (y2[7] >> 28) | (y2[8] << 4);
+    y2[7] &= 0x0fffffffu;
+    u32 r[8];
+    u64 mul = 0;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        mul += (u64)(i < 4 ? K_L[i] : 0u) * n;
+        const u64 d = (u64)y2[i] - (u32)mul - borrow;
+        mul >>= 32;
+        r[i] = (u32)d;
+        borrow = (u32)(d >> 63);
+    }
+    const u32 m = 0u - borrow;
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (u64)r[i] + (K_L[i] & m);
+        y[i] = (u32)c;
+        c >>= 32;
+    }
 }
 
 // z = x * y mod-ish L
