@@ -19,7 +19,7 @@
  * one.  Calls of up to 1024-2048 elements run ONE operation per wave (csrc/coop25519.cuh; verification: one launch of three
  * waves per signature -- hashing and the two square roots side by side, then the three scalar products side by side), the
  * inversion by division steps on a quad of lanes, and a call of one returns on a completion word its last kernel stores
- * behind the results: 43 us per ed25519_CreateKeyPair, 63 us per ed25519_SignMessage, 126 us per ed25519_VerifySignature, 128 /
+ * behind the results: 43 us per ed25519_CreateKeyPair, 62 us per ed25519_SignMessage, 127 us per ed25519_VerifySignature, 128 /
  * 103 us per ed25519_Verify_Init / _Check, end to end (profiles/r06_single_call.txt; round 5: 76 / 105 / 135, 131 / 133;
  * round 3: 0.18 / 0.21 / 0.65 ms).  The reference on one host core of the same box: 43 us per key pair and per signature,
  * 190 us per verification -- a single verification is faster here, a single signature is not.
