@@ -105,6 +105,14 @@ C25519_DEV void wave_fence()
 }
 
 // column sum -> reduced limb
+// ... as ONE asm statement (valu_gfx950.cuh: row_carry -- one hazard slot instead of the compiler's three).  Behind a product
+// level the compiler's own schedule is as good or better (it fills the slots with the next level's address arithmetic: +0.4 ..
+// +0.8 us per single call with the asm there); where a carry follows a carry -- the base-point ladder's "times 9" -- the asm
+// takes 7.7 us off one curve25519_dh_CalculatePublicKey (A/B on one box: tools/scratch/ab_single.py, profiles/r06_single_call_floor.txt).
+C25519_DEV u32 carry_packed(const Lane& L, u64 S)
+{
+    return row_carry(S, L.w, L.mask, L.mask_next, L.m1, L.m2);
+}
 C25519_DEV u32 carry(const Lane& L, u64 S)
 {
     const u32 l0 = (u32)S & L.mask;
@@ -444,7 +452,7 @@ C25519_DEV u32 ladder_step(u32* lds, const Lane& L, u32 v, u32 eq)
     if (BASE9) {
         wave_fence();
         const u32 k9 = (!L.upper && L.odd_row) ? 9u : 1u;
-        return carry(L, (u64)v * k9);
+        return carry_packed(L, (u64)v * k9);
     }
     return mul_level(lds, L, L.row, by_row(L, SLOT_ONE, SLOT_X1, SLOT_ONE, SLOT_ONE));
 }

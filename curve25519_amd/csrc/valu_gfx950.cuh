@@ -170,6 +170,38 @@ C25519_DEV void signal_done(const DoneWord& d)
     }
 }
 
+// The per-wave kernels' carry of a column sum across the lanes of a 16-lane row (coop25519.cuh: carry(); limb c of a field
+// element in lane c): S = l0 + 2^w l1 + 2^51 l2, limb_c = l0_c + l1_(c-1) + l2_(c-2), lanes 9 / 8, 9 wrapping into lanes 0 / 0, 1
+// times 19 (m1 / m2: 19 there, 0 elsewhere), then one more single-bit pass.  One asm statement, ordered so that every DPP move
+// reads a register written at least two instructions earlier (the hazard the compiler pads with s_nop: three a carry, one here):
+// 20 instructions + one s_nop -- a product level of a single call is ~64 instructions, and a call is up to 600 levels in a row.
+C25519_DEV u32 row_carry(u64 S, u32 w, u32 mask, u32 mask_next, u32 m1, u32 m2)
+{
+    u32 limb, l0, l1, l2, a, b;
+    asm("v_alignbit_b32 %[l1], %[Shi], %[Slo], %[w]\n\t"           // the low 32 bits of S >> w (w = 25 / 26, per lane)
+        "v_lshrrev_b32 %[l2], 19, %[Shi]\n\t"                       // S >> 51
+        "v_and_b32 %[l0], %[mask], %[Slo]\n\t"
+        "v_and_b32 %[l1], %[maskn], %[l1]\n\t"
+        "v_mov_b32_dpp %[a], %[l2] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %[b], %[l2] row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_lo_u32 %[b], %[b], %[m2]\n\t"
+        "v_add3_u32 %[limb], %[l0], %[a], %[b]\n\t"
+        "v_mov_b32_dpp %[a], %[l1] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %[b], %[l1] row_ror:7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_lo_u32 %[b], %[b], %[m1]\n\t"
+        "v_add3_u32 %[limb], %[limb], %[a], %[b]\n\t"
+        "v_lshrrev_b32 %[l1], %[w], %[limb]\n\t"                   // e: what the limb holds above its width
+        "v_and_b32 %[limb], %[limb], %[mask]\n\t"
+        "s_nop 0\n\t"
+        "v_mov_b32_dpp %[a], %[l1] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_dpp %[b], %[l1] row_ror:7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_lo_u32 %[b], %[b], %[m1]\n\t"
+        "v_add3_u32 %[limb], %[limb], %[a], %[b]"
+        : [limb] "=&v"(limb), [l0] "=&v"(l0), [l1] "=&v"(l1), [l2] "=&v"(l2), [a] "=&v"(a), [b] "=&v"(b)
+        : [Slo] "v"((u32)S), [Shi] "v"((u32)(S >> 32)), [w] "v"(w), [mask] "v"(mask), [maskn] "v"(mask_next), [m1] "v"(m1), [m2] "v"(m2));
+    return limb;
+}
+
 // acc += sum x[t]*y[t]: one asm statement per column, so the compiler cannot reassociate the chain (it would move
 // the carry-in to the end and re-create a separate 64-bit add) and does not pad every MAD with a wait state (it pads
 // asm boundaries only).  The SGPR pair receives the (never set) carry-out.

@@ -14,7 +14,7 @@
  * A single call is a device batch of one.  Calls of up to a few thousand elements run ONE operation per wave
  * (csrc/coop25519.cuh: a field element limb-per-lane, four field products at a time; curve25519_dh_CreateSharedKey: two waves
  * per element, a ladder step in two product levels), the inversion by division steps on a quad of lanes, and a call of one
- * returns on a completion word its kernel stores behind the result: 0.139 ms for curve25519_dh_CreateSharedKey, 0.13 ms for
+ * returns on a completion word its kernel stores behind the result: 0.139 ms for curve25519_dh_CreateSharedKey, 0.12 ms for
  * curve25519_dh_CalculatePublicKey, 0.04 ms for _fast, end to end (profiles/r06_single_call.txt; round 5: 0.17 / 0.16 /
  * 0.07; round 3's one-operation-per-lane pass: 0.76 ms) against 93 / 93 / 43 us for the reference on one host core of the
  * same box -- the literal drop-in call is correct and five times faster than it was; only _fast is faster than a host core.

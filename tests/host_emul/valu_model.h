@@ -86,6 +86,20 @@ inline u32 ch_32(u32 e, u32 f, u32 g) { return (e & f) | (~e & g); }            
 inline u32 maj_32(u32 a, u32 b, u32 c) { return (a & b) | (a & c) | (b & c); }                 // 0xe8
 struct DoneWord { u32* word; u32 seq; };                                                      // (valu_gfx950.cuh: the completion word)
 inline void signal_done(const DoneWord& d) { if (d.word) __atomic_store_n(d.word, d.seq, __ATOMIC_RELEASE); }
+// valu_gfx950.cuh: row_carry, the same moves in the same order (every lane of the wave meets them together)
+inline u32 row_carry(u64 S, u32 w, u32 mask, u32 mask_next, u32 m1, u32 m2)
+{
+    auto mv = [](u32 x, int ctrl) { return (u32)emul_coop::dpp(0u, x, ctrl, true); };
+    const u32 l0 = (u32)S & mask, l1 = (u32)(S >> w) & mask_next, l2 = (u32)(S >> 51);
+    u32 a = mv(l2, 0x112), b = mv(l2, 0x128);              // row_shr:2, row_ror:8
+    u32 limb = l0 + a + b * m2;
+    a = mv(l1, 0x111); b = mv(l1, 0x127);                  // row_shr:1, row_ror:7
+    limb += a + b * m1;
+    const u32 e = limb >> w;
+    limb &= mask;
+    a = mv(e, 0x111); b = mv(e, 0x127);
+    return limb + a + b * m1;
+}
 inline u64 pair64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 inline u32 alignbit32(u32 hi, u32 lo, int s) { return (u32)((((u64)hi << 32) | lo) >> s); }
 
