@@ -325,8 +325,8 @@ int run_batch(size_t n, std::initializer_list<Arr> arrays, Launch launch, const 
     const bool zero_copy = zero_copy_on && n <= ZERO_COPY_MAX_ROWS && row * n <= ZERO_COPY_MAX_BYTES && nchunks == 1 && !any_dev;
     static const bool done_word_on = [] { const char* e = getenv("C25519_AMD_DONE_WORD"); return !(e && atoi(e) == 0); }();
     if (zero_copy && n == 1 && done_word_on && !t.done_word) {
-        C25519_TRY(hipHostMalloc((void**)&t.done_word, 64, hipHostMallocDefault));
-        *t.done_word = 0;
+        if (hipHostMalloc((void**)&t.done_word, 64, hipHostMallocDefault) == hipSuccess) *t.done_word = 0;
+        else { (void)hipGetLastError(); t.done_word = nullptr; }      // (no word: the call waits for the stream's event, as it used to)
     }
     for (int l = 0; l < sets; l++)
         for (int a = 0; a < na; a++) {
